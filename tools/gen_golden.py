@@ -1,0 +1,393 @@
+#!/usr/bin/env python3
+"""
+Generate tests/golden/*.npz by running the REAL reference (read-only, at
+/root/reference) in the build container.  Nothing of the reference is copied:
+the fixtures hold inputs (occupancy grids, states, decision vectors) and the
+numbers the reference returned for them.
+
+    OMP_NUM_THREADS=1 python tools/gen_golden.py
+
+Fixture families:
+  g1_eval_s{k}.npz   per-evaluation cost / gradient / coefficients, M in {3,21,41}
+  g2_esdf_{k}.npz    occupancy -> esdf_map, esdf_grad_x/y, point lookups
+  g3_trace_{name}.npz L-BFGS-B iterate traces of plan()/warm_start_plan()/batch_plan()
+  g4_init.npz        generate_init_variables / batch_generate_init_variables
+  (g5 = trajectory evaluation arrays, stored inside the g3 files)
+
+Environment pinned: Python 3.10.12, NumPy 2.2.6, SciPy 1.15.3, OMP_NUM_THREADS=1.
+"""
+import os
+import sys
+import types
+
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+
+import numpy as np
+import scipy.optimize
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SCRIPTS = "/root/reference/src/planner/scripts"
+sys.path.insert(0, os.path.join(REF_SCRIPTS, "traj_planner"))
+sys.path.insert(0, os.path.join(REF_SCRIPTS, "map_server"))
+sys.path.insert(0, os.path.join(REPO, "neo-planner_amd"))
+
+import expert_planner as ref_ep            # noqa: E402  (the reference)
+import esdf as ref_esdf                    # noqa: E402  (the reference)
+from neo_planner_amd import synth          # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def yaml_config(**kw):
+    """launch/config/planner_config.yaml:2-13"""
+    c = types.SimpleNamespace(v_max=1.0, T_min=0.5, T_max=5.0, safe_dis=0.7, delta_t=0.1,
+                              weights=[1, 1, 1, 10000], init_wpts_mode='fixed', init_seg_len=2.0,
+                              init_wpts_num=2, init_T=2.5, collision_cost_tol=5, opt_tol=1e-2)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def ref_map(occ2d, res=synth.RES, origin=(0.0, -15.0)):
+    m = ref_esdf.ESDF()
+    m.occupancy_map_cb(synth.OccupancyGridMsg(occ2d, res, origin))
+    return m
+
+
+def T2tau(ts, cfg):
+    return -np.log((cfg.T_max - cfg.T_min) / (ts - cfg.T_min) - 1.0)
+
+
+# ---------------------------------------------------------------- G1
+def gen_g1():
+    cfg = yaml_config()
+    for seed in range(8):
+        occ = synth.occupancy_2d(seed, unknown_frac=0.02 if seed % 2 else 0.0)
+        m = ref_map(occ)
+        out = {"occ": occ, "res": synth.RES, "origin": np.array([0.0, -15.0]),
+               "weights": np.array(cfg.weights, dtype=np.float64),
+               "params": np.array([cfg.v_max, cfg.T_min, cfg.T_max, cfg.safe_dis, cfg.delta_t])}
+        for M in (3, 21, 41):
+            rng = np.random.default_rng(7000 + 100 * seed + M)
+            n_w = M - 1
+            lr = (4.0, 6.0) if M == 3 else (10.0, 28.0)
+            head, tail, wpts, ts = synth.replan_requests(seed * 10 + M, 1, n_w, D=2, length_range=lr,
+                                                         jitter=0.5 if M > 3 else 0.3)
+            head, tail, wpts, ts = head[0], tail[0], wpts[0], ts[0]
+            mode = seed % 4
+            if mode == 1:
+                ts = rng.uniform(0.6, 4.5, M)
+            elif mode == 2:                      # durations straddling k*delta_t
+                k = rng.integers(8, 40, M)
+                ts = k * cfg.delta_t + rng.choice([-1e-9, 1e-9, 3e-3, -3e-3], M)
+            elif mode == 3:                      # short pieces -> velocity violations; some points leave the map
+                ts = rng.uniform(0.55, 1.2, M)
+                wpts = wpts.copy()
+                wpts[1, : max(1, n_w // 4)] -= 16.0      # y < -15: out of range + negative-index truncation band
+                wpts[0, -1] += 0.0
+            if seed == 4:
+                head = head.copy()
+                head[2] = rng.normal(0, 0.5, 2)           # non-zero head acceleration
+                tail = tail.copy()
+                tail[1] = rng.normal(0, 0.4, 2)
+            planner = ref_ep.MinJerkPlanner(cfg)
+            planner.read_planning_conditions(m, head, tail, wpts, ts)
+            x = np.concatenate((wpts.reshape(-1), T2tau(ts, cfg)))
+            cost = planner.get_cost(x)
+            costs = planner.costs.copy()
+            coeffs = planner.coeffs.copy()
+            grad = planner.get_grad(x)
+            tag = f"M{M}_"
+            out[tag + "head"] = planner.head_state.copy()
+            out[tag + "tail"] = planner.tail_state.copy()
+            out[tag + "x"] = x
+            out[tag + "ts"] = planner.ts.copy()
+            out[tag + "coeffs"] = coeffs
+            out[tag + "costs"] = costs
+            out[tag + "cost"] = np.float64(cost)
+            out[tag + "grad"] = grad
+            out[tag + "grad_C"] = planner.grad_C.copy()
+            out[tag + "grad_T"] = planner.grad_T.copy()
+            print(f"g1 seed {seed} M {M}: cost {cost:.6g} costs {costs}")
+        np.savez_compressed(os.path.join(OUT, f"g1_eval_s{seed}.npz"), **out)
+
+
+# ---------------------------------------------------------------- G2
+def gen_g2():
+    specs = [dict(h=48, w=64, res=0.1, origin=(-1.3, 2.7), seed=0),
+             dict(h=40, w=30, res=0.25, origin=(0.0, -5.0), seed=1),
+             dict(h=33, w=57, res=0.05, origin=(3.3, 0.4), seed=2)]
+    for k, sp in enumerate(specs):
+        rng = np.random.default_rng(4200 + sp["seed"])
+        occ = np.zeros((sp["h"], sp["w"]), dtype=np.int8)
+        for _ in range(6):
+            r0 = rng.integers(0, sp["h"] - 3); c0 = rng.integers(0, sp["w"] - 3)
+            occ[r0:r0 + rng.integers(1, 6), c0:c0 + rng.integers(1, 6)] = 100
+        occ[0, :3] = 100                      # touches the border
+        occ[-1, -2:] = 100
+        unk = (rng.random(occ.shape) < 0.05) & (occ == 0)
+        occ[unk] = -1
+        occ[rng.random(occ.shape) < 0.01] = 50    # "probably free" values are free too (only ==100 counts)
+        m = ref_map(occ, sp["res"], sp["origin"])
+        # probes: inside, on cell borders, just below the origin (trunc toward zero), far outside
+        ext_x = sp["w"] * sp["res"]; ext_y = sp["h"] * sp["res"]
+        px = np.concatenate([rng.uniform(sp["origin"][0] - 0.3, sp["origin"][0] + ext_x + 0.3, 300),
+                             sp["origin"][0] + np.array([-0.999, -0.5, -1e-12, 0.0, 1e-12]) * sp["res"],
+                             sp["origin"][0] + ext_x + np.array([-1e-9, 0.0, 1e-9])])
+        py = np.concatenate([rng.uniform(sp["origin"][1] - 0.3, sp["origin"][1] + ext_y + 0.3, 300),
+                             sp["origin"][1] + np.array([0.3, -0.999, -0.2, 0.5, -1.0001]) * sp["res"],
+                             sp["origin"][1] + ext_y + np.array([-0.5, 0.5, -1e-9]) * sp["res"]])
+        pts = np.stack([px, py], axis=1)
+        dis = np.array([float(m.get_edt_dis(p)) for p in pts])
+        grd = np.array([[float(v) for v in m.get_edt_grad(p)] for p in pts])
+        col = np.array([bool(m.has_collision(p)) for p in pts])
+        np.savez_compressed(os.path.join(OUT, f"g2_esdf_{k}.npz"), occ=occ, res=sp["res"],
+                            origin=np.array(sp["origin"]), esdf_map=m.esdf_map,
+                            esdf_grad_x=m.esdf_grad_x, esdf_grad_y=m.esdf_grad_y,
+                            probe_pts=pts, probe_dis=dis, probe_grad=grd, probe_collision=col)
+        print(f"g2 {k}: {occ.shape} max dist {m.esdf_map.max():.3f}")
+
+
+# ---------------------------------------------------------------- G3 (+G5)
+class _Recorder:
+    """stands in for the `opt` module alias inside the reference module so the
+    L-BFGS-B iterates can be observed; forwards to scipy unchanged otherwise."""
+
+    def __init__(self):
+        self.runs = []
+
+    def minimize(self, fun, x0, **kw):
+        iterates = []
+        evals = []
+
+        def cb(intermediate_result):
+            iterates.append((np.array(intermediate_result.x), float(intermediate_result.fun)))
+
+        def fun_rec(x):
+            f = fun(x)
+            evals.append((np.array(x), float(f)))
+            return f
+        kw["callback"] = cb
+        res = scipy.optimize.minimize(fun_rec, x0, **kw)
+        self.runs.append(dict(x0=np.array(x0), iterates=iterates, evals=evals, res=res))
+        return res
+
+
+def local_target(m, cur, goal, v_move=0.8, step=5.0):
+    """ros_node/traj_planner_node.py:450-486 with seed 0 (no random shift)"""
+    if np.linalg.norm(goal - cur) < step:
+        return np.array([goal, [0.0, 0.0]])
+    along = (goal - cur) / np.linalg.norm(goal - cur)
+    lat = np.array([[along[1], -along[0]], [-along[1], along[0]]])
+    flag, dist = 0, 1.0
+    p = cur + step * along
+    while m.has_collision(p):
+        p = p + dist * lat[flag]
+        flag = 1 - flag
+        dist += 1.0
+    gdir = (goal - p) / np.linalg.norm(goal - p)
+    return np.array([p, v_move * gdir])
+
+
+def pack_runs(rec):
+    out = {"n_runs": len(rec.runs)}
+    for r, run in enumerate(rec.runs):
+        res = run["res"]
+        out[f"r{r}_x0"] = run["x0"]
+        out[f"r{r}_iter_x"] = np.array([it[0] for it in run["iterates"]]).reshape(len(run["iterates"]), -1)
+        out[f"r{r}_iter_f"] = np.array([it[1] for it in run["iterates"]])
+        out[f"r{r}_eval_x"] = np.array([e[0] for e in run["evals"]])
+        out[f"r{r}_eval_f"] = np.array([e[1] for e in run["evals"]])
+        out[f"r{r}_x"] = res.x
+        out[f"r{r}_fun"] = np.float64(res.fun)
+        out[f"r{r}_nit"] = res.nit
+        out[f"r{r}_nfev"] = res.nfev
+        out[f"r{r}_status"] = res.status
+        out[f"r{r}_message"] = str(res.message)
+    return out
+
+
+class _CoeffView(np.ndarray):
+    """TrajUtils.get_pos tests `self.coeffs == []` (traj_utils.py:93); with NumPy >= 2
+    that comparison raises for an ndarray.  Viewing the solved coefficients through this
+    subclass makes the test answer False again (what old NumPy did) without touching any
+    arithmetic."""
+
+    def __eq__(self, other):
+        if isinstance(other, list):
+            return False
+        return np.ndarray.__eq__(self, other)
+
+    __hash__ = None
+
+
+class _RefPlanner(ref_ep.MinJerkPlanner):
+    def get_coeffs(self, int_wpts, ts):
+        super().get_coeffs(int_wpts, ts)
+        self.coeffs = self.coeffs.view(_CoeffView)
+
+
+def run_traced(entry, cfg, m, head, tail, int_wpts=None, ts=None, np_seed=None):
+    rec = _Recorder()
+    ref_ep.opt = rec
+    planner = _RefPlanner(cfg)
+    if np_seed is not None:
+        np.random.seed(np_seed)
+    err = ""
+    try:
+        if entry == "plan":
+            planner.plan(m, head, tail)
+        elif entry == "warm":
+            planner.warm_start_plan(m, head, tail, int_wpts, ts)
+        elif entry == "batch":
+            planner.batch_plan(m, head, tail)
+        elif entry == "once":
+            planner.read_planning_conditions(m, head, tail, int_wpts, ts)
+            planner.plan_once()
+    except Exception as ex:       # the reference uses exceptions as control flow
+        err = f"{type(ex).__name__}:{ex}"
+    finally:
+        ref_ep.opt = scipy.optimize
+    out = pack_runs(rec)
+    out["error"] = err
+    out["final_int_wpts"] = np.array(planner.int_wpts)
+    out["final_ts"] = np.array(planner.ts)
+    out["iter_num"] = planner.iter_num
+    out["opt_running_times"] = planner.opt_running_times
+    if hasattr(planner, "weighted_cost"):
+        out["weighted_cost"] = np.array(planner.weighted_cost)
+        out["final_cost"] = np.float64(planner.final_cost)
+    if hasattr(planner, "costs"):
+        out["costs"] = np.array(planner.costs)
+    if not err or entry == "once":
+        # G5: evaluation of the final trajectory
+        try:
+            hz = 60 if planner.M <= 3 else 5          # keep the big-M fixtures small
+            out["state_cmd_hz"] = hz
+            out["state_cmd_60"] = planner.get_full_state_cmd(hz)
+            out["pos_array"] = planner.get_pos_array()
+            out["vel_array"] = planner.get_vel_array()
+            out["final_coeffs"] = np.array(planner.coeffs)
+        except Exception as ex:
+            print("   eval failed:", ex)
+    return out, planner
+
+
+def gen_g3():
+    cfg = yaml_config()
+    goal = np.array([30.0, 0.0])
+    n_fail = 0
+    for seed in range(6):
+        occ = synth.occupancy_2d(seed)
+        m = ref_map(occ)
+        head = np.array([[0.0, 0.0], [0.0, 0.0]])
+        tail = local_target(m, head[0], goal)
+        out, pl = run_traced("plan", cfg, m, head, tail, np_seed=100 + seed)
+        out.update(occ=occ, res=synth.RES, origin=np.array([0.0, -15.0]), head=head, tail=tail,
+                   entry="plan", np_seed=100 + seed)
+        np.savez_compressed(os.path.join(OUT, f"g3_trace_plan_s{seed}.npz"), **out)
+        print(f"g3 plan seed {seed}: runs {out['n_runs']} nit {out['r0_nit']} nfev {out['r0_nfev']} "
+              f"err '{out['error']}' final_cost {out.get('final_cost')}")
+        # second replan from a mid-trajectory state (non-zero head velocity), cfg-1 style chain
+        if not out["error"]:
+            st = out["state_cmd_60"]
+            idx = min(60, st.shape[0] - 1)
+            head2 = np.array([st[idx, 0], st[idx, 1]])
+            tail2 = local_target(m, head2[0], goal)
+            out2, _ = run_traced("plan", cfg, m, head2, tail2, np_seed=200 + seed)
+            out2.update(occ=occ, res=synth.RES, origin=np.array([0.0, -15.0]), head=head2, tail=tail2,
+                        entry="plan", np_seed=200 + seed)
+            np.savez_compressed(os.path.join(OUT, f"g3_trace_replan_s{seed}.npz"), **out2)
+            print(f"   replan: runs {out2['n_runs']} nit {out2['r0_nit']} err '{out2['error']}'")
+
+    # batch_plan (3 lateral candidates)
+    for seed in (1, 3):
+        occ = synth.occupancy_2d(seed)
+        m = ref_map(occ)
+        head = np.array([[0.5, 0.3], [0.4, 0.0]])
+        tail = local_target(m, head[0], goal)
+        out, _ = run_traced("batch", cfg, m, head, tail, np_seed=300 + seed)
+        out.update(occ=occ, res=synth.RES, origin=np.array([0.0, -15.0]), head=head, tail=tail,
+                   entry="batch", np_seed=300 + seed)
+        np.savez_compressed(os.path.join(OUT, f"g3_trace_batch_s{seed}.npz"), **out)
+        print(f"g3 batch seed {seed}: runs {out['n_runs']} err '{out['error']}' final_cost {out.get('final_cost')}")
+
+    # retry paths: targets placed so that the straight-line first attempt ends in collision
+    found = 0
+    for seed in range(40):
+        if found >= 2:
+            break
+        occ = synth.occupancy_2d(seed, count=40)
+        m = ref_map(occ)
+        boxes = synth.forest_boxes(seed, count=40)
+        cx, cy = boxes[0][0], boxes[0][1]
+        head = np.array([[cx - 2.5, cy], [0.5, 0.0]])
+        tail = np.array([[cx + 2.5, cy], [0.5, 0.0]])
+        if m.has_collision(head[0]) or m.has_collision(tail[0]):
+            continue
+        out, _ = run_traced("plan", cfg, m, head, tail, np_seed=400 + seed)
+        if out["n_runs"] < 2:
+            continue
+        out.update(occ=occ, res=synth.RES, origin=np.array([0.0, -15.0]), head=head, tail=tail,
+                   entry="plan", np_seed=400 + seed)
+        np.savez_compressed(os.path.join(OUT, f"g3_trace_retry_{found}.npz"), **out)
+        print(f"g3 retry {found} (seed {seed}): runs {out['n_runs']} err '{out['error']}'")
+        found += 1
+
+    # larger problems: M = 21 and M = 41 single plan_once from a jittered straight line
+    for M, seed in ((21, 0), (21, 1), (41, 2)):
+        occ = synth.occupancy_2d(seed)
+        m = ref_map(occ)
+        head, tail, wpts, ts = synth.replan_requests(900 + seed, 1, M - 1, D=2)
+        out, _ = run_traced("once", cfg, m, head[0][:2], tail[0][:2], wpts[0], ts[0])
+        out.update(occ=occ, res=synth.RES, origin=np.array([0.0, -15.0]), head=head[0][:2], tail=tail[0][:2],
+                   init_wpts=wpts[0], init_ts=ts[0], entry="once", np_seed=-1)
+        np.savez_compressed(os.path.join(OUT, f"g3_trace_once_M{M}_s{seed}.npz"), **out)
+        print(f"g3 once M {M} seed {seed}: nit {out['r0_nit']} nfev {out['r0_nfev']} err '{out['error']}' "
+              f"cost {out.get('final_cost')}")
+
+
+# ---------------------------------------------------------------- G4
+def gen_g4():
+    out = {}
+    k = 0
+    for mode, head, tail in (("fixed", [[0, 0], [0, 0]], [[5, 0], [0.8, 0]]),
+                             ("fixed", [[1.2, -0.7], [0.3, 0.1]], [[5.5, 2.0], [0.5, 0.5]]),
+                             ("adaptive", [[0, 0], [0, 0]], [[9.1, 3.0], [0, 0]]),
+                             ("adaptive", [[0, 0], [0, 0]], [[1.0, 0.5], [0, 0]])):
+        cfg = yaml_config(init_wpts_mode=mode)
+        pl = ref_ep.MinJerkPlanner(cfg)
+        h, t = np.array(head, dtype=float), np.array(tail, dtype=float)
+        w, ts = pl.generate_init_variables(h, t)
+        out[f"c{k}_mode"] = mode
+        out[f"c{k}_head"] = h
+        out[f"c{k}_tail"] = t
+        out[f"c{k}_wpts"] = w
+        out[f"c{k}_ts"] = ts
+        np.random.seed(77 + k)
+        w2, ts2 = pl.generate_init_variables(h, t, seed=2)
+        out[f"c{k}_wpts_seeded"] = w2
+        if mode == "fixed":
+            bw, bts = pl.batch_generate_init_variables(h, t)
+            out[f"c{k}_batch_wpts"] = bw
+            out[f"c{k}_batch_ts"] = bts
+        k += 1
+    out["n_cases"] = k
+    np.savez_compressed(os.path.join(OUT, "g4_init.npz"), **out)
+    print("g4 done")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4"]
+    if "g1" in which:
+        gen_g1()
+    if "g2" in which:
+        gen_g2()
+    if "g3" in which:
+        gen_g3()
+    if "g4" in which:
+        gen_g4()
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print(f"golden dir: {len(os.listdir(OUT))} files, {total / 1024:.1f} KiB")
