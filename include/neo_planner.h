@@ -1,0 +1,190 @@
+/*
+ * neo_planner.h -- C ABI of libneo_planner_hip.so (MI355X / gfx950).
+ *
+ * The reference (Amos-Chen98/neo-planner) has no FFI: its boundary is the Python
+ * object protocol between ros_node/traj_planner_node.py and
+ * traj_planner/expert_planner.py:MinJerkPlanner, and between MinJerkPlanner and
+ * map_server/esdf.py:ESDF.  This header is the boundary the MI355X path puts
+ * underneath that protocol; neo_planner_amd/planner.py binds it with ctypes and
+ * keeps the reference's method names.  Every entry point cites the reference code
+ * it replaces (paths relative to src/planner/scripts/).
+ *
+ * Conventions: plain C, int status return (0 = NEO_OK), caller-owned buffers,
+ * opaque context, no exceptions.  All arrays are C-contiguous.  A context owns one
+ * HIP stream; calls on one context are serialised, different contexts are
+ * independent.  Pointers are HOST pointers unless the argument is documented as a
+ * device pointer (the *_dev entry points take device pointers and are asynchronous
+ * on the context's stream).
+ *
+ * Decision vector layout (expert_planner.py:211, :540-541):
+ *   x[n] = [ int_wpts row-major (D, M-1) ; tau (M) ],  n = D*(M-1) + M.
+ * Boundary states: head[3][D], tail[3][D] = position, velocity, acceleration
+ *   (expert_planner.py:170-181).
+ */
+#ifndef NEO_PLANNER_H
+#define NEO_PLANNER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEO_ABI_VERSION 1
+#define NEO_MAX_PIECES 64 /* M: one lane per piece */
+#define NEO_MAX_DIM 3     /* D */
+#define NEO_LBFGS_M 10    /* maxcor (expert_planner.py:221) */
+
+typedef struct neo_ctx neo_ctx; /* opaque */
+
+/* status codes: per call (return value) and per trajectory (status[] arrays) */
+enum {
+  NEO_OK = 0,
+  NEO_ERR_INVALID = 1,      /* bad argument */
+  NEO_ERR_HIP = 2,          /* HIP runtime failure, see neo_last_error */
+  NEO_ERR_NO_MAP = 3,       /* scene id has no ESDF uploaded */
+  NEO_ERR_UNSUPPORTED = 4,
+};
+
+/* per-trajectory termination codes (neo_optimize_*): the ctypes host maps them to
+ * the reference's exceptions (expert_planner.py:236-237, :481). */
+enum {
+  NEO_TRAJ_CONVERGED_GRAD = 0,   /* max|g| <= gtol                 (L-BFGS-B "NORM OF PROJECTED GRADIENT") */
+  NEO_TRAJ_CONVERGED_F = 1,      /* rel. reduction of f <= ftol    (L-BFGS-B "REL_REDUCTION_OF_F")          */
+  NEO_TRAJ_ABNORMAL = 2,         /* line search failed with empty memory (L-BFGS-B "ABNORMAL")             */
+  NEO_TRAJ_MAXITER = 3,          /* iteration / evaluation cap                                                */
+  NEO_TRAJ_NUMERIC_RANGE = 4,    /* exp(-tau) overflow: the reference raises OverflowError (:481)            */
+  NEO_TRAJ_NONFINITE = 5,        /* NaN/Inf objective                                                         */
+};
+/* OR-ed into the code above when weighted collision cost > collision_cost_tol
+ * (expert_planner.py:235-237 raises ValueError("collision cost too large")). */
+#define NEO_TRAJ_FLAG_COLLISION 0x100
+
+/* ESDF lookup mode */
+enum {
+  NEO_INTERP_NEAREST_2D_REF = 0, /* esdf.py:53-82: nearest cell, int() truncation, gradient in m/cell */
+  NEO_INTERP_TRILINEAR_3D = 1,   /* north-star mode: trilinear distance + analytic gradient (m/m)     */
+};
+
+/* element type of an uploaded distance field / arithmetic of the sampling phase */
+enum { NEO_F64 = 0, NEO_F32 = 1, NEO_F16 = 2 };
+
+/* voxel order of a 3-D field in HBM */
+enum {
+  NEO_LAYOUT_LINEAR = 0, /* [z][y][x] */
+  NEO_LAYOUT_BRICK4 = 1, /* 4x4x4 bricks (256 B for f32), bricks in [bz][by][bx] order */
+};
+
+/* planner parameters: DefaultConfig / PlannerConfig fields (expert_planner.py:12-25,
+ * ros_node/traj_planner_node.py:32-46); real values launch/config/planner_config.yaml:2-13 */
+typedef struct neo_params {
+  double v_max;
+  double T_min;
+  double T_max;
+  double safe_dis;
+  double delta_t;
+  double weights[4]; /* energy, time, feasibility, collision */
+  double collision_cost_tol;
+  /* L-BFGS-B options, expert_planner.py:213-225 (tol=1e-4 -> ftol = gtol = 1e-4) */
+  double ftol;
+  double gtol;
+  int32_t maxls;   /* 20 */
+  int32_t maxiter; /* 15000 */
+  int32_t maxfun;  /* 15000 */
+  int32_t bugcompat_stale_T; /* 1 = reproduce expert_planner.py:528-533 */
+  int32_t sample_dtype;      /* NEO_F64 | NEO_F32: arithmetic of the sampled cost terms */
+  int32_t reserved;
+} neo_params;
+
+/* ---- lifetime ------------------------------------------------------------- */
+int neo_abi_version(void);
+/* device_id: HIP device ordinal.  stream: a hipStream_t to run on, or NULL to let the
+ * context create its own. */
+int neo_ctx_create(int device_id, void *stream, neo_ctx **out);
+int neo_ctx_destroy(neo_ctx *ctx);
+const char *neo_last_error(neo_ctx *ctx);
+/* fills p with the ROS YAML defaults */
+int neo_params_default(neo_params *p);
+int neo_params_set(neo_ctx *ctx, const neo_params *p);
+int neo_ctx_synchronize(neo_ctx *ctx);
+
+/* ---- maps (map_server/esdf.py) ------------------------------------------- */
+/* replaces ESDF.esdf_map / esdf_grad_x / esdf_grad_y (esdf.py:29-33) as looked up by
+ * get_edt_dis / get_edt_grad (esdf.py:53-82).  Arrays are [height][width] float64. */
+int neo_esdf_upload_2d(neo_ctx *ctx, int scene_id, const double *dist, const double *grad_x,
+                       const double *grad_y, int width, int height, double resolution,
+                       double origin_x, double origin_y);
+/* replaces ESDF.occupancy_map_cb (esdf.py:11-33): int8 occupancy (100 = occupied) ->
+ * exact EDT * resolution -> np.gradient, all on the device.  Optionally copies the three
+ * arrays back (any of the out pointers may be NULL). */
+int neo_esdf_build_2d(neo_ctx *ctx, int scene_id, const int8_t *occupancy, int width, int height,
+                      double resolution, double origin_x, double origin_y, double *out_dist,
+                      double *out_grad_x, double *out_grad_y);
+/* 3-D distance field for NEO_INTERP_TRILINEAR_3D.  dist is [nz][ny][nx] of src_dtype
+ * (host pointer, or device pointer when src_is_device != 0); it is stored on the device
+ * as store_dtype in `layout`. */
+int neo_esdf_upload_3d(neo_ctx *ctx, int scene_id, const void *dist, int src_dtype,
+                       int src_is_device, int nx, int ny, int nz, double resolution,
+                       const double origin[3], int store_dtype, int layout);
+int neo_esdf_drop(neo_ctx *ctx, int scene_id);
+/* point queries, replaces get_edt_dis / get_edt_grad called from Python
+ * (astar_planner.py:134, traj_planner_node.py:474).  pts[n][D_map], grad[n][D_map]. */
+int neo_esdf_query(neo_ctx *ctx, int scene_id, int n, const double *pts, double *dist, double *grad);
+
+/* ---- cost / gradient (expert_planner.py:539-585) --------------------------
+ * One evaluation of get_cost(x) and get_grad(x) for B trajectories of one scene.
+ *   x[B][n], head[B][3][D], tail[B][3][D]
+ *   cost[B]      = dot(costs, weights)                       (:558)
+ *   costs4[B][4] = unweighted [energy, time, feasibility, collision] (:549-552)
+ *   grad[B][n]                                               (:579)
+ *   coeffs[B][6M][D]  polynomial coefficients (:336)         (may be NULL)
+ *   status[B]    NEO_TRAJ_NUMERIC_RANGE or 0                 (may be NULL) */
+int neo_cost_grad_batch(neo_ctx *ctx, int scene_id, int B, int M, int D, const double *x,
+                        const double *head, const double *tail, double *cost, double *costs4,
+                        double *grad, double *coeffs, int32_t *status);
+/* same, device pointers, asynchronous on the context stream */
+int neo_cost_grad_batch_dev(neo_ctx *ctx, int scene_id, int B, int M, int D, const double *x,
+                            const double *head, const double *tail, double *cost, double *costs4,
+                            double *grad, double *coeffs, int32_t *status);
+
+/* ---- optimiser (expert_planner.py:205-237: plan_once) ----------------------
+ * Runs L-BFGS-B(maxcor 10, no bounds) from x to termination for every trajectory,
+ * entirely on the device.  scene_ids[B] selects the map per trajectory (NULL = all
+ * use `scene_id`).
+ *   x[B][n]         in: x0, out: final x (res.x)
+ *   costs4[B][4]    unweighted costs at the final x
+ *   costs4_last[B][4] unweighted costs at the LAST EVALUATED x -- what the reference
+ *                   reports as weighted_cost / final_cost (:233-234)   (may be NULL)
+ *   nit[B], nfev[B] L-BFGS-B iteration / evaluation counts (res.nit, res.nfev)
+ *   status[B]       NEO_TRAJ_* | NEO_TRAJ_FLAG_COLLISION */
+int neo_optimize_batch(neo_ctx *ctx, int scene_id, const int32_t *scene_ids, int B, int M, int D,
+                       double *x, const double *head, const double *tail, double *costs4,
+                       double *costs4_last, int32_t *nit, int32_t *nfev, int32_t *status);
+int neo_optimize_batch_dev(neo_ctx *ctx, int scene_id, const int32_t *scene_ids, int B, int M,
+                           int D, double *x, const double *head, const double *tail,
+                           double *costs4, double *costs4_last, int32_t *nit, int32_t *nfev,
+                           int32_t *status);
+/* bytes of device workspace neo_optimize_batch_dev keeps for B trajectories (L-BFGS
+ * history); allocated on first use and reused. */
+size_t neo_optimize_workspace_bytes(int B, int M, int D);
+
+/* ---- trajectory evaluation (traj_utils.py:85-222) --------------------------
+ * state[B][K][3][D] = position, velocity, acceleration at t_k = k / hz, k < K; rows with
+ * t_k >= sum(ts) are left zero and count[B] returns the valid number
+ * (= len(np.arange(0, sum(ts), 1/hz)), traj_utils.py:185).  x as above. */
+int neo_eval_traj_batch(neo_ctx *ctx, int B, int M, int D, const double *x, const double *head,
+                        const double *tail, double hz, int K, double *state, int32_t *count);
+
+/* ---- timing of the device work (bench.py) ----------------------------------
+ * When enabled, every kernel launch of the named family is bracketed by HIP events on
+ * the context stream; neo_profile_read returns launches and summed milliseconds. */
+enum { NEO_KERNEL_EVAL = 0, NEO_KERNEL_OPTIMIZE = 1, NEO_KERNEL_ESDF_BUILD = 2, NEO_KERNEL_COUNT = 3 };
+int neo_profile_enable(neo_ctx *ctx, int on);
+int neo_profile_read(neo_ctx *ctx, int kernel, int64_t *launches, double *total_ms);
+int neo_profile_reset(neo_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEO_PLANNER_H */

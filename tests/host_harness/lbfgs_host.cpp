@@ -1,0 +1,100 @@
+// TEST HARNESS ONLY (built by tests/test_lbfgs_host.py with g++, never part of the
+// shipped library): runs the product's L-BFGS control flow (csrc/neo_lbfgs.hpp,
+// csrc/neo_linesearch.hpp) on plain host arrays with a Python callback as the objective,
+// so that it can be compared against SciPy's L-BFGS-B iterate by iterate without a GPU.
+#include <cstring>
+#include <vector>
+
+#include "neo_lbfgs.hpp"
+
+extern "C" {
+typedef int (*eval_cb)(const double *x, int n, double *f, double *g, double *costs, void *user);
+}
+
+namespace {
+struct HostBackend {
+  using Vec = std::vector<double>;
+  int n, m;
+  eval_cb cb;
+  void *user;
+  std::vector<double> S, Y, scal;
+  HostBackend(int n_, int m_, eval_cb cb_, void *u)
+      : n(n_), m(m_), cb(cb_), user(u), S(size_t(n_) * m_), Y(size_t(n_) * m_), scal(2 * m_) {}
+  static void fit(Vec &v, int n) {
+    if ((int)v.size() != n) v.assign(n, 0.0);
+  }
+  double dot(const Vec &a, const Vec &b) {
+    double s = 0;
+    for (int i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+  }
+  double amax(const Vec &a) {
+    double s = 0;
+    for (int i = 0; i < n; ++i) s = fmax(s, fabs(a[i]));
+    return s;
+  }
+  void copy(Vec &d, const Vec &s) { d = s; }
+  void neg(Vec &d, const Vec &s) {
+    fit(d, n);
+    for (int i = 0; i < n; ++i) d[i] = -s[i];
+  }
+  void axpy(double a, const Vec &x, Vec &y) {
+    for (int i = 0; i < n; ++i) y[i] += a * x[i];
+  }
+  void lincomb(Vec &out, const Vec &a, double s, const Vec &b) {
+    fit(out, n);
+    for (int i = 0; i < n; ++i) out[i] = a[i] + s * b[i];
+  }
+  void scale(Vec &v, double s) {
+    for (int i = 0; i < n; ++i) v[i] *= s;
+  }
+  void hist_put(int slot, const Vec &s, const Vec &y) {
+    memcpy(&S[size_t(slot) * n], s.data(), n * sizeof(double));
+    memcpy(&Y[size_t(slot) * n], y.data(), n * sizeof(double));
+  }
+  void hist_get_s(int slot, Vec &v) { v.assign(&S[size_t(slot) * n], &S[size_t(slot) * n] + n); }
+  void hist_get_y(int slot, Vec &v) { v.assign(&Y[size_t(slot) * n], &Y[size_t(slot) * n] + n); }
+  void sput(int i, double v) { scal[i] = v; }
+  double sget(int i) { return scal[i]; }
+  int eval(const Vec &x, double &f, Vec &g, double costs[4]) {
+    fit(g, n);
+    return cb(x.data(), n, &f, g.data(), costs, user);
+  }
+};
+}  // namespace
+
+extern "C" {
+
+int lbfgs_host_minimize(int n, double *x, double ftol, double gtol, int maxls, int maxiter,
+                        int maxfun, int m, eval_cb cb, void *user, double *f_out, int *nit,
+                        int *nfev, int *status, double *costs, double *costs_last) {
+  HostBackend be(n, m, cb, user);
+  HostBackend::Vec xv(x, x + n);
+  neo::LbfgsOpts o{ftol, gtol, maxls, maxiter, maxfun, m};
+  neo::LbfgsResult res;
+  neo::lbfgs_minimize(be, xv, o, res);
+  memcpy(x, xv.data(), n * sizeof(double));
+  *f_out = res.f;
+  *nit = res.nit;
+  *nfev = res.nfev;
+  *status = res.status;
+  memcpy(costs, res.costs, sizeof(res.costs));
+  memcpy(costs_last, res.costs_last, sizeof(res.costs_last));
+  return 0;
+}
+
+// reverse-communication line search, state kept in a caller-provided 20-double blob
+int dcsrch_host(double *state, double f, double g, double *stp, int task, double ftol, double gtol,
+                double xtol, double stpmin, double stpmax) {
+  static_assert(sizeof(neo::LineSearch) <= 20 * sizeof(double), "state blob too small");
+  neo::LineSearch *L = reinterpret_cast<neo::LineSearch *>(state);
+  if (task == neo::LS_START) {
+    L->ftol = ftol;
+    L->gtol = gtol;
+    L->xtol = xtol;
+    L->stpmin = stpmin;
+    L->stpmax = stpmax;
+  }
+  return neo::dcsrch(*L, f, g, *stp, task);
+}
+}
