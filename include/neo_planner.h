@@ -151,7 +151,9 @@ int neo_cost_grad_batch_dev(neo_ctx *ctx, int scene_id, int B, int M, int D, con
 /* ---- optimiser (expert_planner.py:205-237: plan_once) ----------------------
  * Runs L-BFGS-B(maxcor 10, no bounds) from x to termination for every trajectory,
  * entirely on the device.  scene_ids[B] selects the map per trajectory (NULL = all
- * use `scene_id`).
+ * use `scene_id`); all maps of one call must be of the same kind and element type.
+ * The *_dev variant takes a DEVICE array of map-table slots (neo_scene_slot) in
+ * place of scene ids, and `scene_id` then only names the kind of map.
  *   x[B][n]         in: x0, out: final x (res.x)
  *   costs4[B][4]    unweighted costs at the final x
  *   costs4_last[B][4] unweighted costs at the LAST EVALUATED x -- what the reference
@@ -165,6 +167,9 @@ int neo_optimize_batch_dev(neo_ctx *ctx, int scene_id, const int32_t *scene_ids,
                            int D, double *x, const double *head, const double *tail,
                            double *costs4, double *costs4_last, int32_t *nit, int32_t *nfev,
                            int32_t *status);
+/* slot of a scene in the device-side map table, -1 if it has no map.  Slots change
+ * whenever a map is uploaded or dropped. */
+int neo_scene_slot(neo_ctx *ctx, int scene_id);
 /* bytes of device workspace neo_optimize_batch_dev keeps for B trajectories (L-BFGS
  * history); allocated on first use and reused. */
 size_t neo_optimize_workspace_bytes(int B, int M, int D);

@@ -1,0 +1,1224 @@
+// neo_kernels.hip -- kernels and C ABI of libneo_planner_hip.so (gfx950 only).
+//
+//   eval_kernel      get_cost + get_grad for a batch            (expert_planner.py:539-585)
+//   optimize_kernel  plan_once: the whole L-BFGS-B run on-chip  (expert_planner.py:205-237)
+//   query_kernel     ESDF point lookups                         (map_server/esdf.py:53-82)
+//   edt / gradient   ESDF.occupancy_map_cb                      (map_server/esdf.py:11-33)
+//   traj_state_kernel get_full_state_cmd                        (traj_utils.py:85-195)
+//
+// One 64-lane workgroup (= one wavefront) per trajectory: the optimiser never leaves the chip,
+// finished trajectories free their slot for the next ones, no host round trips.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/neo_planner.h"
+#include "neo_device.hpp"
+#include "neo_lbfgs.hpp"
+
+namespace neo {
+
+// ------------------------------------------------------------------ device backend of the optimiser
+template <int D, typename Real, class MapT, class LookupT>
+struct DevBackend {
+  struct Vec {
+    double v[kSlots];
+  };
+  Traj<D> t;
+  const DevParams &prm;
+  const MapT &map;
+  double *xs;    // LDS [256]: FLAT <-> PIECE staging
+  double *sc;    // LDS [2m]: rho / alpha of the two-loop recursion
+  double *hist;  // global [2][m][npad] for this trajectory
+  int npad, nsl, m;
+  double *coeff_out;  // optional [6M][D] (eval kernel)
+
+  __device__ DevBackend(const DevParams &p, const MapT &mp) : prm(p), map(mp) {}
+
+  __device__ __forceinline__ double dot(const Vec &a, const Vec &b) const {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k)
+      if (k < nsl) s += a.v[k] * b.v[k];
+    return uniform(wave_sum(s));
+  }
+  __device__ __forceinline__ double amax(const Vec &a) const {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k)
+      if (k < nsl) s = fmax(s, fabs(a.v[k]));
+    return uniform(wave_max(s));
+  }
+  __device__ __forceinline__ void copy(Vec &d, const Vec &s) const {
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) d.v[k] = s.v[k];
+  }
+  __device__ __forceinline__ void neg(Vec &d, const Vec &s) const {
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) d.v[k] = -s.v[k];
+  }
+  __device__ __forceinline__ void axpy(double a, const Vec &x, Vec &y) const {
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) y.v[k] += a * x.v[k];
+  }
+  __device__ __forceinline__ void lincomb(Vec &o, const Vec &a, double s, const Vec &b) const {
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) o.v[k] = a.v[k] + s * b.v[k];
+  }
+  __device__ __forceinline__ void scale(Vec &v, double s) const {
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) v.v[k] *= s;
+  }
+  __device__ __forceinline__ void hist_put(int slot, const Vec &s, const Vec &y) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k)
+      if (k < nsl) {
+        hist[(size_t)slot * npad + k * kWave + lane] = s.v[k];
+        hist[(size_t)(m + slot) * npad + k * kWave + lane] = y.v[k];
+      }
+  }
+  __device__ __forceinline__ void hist_get(int row, Vec &v) const {
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) v.v[k] = (k < nsl) ? hist[(size_t)row * npad + k * kWave + lane] : 0.0;
+  }
+  __device__ __forceinline__ void hist_get_s(int slot, Vec &v) const { hist_get(slot, v); }
+  __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
+  __device__ __forceinline__ void sput(int i, double v) {
+    sc[i] = v;
+    __syncthreads();
+  }
+  __device__ __forceinline__ double sget(int i) const { return sc[i]; }
+
+  // FLAT x -> PIECE inputs
+  __device__ __forceinline__ void scatter_x(const Vec &x) {
+    const int lane = lane_id();
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k)
+      if (k * kWave + lane < t.n) xs[k * kWave + lane] = x.v[k];
+    __syncthreads();
+    const int M = t.M;
+    const bool act = lane < M;
+    t.tau = act ? xs[t.nq + lane] : 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      t.P0[d] = (lane == 0 || !act) ? t.head[0][d] : xs[d * (M - 1) + lane - 1];
+      t.P1[d] = (lane >= M - 1) ? t.tail[0][d] : xs[d * (M - 1) + lane];
+    }
+  }
+
+  // one evaluation of cost and gradient (get_cost + get_grad, :539-585)
+  __device__ __forceinline__ int eval(const Vec &x, double &f, Vec &g, double (&costs)[4]) {
+    const int lane = lane_id();
+    scatter_x(x);
+    double energy, tsum;
+    const int st = minco_forward<D>(t, prm, energy, tsum);
+    if (st != 0) {
+      f = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) costs[k] = 0.0;
+      return st;
+    }
+    if (coeff_out != nullptr && lane < t.M) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int d = 0; d < D; ++d) coeff_out[(size_t)(6 * lane + k) * D + d] = t.c[k][d];
+    }
+    double gC[6][D], gT = 0.0, cf, ck;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int d = 0; d < D; ++d) gC[k][d] = 0.0;
+    LookupT lk(map);
+    minco_sample<Real, D, LookupT>(t, prm, lk, gC, gT, cf, ck);
+    costs[0] = uniform(energy);
+    costs[1] = uniform(tsum);
+    costs[2] = uniform(cf);
+    costs[3] = uniform(ck);
+    f = costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3];
+    double gq[D], gtau;
+    minco_backward<D>(t, prm, gC, gT, gq, gtau);
+    // PIECE -> FLAT
+    __syncthreads();
+    if (lane >= 1 && lane < t.M) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) xs[d * (t.M - 1) + lane - 1] = gq[d];
+    }
+    if (lane < t.M) xs[t.nq + lane] = gtau;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) g.v[k] = (k * kWave + lane < t.n) ? xs[k * kWave + lane] : 0.0;
+    return 0;
+  }
+};
+
+template <int D>
+__device__ __forceinline__ void load_boundary(Traj<D> &t, const double *head, const double *tail, int M) {
+  t.M = M;
+  t.nq = D * (M - 1);
+  t.n = t.nq + M;
+  int L = kWave / M;
+  t.L = L < 1 ? 1 : L;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      t.head[k][d] = head[k * D + d];
+      t.tail[k][d] = tail[k * D + d];
+    }
+}
+
+struct MapTable {
+  const void *maps;  // array of MapT indexed by scene slot
+};
+
+// ------------------------------------------------------------------ kernels
+template <int D, typename Real, class MapT, class LookupT>
+__global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm, MapT map,
+                                                      const double *__restrict__ x,
+                                                      const double *__restrict__ head,
+                                                      const double *__restrict__ tail,
+                                                      double *__restrict__ cost, double *__restrict__ costs4,
+                                                      double *__restrict__ grad, double *__restrict__ coeffs,
+                                                      int *__restrict__ status) {
+  __shared__ double xs[kSlots * kWave];
+  __shared__ double sc[2 * NEO_LBFGS_M];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  using BE = DevBackend<D, Real, MapT, LookupT>;
+  BE be(prm, map);
+  be.xs = xs;
+  be.sc = sc;
+  be.hist = nullptr;
+  be.m = NEO_LBFGS_M;
+  load_boundary<D>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
+  const int n = be.t.n;
+  be.nsl = (n + kWave - 1) / kWave;
+  be.npad = be.nsl * kWave;
+  be.coeff_out = coeffs ? coeffs + (size_t)b * 6 * M * D : nullptr;
+  const int lane = lane_id();
+  typename BE::Vec xv, gv;
+#pragma unroll
+  for (int k = 0; k < kSlots; ++k) xv.v[k] = (k * kWave + lane < n) ? x[(size_t)b * n + k * kWave + lane] : 0.0;
+  double f, costs[4];
+  const int st = be.eval(xv, f, gv, costs);
+#pragma unroll
+  for (int k = 0; k < kSlots; ++k)
+    if (k * kWave + lane < n) grad[(size_t)b * n + k * kWave + lane] = gv.v[k];
+  if (lane == 0) {
+    cost[b] = f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) costs4[(size_t)b * 4 + k] = costs[k];
+    if (status) status[b] = st;
+  }
+}
+
+template <int D, typename Real, class MapT, class LookupT>
+__global__ __launch_bounds__(kWave) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
+                                                          const int *__restrict__ scene_slot,
+                                                          double *__restrict__ x,
+                                                          const double *__restrict__ head,
+                                                          const double *__restrict__ tail,
+                                                          double *__restrict__ hist_ws,
+                                                          double *__restrict__ costs4,
+                                                          double *__restrict__ costs4_last,
+                                                          int *__restrict__ nit, int *__restrict__ nfev,
+                                                          int *__restrict__ status) {
+  __shared__ double xs[kSlots * kWave];
+  __shared__ double sc[2 * NEO_LBFGS_M];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  using BE = DevBackend<D, Real, MapT, LookupT>;
+  const MapT map = maps[scene_slot ? scene_slot[b] : 0];
+  BE be(prm, map);
+  be.xs = xs;
+  be.sc = sc;
+  be.m = NEO_LBFGS_M;
+  be.coeff_out = nullptr;
+  load_boundary<D>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
+  const int n = be.t.n;
+  be.nsl = (n + kWave - 1) / kWave;
+  be.npad = be.nsl * kWave;
+  be.hist = hist_ws + (size_t)b * 2 * NEO_LBFGS_M * be.npad;
+  const int lane = lane_id();
+  typename BE::Vec xv;
+#pragma unroll
+  for (int k = 0; k < kSlots; ++k) xv.v[k] = (k * kWave + lane < n) ? x[(size_t)b * n + k * kWave + lane] : 0.0;
+  LbfgsOpts o{prm.ftol, prm.gtol, prm.maxls, prm.maxiter, prm.maxfun, NEO_LBFGS_M};
+  LbfgsResult res;
+  lbfgs_minimize(be, xv, o, res);
+#pragma unroll
+  for (int k = 0; k < kSlots; ++k)
+    if (k * kWave + lane < n) x[(size_t)b * n + k * kWave + lane] = xv.v[k];
+  if (lane == 0) {
+    int st = res.status;
+    // weighted collision cost of the last evaluated x against the tolerance (:233-237)
+    if (res.costs_last[3] * prm.w[3] > prm.coll_tol) st |= NEO_TRAJ_FLAG_COLLISION;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      costs4[(size_t)b * 4 + k] = res.costs[k];
+      if (costs4_last) costs4_last[(size_t)b * 4 + k] = res.costs_last[k];
+    }
+    nit[b] = res.nit;
+    nfev[b] = res.nfev;
+    status[b] = st;
+  }
+}
+
+template <typename Real, class MapT, class LookupT, int DM>
+__global__ void query_kernel(int n, MapT map, const double *__restrict__ pts, double *__restrict__ dist,
+                             double *__restrict__ grad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Real pos[DM], g[DM];
+#pragma unroll
+  for (int d = 0; d < DM; ++d) pos[d] = (Real)pts[(size_t)i * DM + d];
+  bool inside;
+  LookupT lk(map);
+  const Real v = lk.template fetch<DM>(pos, g, inside);
+  dist[i] = (double)v;
+  if (grad)
+#pragma unroll
+    for (int d = 0; d < DM; ++d) grad[(size_t)i * DM + d] = (double)g[d];
+}
+
+// ---- ESDF construction (esdf.py:23-33) ------------------------------------
+// exact Euclidean distance transform of the free cells to the nearest occupied cell, two
+// separable passes over integer squared distances (Felzenszwalb & Huttenlocher lower envelope),
+// then sqrt * resolution and numpy.gradient with unit spacing.
+constexpr int kEdtInf = 1 << 28;
+
+__global__ void edt_columns_kernel(const int8_t *__restrict__ occ, int W, int H, int *__restrict__ g) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= W) return;
+  int d = kEdtInf;
+  for (int y = 0; y < H; ++y) {
+    d = (occ[(size_t)y * W + x] == 100) ? 0 : (d >= kEdtInf ? kEdtInf : d + 1);
+    g[(size_t)y * W + x] = d;
+  }
+  d = kEdtInf;
+  for (int y = H - 1; y >= 0; --y) {
+    d = (occ[(size_t)y * W + x] == 100) ? 0 : (d >= kEdtInf ? kEdtInf : d + 1);
+    const int cur = g[(size_t)y * W + x];
+    g[(size_t)y * W + x] = cur < d ? cur : d;
+  }
+}
+
+// one thread per row; v/z scratch rows live in global memory (W ints / W+1 doubles per row)
+__global__ void edt_rows_kernel(const int *__restrict__ g, int W, int H, double res, int *__restrict__ vbuf,
+                                double *__restrict__ zbuf, double *__restrict__ dist) {
+  const int y = blockIdx.x * blockDim.x + threadIdx.x;
+  if (y >= H) return;
+  const int *f = g + (size_t)y * W;
+  int *v = vbuf + (size_t)y * W;
+  double *z = zbuf + (size_t)y * (W + 1);
+  int k = -1;
+  for (int q = 0; q < W; ++q) {
+    if (f[q] >= kEdtInf) continue;
+    const double fq = (double)f[q] * (double)f[q] + (double)q * q;
+    double s = 0.0;
+    while (k >= 0) {
+      const int p = v[k];
+      const double fp = (double)f[p] * (double)f[p] + (double)p * p;
+      s = (fq - fp) / (2.0 * q - 2.0 * p);
+      if (s <= z[k]) {
+        --k;
+      } else {
+        break;
+      }
+    }
+    ++k;
+    v[k] = q;
+    z[k] = (k == 0) ? -1.0e300 : s;
+    z[k + 1] = 1.0e300;
+  }
+  double *out = dist + (size_t)y * W;
+  if (k < 0) {  // no obstacle anywhere in this row's columns
+    for (int q = 0; q < W; ++q) out[q] = 1.0e300;
+    return;
+  }
+  int j = 0;
+  for (int q = 0; q < W; ++q) {
+    while (z[j + 1] < (double)q) ++j;
+    const long long p = v[j];
+    const long long dq = q - p;
+    const long long sq = dq * dq + (long long)f[p] * f[p];
+    out[q] = sqrt((double)sq) * res;
+  }
+}
+
+// numpy.gradient, unit spacing: central differences inside, one-sided at the borders
+__global__ void gradient_pack_kernel(const double *__restrict__ dist, int W, int H, double4 *__restrict__ rec,
+                                     double *__restrict__ gx_out, double *__restrict__ gy_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= W * H) return;
+  const int y = i / W, x = i - y * W;
+  double gx, gy;
+  if (W == 1) gx = 0.0;
+  else if (x == 0) gx = dist[i + 1] - dist[i];
+  else if (x == W - 1) gx = dist[i] - dist[i - 1];
+  else gx = (dist[i + 1] - dist[i - 1]) / 2.0;
+  if (H == 1) gy = 0.0;
+  else if (y == 0) gy = dist[i + W] - dist[i];
+  else if (y == H - 1) gy = dist[i] - dist[i - W];
+  else gy = (dist[i + W] - dist[i - W]) / 2.0;
+  rec[i] = make_double4(dist[i], gx, gy, 0.0);
+  if (gx_out) gx_out[i] = gx;
+  if (gy_out) gy_out[i] = gy;
+}
+
+__global__ void pack2d_kernel(const double *__restrict__ dist, const double *__restrict__ gx,
+                              const double *__restrict__ gy, int n, double4 *__restrict__ rec) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) rec[i] = make_double4(dist[i], gx[i], gy[i], 0.0);
+}
+
+// 3-D field: convert element type and (optionally) re-tile into 4x4x4 bricks
+template <typename SrcT, typename DstT>
+__global__ void pack3d_kernel(const SrcT *__restrict__ src, int nx, int ny, int nz, int layout, int bx, int by,
+                              DstT *__restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)nx * ny * nz;
+  if (i >= total) return;
+  const int ix = (int)(i % nx), iy = (int)((i / nx) % ny), iz = (int)(i / ((size_t)nx * ny));
+  size_t o = i;
+  if (layout == 1) {
+    const size_t brick = ((size_t)(iz >> 2) * by + (iy >> 2)) * bx + (ix >> 2);
+    o = brick * 64 + ((iz & 3) << 4) + ((iy & 3) << 2) + (ix & 3);
+  }
+  const float v = (float)src[i];
+  if constexpr (sizeof(DstT) == 2)
+    dst[o] = __float2half(v);
+  else
+    dst[o] = (DstT)v;
+}
+
+// get_full_state_cmd (traj_utils.py:85-195): one wavefront per trajectory solves the
+// coefficients, then its lanes walk the sample times.
+template <int D>
+__global__ __launch_bounds__(kWave) void traj_state_kernel(int B, int M, DevParams prm,
+                                                            const double *__restrict__ x,
+                                                            const double *__restrict__ head,
+                                                            const double *__restrict__ tail, double hz, int K,
+                                                            double *__restrict__ state, int *__restrict__ count) {
+  __shared__ double xs[kSlots * kWave];
+  __shared__ double sc[2 * NEO_LBFGS_M];
+  __shared__ double cs[kWave * 6 * D];
+  __shared__ double tcum[kWave + 1];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  struct NoMap {};
+  struct NoLookup {
+    __device__ explicit NoLookup(const NoMap &) {}
+  };
+  DevParams p = prm;
+  NoMap nm;
+  DevBackend<D, double, NoMap, NoLookup> be(p, nm);
+  be.xs = xs;
+  be.sc = sc;
+  be.hist = nullptr;
+  be.m = NEO_LBFGS_M;
+  be.coeff_out = nullptr;
+  load_boundary<D>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
+  const int n = be.t.n;
+  be.nsl = (n + kWave - 1) / kWave;
+  const int lane = lane_id();
+  typename DevBackend<D, double, NoMap, NoLookup>::Vec xv;
+#pragma unroll
+  for (int k = 0; k < kSlots; ++k) xv.v[k] = (k * kWave + lane < n) ? x[(size_t)b * n + k * kWave + lane] : 0.0;
+  be.scatter_x(xv);
+  double e, ts;
+  const int st = minco_forward<D>(be.t, p, e, ts);
+  if (st != 0) {
+    if (lane == 0) count[b] = -1;
+    return;
+  }
+  if (lane < M) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int d = 0; d < D; ++d) cs[(lane * 6 + k) * D + d] = be.t.c[k][d];
+  }
+  // sequential prefix sums like Python's sum(ts[:k]) (traj_utils.py:98-101)
+  if (lane == 0) tcum[0] = 0.0;
+  for (int pce = 0; pce < M; ++pce) {
+    const double Tp = rdlane(be.t.T, pce);
+    if (lane == 0) tcum[pce + 1] = tcum[pce] + Tp;
+  }
+  __syncthreads();
+  const double total = tcum[M];
+  const double step = 1.0 / hz;
+  const int cnt = (int)ceil(total / step);  // len(np.arange(0, total, 1/hz))
+  if (lane == 0) count[b] = cnt;
+  for (int k = lane; k < K; k += kWave) {
+    double *out = state + ((size_t)b * K + k) * 3 * D;
+    if (k >= cnt) {
+#pragma unroll
+      for (int q = 0; q < 3 * D; ++q) out[q] = 0.0;
+      continue;
+    }
+    double tt = (double)k * step;
+    if (tt > total) tt = total;
+    int pc = 0;
+    while (pc < M - 1 && tcum[pc + 1] < tt) ++pc;
+    const double T = tt - tcum[pc];
+    const double T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const double c0 = cs[(pc * 6 + 0) * D + d], c1 = cs[(pc * 6 + 1) * D + d], c2 = cs[(pc * 6 + 2) * D + d];
+      const double c3 = cs[(pc * 6 + 3) * D + d], c4 = cs[(pc * 6 + 4) * D + d], c5 = cs[(pc * 6 + 5) * D + d];
+      out[0 * D + d] = c0 + c1 * T + c2 * T2 + c3 * T3 + c4 * T4 + c5 * T5;
+      out[1 * D + d] = c1 + 2.0 * c2 * T + 3.0 * c3 * T2 + 4.0 * c4 * T3 + 5.0 * c5 * T4;
+      out[2 * D + d] = 2.0 * c2 + 6.0 * c3 * T + 12.0 * c4 * T2 + 20.0 * c5 * T3;
+    }
+  }
+}
+
+}  // namespace neo
+
+// =================================================================== host side
+using namespace neo;
+
+namespace {
+
+struct MapEntry {
+  int kind = -1;  // 0 = 2-D reference map, 1 = 3-D field
+  int elem = NEO_F64;
+  void *data = nullptr;  // device
+  Map2D m2{};
+  Map3D m3{};
+  int slot = -1;  // index into the device-side map table
+};
+
+struct ProfileSlot {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  int64_t launches = 0;
+  double ms = 0.0;
+};
+
+}  // namespace
+
+struct neo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  neo_params params{};
+  DevParams dev{};
+  std::map<int, MapEntry> maps;
+  std::string err;
+  std::mutex mu;
+  // optimiser workspace
+  double *hist = nullptr;
+  size_t hist_bytes = 0;
+  // device-side table of maps (rebuilt when a map changes)
+  void *table2d = nullptr, *table3d = nullptr;
+  int n2d = 0, n3d = 0;
+  bool table_dirty = true;
+  // scratch for the host-pointer entry points
+  void *scratch = nullptr;
+  size_t scratch_bytes = 0;
+  bool profile = false;
+  ProfileSlot prof[NEO_KERNEL_COUNT];
+};
+
+namespace {
+
+int fail(neo_ctx *c, int code, const std::string &msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                     \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(c, NEO_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));       \
+  } while (0)
+
+void fill_dev_params(neo_ctx *c) {
+  const neo_params &p = c->params;
+  DevParams &d = c->dev;
+  d.v_max = p.v_max;
+  d.T_min = p.T_min;
+  d.T_max = p.T_max;
+  d.safe_dis = p.safe_dis;
+  d.delta_t = p.delta_t;
+  for (int k = 0; k < 4; ++k) d.w[k] = p.weights[k];
+  d.coll_tol = p.collision_cost_tol;
+  d.ftol = p.ftol;
+  d.gtol = p.gtol;
+  d.maxls = p.maxls;
+  d.maxiter = p.maxiter;
+  d.maxfun = p.maxfun;
+  d.stale_T = p.bugcompat_stale_T;
+}
+
+struct ProfScope {
+  neo_ctx *c;
+  int k;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(neo_ctx *c_, int k_) : c(c_), k(k_) {
+    if (c->profile) {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, c->stream);
+    }
+  }
+  ~ProfScope() {
+    if (c->profile) {
+      hipEventRecord(b, c->stream);
+      c->prof[k].pending.emplace_back(a, b);
+    }
+  }
+};
+
+int ensure_scratch(neo_ctx *c, size_t bytes) {
+  if (bytes <= c->scratch_bytes) return NEO_OK;
+  if (c->scratch) hipFree(c->scratch);
+  c->scratch = nullptr;
+  c->scratch_bytes = 0;
+  HIPCHK(c, hipMalloc(&c->scratch, bytes));
+  c->scratch_bytes = bytes;
+  return NEO_OK;
+}
+
+// bump allocator over the scratch buffer
+struct Carver {
+  char *base;
+  size_t off = 0;
+  explicit Carver(void *b) : base(static_cast<char *>(b)) {}
+  template <typename T>
+  T *take(size_t count) {
+    off = (off + 255) & ~size_t(255);
+    T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+int rebuild_tables(neo_ctx *c) {
+  if (!c->table_dirty) return NEO_OK;
+  std::vector<Map2D> t2;
+  std::vector<Map3D> t3;
+  for (auto &kv : c->maps) {
+    MapEntry &e = kv.second;
+    if (e.kind == 0) {
+      e.slot = (int)t2.size();
+      t2.push_back(e.m2);
+    } else if (e.kind == 1) {
+      e.slot = (int)t3.size();
+      t3.push_back(e.m3);
+    }
+  }
+  if (c->table2d) hipFree(c->table2d);
+  if (c->table3d) hipFree(c->table3d);
+  c->table2d = c->table3d = nullptr;
+  if (!t2.empty()) {
+    HIPCHK(c, hipMalloc(&c->table2d, t2.size() * sizeof(Map2D)));
+    HIPCHK(c, hipMemcpyAsync(c->table2d, t2.data(), t2.size() * sizeof(Map2D), hipMemcpyHostToDevice, c->stream));
+  }
+  if (!t3.empty()) {
+    HIPCHK(c, hipMalloc(&c->table3d, t3.size() * sizeof(Map3D)));
+    HIPCHK(c, hipMemcpyAsync(c->table3d, t3.data(), t3.size() * sizeof(Map3D), hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->n2d = (int)t2.size();
+  c->n3d = (int)t3.size();
+  c->table_dirty = false;
+  return NEO_OK;
+}
+
+int check_shape(neo_ctx *c, int B, int M, int D) {
+  if (!c) return NEO_ERR_INVALID;
+  if (B < 0 || M < 1 || M > NEO_MAX_PIECES || D < 2 || D > NEO_MAX_DIM)
+    return fail(c, NEO_ERR_INVALID, "shape out of range (1 <= M <= 64, D in {2,3})");
+  if (D * (M - 1) + M > kSlots * kWave) return fail(c, NEO_ERR_INVALID, "n = D(M-1)+M exceeds 256");
+  return NEO_OK;
+}
+
+// ---- dispatch over (D, sample dtype, map kind, element type) -------------------
+template <int D, typename Real>
+int launch_eval_2d(neo_ctx *c, const MapEntry &e, int B, int M, const double *x, const double *head,
+                   const double *tail, double *cost, double *costs4, double *grad, double *coeffs, int *status) {
+  hipLaunchKernelGGL((eval_kernel<D, Real, Map2D, Lookup2D<Real>>), dim3(B), dim3(kWave), 0, c->stream, B, M,
+                     c->dev, e.m2, x, head, tail, cost, costs4, grad, coeffs, status);
+  return NEO_OK;
+}
+template <typename Real, typename E>
+int launch_eval_3d(neo_ctx *c, const MapEntry &e, int B, int M, const double *x, const double *head,
+                   const double *tail, double *cost, double *costs4, double *grad, double *coeffs, int *status) {
+  hipLaunchKernelGGL((eval_kernel<3, Real, Map3D, Lookup3D<Real, E>>), dim3(B), dim3(kWave), 0, c->stream, B, M,
+                     c->dev, e.m3, x, head, tail, cost, costs4, grad, coeffs, status);
+  return NEO_OK;
+}
+
+int dispatch_eval(neo_ctx *c, const MapEntry &e, int B, int M, int D, const double *x, const double *head,
+                  const double *tail, double *cost, double *costs4, double *grad, double *coeffs, int *status) {
+  const bool f32 = c->params.sample_dtype == NEO_F32;
+  if (e.kind == 0) {
+    if (D == 2)
+      return f32 ? launch_eval_2d<2, float>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status)
+                 : launch_eval_2d<2, double>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status);
+    return f32 ? launch_eval_2d<3, float>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status)
+               : launch_eval_2d<3, double>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status);
+  }
+  if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
+  if (e.elem == NEO_F32)
+    return f32 ? launch_eval_3d<float, float>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status)
+               : launch_eval_3d<double, float>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status);
+  return f32 ? launch_eval_3d<float, __half>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status)
+             : launch_eval_3d<double, __half>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status);
+}
+
+template <int D, typename Real, class MapT, class LookupT>
+int launch_opt(neo_ctx *c, const void *table, const int *slots, int B, int M, double *x, const double *head,
+               const double *tail, double *costs4, double *costs4_last, int *nit, int *nfev, int *status) {
+  hipLaunchKernelGGL((optimize_kernel<D, Real, MapT, LookupT>), dim3(B), dim3(kWave), 0, c->stream, B, M, c->dev,
+                     static_cast<const MapT *>(table), slots, x, head, tail, c->hist, costs4, costs4_last, nit,
+                     nfev, status);
+  return NEO_OK;
+}
+
+int dispatch_opt(neo_ctx *c, int kind, int elem, const void *table, const int *slots, int B, int M, int D,
+                 double *x, const double *head, const double *tail, double *costs4, double *costs4_last, int *nit,
+                 int *nfev, int *status) {
+  const bool f32 = c->params.sample_dtype == NEO_F32;
+#define OPT(DD, RR, MT, LT) \
+  launch_opt<DD, RR, MT, LT>(c, table, slots, B, M, x, head, tail, costs4, costs4_last, nit, nfev, status)
+  if (kind == 0) {
+    if (D == 2) return f32 ? OPT(2, float, Map2D, Lookup2D<float>) : OPT(2, double, Map2D, Lookup2D<double>);
+    return f32 ? OPT(3, float, Map2D, Lookup2D<float>) : OPT(3, double, Map2D, Lookup2D<double>);
+  }
+  if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
+  if (elem == NEO_F32) {
+    using LF = Lookup3D<float, float>;
+    using LD = Lookup3D<double, float>;
+    return f32 ? OPT(3, float, Map3D, LF) : OPT(3, double, Map3D, LD);
+  }
+  using HF = Lookup3D<float, __half>;
+  using HD = Lookup3D<double, __half>;
+  return f32 ? OPT(3, float, Map3D, HF) : OPT(3, double, Map3D, HD);
+#undef OPT
+}
+
+size_t hist_bytes_for(int B, int M, int D) {
+  const int n = D * (M - 1) + M;
+  const size_t npad = (size_t)((n + kWave - 1) / kWave) * kWave;
+  return (size_t)B * 2 * NEO_LBFGS_M * npad * sizeof(double);
+}
+
+void drain_profile(neo_ctx *c) {
+  for (int k = 0; k < NEO_KERNEL_COUNT; ++k) {
+    for (auto &pr : c->prof[k].pending) {
+      float ms = 0.f;
+      hipEventSynchronize(pr.second);
+      hipEventElapsedTime(&ms, pr.first, pr.second);
+      c->prof[k].ms += ms;
+      c->prof[k].launches += 1;
+      hipEventDestroy(pr.first);
+      hipEventDestroy(pr.second);
+    }
+    c->prof[k].pending.clear();
+  }
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+int neo_abi_version(void) { return NEO_ABI_VERSION; }
+
+int neo_params_default(neo_params *p) {
+  if (!p) return NEO_ERR_INVALID;
+  memset(p, 0, sizeof(*p));
+  // launch/config/planner_config.yaml:2-13
+  p->v_max = 1.0;
+  p->T_min = 0.5;
+  p->T_max = 5.0;
+  p->safe_dis = 0.7;
+  p->delta_t = 0.1;
+  p->weights[0] = 1.0;
+  p->weights[1] = 1.0;
+  p->weights[2] = 1.0;
+  p->weights[3] = 10000.0;
+  p->collision_cost_tol = 5.0;
+  // expert_planner.py:213-225
+  p->ftol = 1e-4;
+  p->gtol = 1e-4;
+  p->maxls = 20;
+  p->maxiter = 15000;
+  p->maxfun = 15000;
+  p->bugcompat_stale_T = 1;
+  p->sample_dtype = NEO_F64;
+  return NEO_OK;
+}
+
+int neo_ctx_create(int device_id, void *stream, neo_ctx **out) {
+  if (!out) return NEO_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return NEO_ERR_HIP;
+  if (device_id < 0 || device_id >= count) return NEO_ERR_INVALID;
+  if (hipSetDevice(device_id) != hipSuccess) return NEO_ERR_HIP;
+  neo_ctx *c = new neo_ctx();
+  c->device = device_id;
+  if (stream) {
+    c->stream = static_cast<hipStream_t>(stream);
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return NEO_ERR_HIP;
+    }
+    c->own_stream = true;
+  }
+  neo_params_default(&c->params);
+  fill_dev_params(c);
+  *out = c;
+  return NEO_OK;
+}
+
+int neo_ctx_destroy(neo_ctx *c) {
+  if (!c) return NEO_ERR_INVALID;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  drain_profile(c);
+  for (auto &kv : c->maps)
+    if (kv.second.data) hipFree(kv.second.data);
+  if (c->hist) hipFree(c->hist);
+  if (c->table2d) hipFree(c->table2d);
+  if (c->table3d) hipFree(c->table3d);
+  if (c->scratch) hipFree(c->scratch);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+  return NEO_OK;
+}
+
+const char *neo_last_error(neo_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int neo_params_set(neo_ctx *c, const neo_params *p) {
+  if (!c || !p) return NEO_ERR_INVALID;
+  if (!(p->T_max > p->T_min) || !(p->delta_t > 0.0) || p->maxls < 1)
+    return fail(c, NEO_ERR_INVALID, "bad parameters");
+  if (p->sample_dtype != NEO_F64 && p->sample_dtype != NEO_F32)
+    return fail(c, NEO_ERR_INVALID, "sample_dtype must be NEO_F64 or NEO_F32");
+  std::lock_guard<std::mutex> g(c->mu);
+  c->params = *p;
+  fill_dev_params(c);
+  return NEO_OK;
+}
+
+int neo_ctx_synchronize(neo_ctx *c) {
+  if (!c) return NEO_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NEO_OK;
+}
+
+static int drop_locked(neo_ctx *c, int scene_id) {
+  auto it = c->maps.find(scene_id);
+  if (it != c->maps.end()) {
+    hipStreamSynchronize(c->stream);
+    if (it->second.data) hipFree(it->second.data);
+    c->maps.erase(it);
+    c->table_dirty = true;
+  }
+  return NEO_OK;
+}
+
+int neo_esdf_drop(neo_ctx *c, int scene_id) {
+  if (!c) return NEO_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  return drop_locked(c, scene_id);
+}
+
+int neo_esdf_upload_2d(neo_ctx *c, int scene_id, const double *dist, const double *gx, const double *gy, int W,
+                       int H, double res, double ox, double oy) {
+  if (!c || !dist || !gx || !gy || W < 1 || H < 1 || !(res > 0.0)) return NEO_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  drop_locked(c, scene_id);
+  const size_t ncell = (size_t)W * H;
+  int rc = ensure_scratch(c, 3 * ncell * sizeof(double) + 1024);
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  double *d0 = cv.take<double>(ncell), *d1 = cv.take<double>(ncell), *d2 = cv.take<double>(ncell);
+  MapEntry e;
+  e.kind = 0;
+  e.elem = NEO_F64;
+  HIPCHK(c, hipMalloc(&e.data, ncell * sizeof(double4)));
+  HIPCHK(c, hipMemcpyAsync(d0, dist, ncell * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d1, gx, ncell * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d2, gy, ncell * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(pack2d_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, d0, d1, d2,
+                     (int)ncell, static_cast<double4 *>(e.data));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  e.m2 = Map2D{static_cast<const double4 *>(e.data), W, H, res, ox, oy};
+  c->maps[scene_id] = e;
+  c->table_dirty = true;
+  return NEO_OK;
+}
+
+int neo_esdf_build_2d(neo_ctx *c, int scene_id, const int8_t *occ, int W, int H, double res, double ox, double oy,
+                      double *out_dist, double *out_gx, double *out_gy) {
+  if (!c || !occ || W < 1 || H < 1 || !(res > 0.0)) return NEO_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  drop_locked(c, scene_id);
+  const size_t ncell = (size_t)W * H;
+  const size_t need = ncell * (sizeof(int8_t) + 2 * sizeof(int) + 3 * sizeof(double)) +
+                      (size_t)H * (W + 1) * sizeof(double) + 4096;
+  int rc = ensure_scratch(c, need);
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  int8_t *d_occ = cv.take<int8_t>(ncell);
+  int *d_g = cv.take<int>(ncell);
+  int *d_v = cv.take<int>(ncell);
+  double *d_z = cv.take<double>((size_t)H * (W + 1));
+  double *d_dist = cv.take<double>(ncell);
+  double *d_gx = cv.take<double>(ncell);
+  double *d_gy = cv.take<double>(ncell);
+  MapEntry e;
+  e.kind = 0;
+  e.elem = NEO_F64;
+  HIPCHK(c, hipMalloc(&e.data, ncell * sizeof(double4)));
+  HIPCHK(c, hipMemcpyAsync(d_occ, occ, ncell, hipMemcpyHostToDevice, c->stream));
+  {
+    ProfScope ps(c, NEO_KERNEL_ESDF_BUILD);
+    hipLaunchKernelGGL(edt_columns_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, d_occ, W, H, d_g);
+    hipLaunchKernelGGL(edt_rows_kernel, dim3((H + 63) / 64), dim3(64), 0, c->stream, d_g, W, H, res, d_v, d_z,
+                       d_dist);
+    hipLaunchKernelGGL(gradient_pack_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream,
+                       d_dist, W, H, static_cast<double4 *>(e.data), d_gx, d_gy);
+  }
+  if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, d_dist, ncell * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (out_gx) HIPCHK(c, hipMemcpyAsync(out_gx, d_gx, ncell * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (out_gy) HIPCHK(c, hipMemcpyAsync(out_gy, d_gy, ncell * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  e.m2 = Map2D{static_cast<const double4 *>(e.data), W, H, res, ox, oy};
+  c->maps[scene_id] = e;
+  c->table_dirty = true;
+  return NEO_OK;
+}
+
+int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype, int src_is_device, int nx, int ny,
+                       int nz, double res, const double origin[3], int store_dtype, int layout) {
+  if (!c || !dist || !origin || nx < 2 || ny < 2 || nz < 2 || !(res > 0.0)) return NEO_ERR_INVALID;
+  if (src_dtype != NEO_F64 && src_dtype != NEO_F32) return fail(c, NEO_ERR_INVALID, "src_dtype must be f64 or f32");
+  if (store_dtype != NEO_F32 && store_dtype != NEO_F16)
+    return fail(c, NEO_ERR_INVALID, "store_dtype must be f32 or f16");
+  if (layout != NEO_LAYOUT_LINEAR && layout != NEO_LAYOUT_BRICK4) return fail(c, NEO_ERR_INVALID, "bad layout");
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  drop_locked(c, scene_id);
+  const size_t nvox = (size_t)nx * ny * nz;
+  const size_t ssz = src_dtype == NEO_F64 ? 8 : 4, dsz = store_dtype == NEO_F32 ? 4 : 2;
+  const int bx = (nx + 3) / 4, by = (ny + 3) / 4, bz = (nz + 3) / 4;
+  const size_t nstore = layout == NEO_LAYOUT_BRICK4 ? (size_t)bx * by * bz * 64 : nvox;
+  const void *src = dist;
+  void *staged = nullptr;
+  if (!src_is_device) {
+    HIPCHK(c, hipMalloc(&staged, nvox * ssz));
+    HIPCHK(c, hipMemcpyAsync(staged, dist, nvox * ssz, hipMemcpyHostToDevice, c->stream));
+    src = staged;
+  }
+  MapEntry e;
+  e.kind = 1;
+  e.elem = store_dtype;
+  // +64 elements of slack: the x-pair load of the last voxel row touches one element past the end
+  HIPCHK(c, hipMalloc(&e.data, (nstore + 64) * dsz));
+  HIPCHK(c, hipMemsetAsync(e.data, 0, (nstore + 64) * dsz, c->stream));
+  const dim3 grid((unsigned)((nvox + 255) / 256)), blk(256);
+  if (src_dtype == NEO_F64 && store_dtype == NEO_F32)
+    hipLaunchKernelGGL((pack3d_kernel<double, float>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz,
+                       layout, bx, by, (float *)e.data);
+  else if (src_dtype == NEO_F64)
+    hipLaunchKernelGGL((pack3d_kernel<double, __half>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz,
+                       layout, bx, by, (__half *)e.data);
+  else if (store_dtype == NEO_F32)
+    hipLaunchKernelGGL((pack3d_kernel<float, float>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz,
+                       layout, bx, by, (float *)e.data);
+  else
+    hipLaunchKernelGGL((pack3d_kernel<float, __half>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz,
+                       layout, bx, by, (__half *)e.data);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (staged) hipFree(staged);
+  e.m3 = Map3D{e.data, nx, ny, nz, layout, bx, by, res, origin[0], origin[1], origin[2]};
+  c->maps[scene_id] = e;
+  c->table_dirty = true;
+  return NEO_OK;
+}
+
+int neo_esdf_query(neo_ctx *c, int scene_id, int n, const double *pts, double *dist, double *grad) {
+  if (!c || n < 0 || !pts || !dist) return NEO_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  auto it = c->maps.find(scene_id);
+  if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for this scene");
+  if (n == 0) return NEO_OK;
+  const MapEntry &e = it->second;
+  const int dm = e.kind == 0 ? 2 : 3;
+  int rc = ensure_scratch(c, (size_t)n * (2 * dm + 1) * sizeof(double) + 1024);
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  double *d_p = cv.take<double>((size_t)n * dm), *d_d = cv.take<double>(n), *d_g = cv.take<double>((size_t)n * dm);
+  HIPCHK(c, hipMemcpyAsync(d_p, pts, (size_t)n * dm * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  const dim3 grid((n + 127) / 128), blk(128);
+  if (e.kind == 0)
+    hipLaunchKernelGGL((query_kernel<double, Map2D, Lookup2D<double>, 2>), grid, blk, 0, c->stream, n, e.m2, d_p, d_d,
+                       d_g);
+  else if (e.elem == NEO_F32)
+    hipLaunchKernelGGL((query_kernel<double, Map3D, Lookup3D<double, float>, 3>), grid, blk, 0, c->stream, n, e.m3,
+                       d_p, d_d, d_g);
+  else
+    hipLaunchKernelGGL((query_kernel<double, Map3D, Lookup3D<double, __half>, 3>), grid, blk, 0, c->stream, n, e.m3,
+                       d_p, d_d, d_g);
+  HIPCHK(c, hipMemcpyAsync(dist, d_d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (grad) HIPCHK(c, hipMemcpyAsync(grad, d_g, (size_t)n * dm * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NEO_OK;
+}
+
+int neo_cost_grad_batch_dev(neo_ctx *c, int scene_id, int B, int M, int D, const double *x, const double *head,
+                            const double *tail, double *cost, double *costs4, double *grad, double *coeffs,
+                            int32_t *status) {
+  int rc = check_shape(c, B, M, D);
+  if (rc) return rc;
+  if (!x || !head || !tail || !cost || !costs4 || !grad) return fail(c, NEO_ERR_INVALID, "null buffer");
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  auto it = c->maps.find(scene_id);
+  if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for this scene");
+  if (B == 0) return NEO_OK;
+  ProfScope ps(c, NEO_KERNEL_EVAL);
+  rc = dispatch_eval(c, it->second, B, M, D, x, head, tail, cost, costs4, grad, coeffs, status);
+  if (rc) return rc;
+  HIPCHK(c, hipGetLastError());
+  return NEO_OK;
+}
+
+int neo_cost_grad_batch(neo_ctx *c, int scene_id, int B, int M, int D, const double *x, const double *head,
+                        const double *tail, double *cost, double *costs4, double *grad, double *coeffs,
+                        int32_t *status) {
+  int rc = check_shape(c, B, M, D);
+  if (rc) return rc;
+  if (!x || !head || !tail || !cost || !costs4 || !grad) return fail(c, NEO_ERR_INVALID, "null buffer");
+  if (B == 0) return NEO_OK;
+  const size_t n = (size_t)D * (M - 1) + M, bs = (size_t)B;
+  double *dx, *dh, *dt, *dc, *dc4, *dg, *dco;
+  int *dst;
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    hipSetDevice(c->device);
+    const size_t bytes = bs * (2 * n + 6 * D + 5 + 6 * M * D) * sizeof(double) + bs * sizeof(int) + 8 * 256;
+    rc = ensure_scratch(c, bytes);
+    if (rc) return rc;
+    Carver cv(c->scratch);
+    dx = cv.take<double>(bs * n);
+    dh = cv.take<double>(bs * 3 * D);
+    dt = cv.take<double>(bs * 3 * D);
+    dc = cv.take<double>(bs);
+    dc4 = cv.take<double>(bs * 4);
+    dg = cv.take<double>(bs * n);
+    dco = cv.take<double>(bs * 6 * M * D);
+    dst = cv.take<int>(bs);
+    HIPCHK(c, hipMemcpyAsync(dx, x, bs * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dh, head, bs * 3 * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dt, tail, bs * 3 * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  rc = neo_cost_grad_batch_dev(c, scene_id, B, M, D, dx, dh, dt, dc, dc4, dg, coeffs ? dco : nullptr, dst);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipMemcpyAsync(cost, dc, bs * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(costs4, dc4, bs * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(grad, dg, bs * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (coeffs) HIPCHK(c, hipMemcpyAsync(coeffs, dco, bs * 6 * M * D * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (status) HIPCHK(c, hipMemcpyAsync(status, dst, bs * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NEO_OK;
+}
+
+size_t neo_optimize_workspace_bytes(int B, int M, int D) { return hist_bytes_for(B, M, D); }
+
+int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, int B, int M, int D, double *x,
+                           const double *head, const double *tail, double *costs4, double *costs4_last, int32_t *nit,
+                           int32_t *nfev, int32_t *status) {
+  int rc = check_shape(c, B, M, D);
+  if (rc) return rc;
+  if (!x || !head || !tail || !costs4 || !nit || !nfev || !status) return fail(c, NEO_ERR_INVALID, "null buffer");
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  if (B == 0) return NEO_OK;
+  rc = rebuild_tables(c);
+  if (rc) return rc;
+  // scene_ids (device array) holds map-table SLOTS when given; a single scene_id is looked up here
+  int kind, elem;
+  const void *table;
+  const int *slots = scene_ids;
+  std::vector<int> one;
+  if (scene_ids) {
+    // all maps of a multi-scene call must be of one kind/element type: take it from scene_id
+    auto it = c->maps.find(scene_id);
+    if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for the reference scene");
+    kind = it->second.kind;
+    elem = it->second.elem;
+    table = kind == 0 ? c->table2d : c->table3d;
+  } else {
+    auto it = c->maps.find(scene_id);
+    if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for this scene");
+    kind = it->second.kind;
+    elem = it->second.elem;
+    const char *base = static_cast<const char *>(kind == 0 ? c->table2d : c->table3d);
+    table = base + (size_t)it->second.slot * (kind == 0 ? sizeof(Map2D) : sizeof(Map3D));
+  }
+  const size_t need = hist_bytes_for(B, M, D);
+  if (need > c->hist_bytes) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->hist) hipFree(c->hist);
+    c->hist = nullptr;
+    c->hist_bytes = 0;
+    HIPCHK(c, hipMalloc((void **)&c->hist, need));
+    c->hist_bytes = need;
+  }
+  ProfScope ps(c, NEO_KERNEL_OPTIMIZE);
+  rc = dispatch_opt(c, kind, elem, table, slots, B, M, D, x, head, tail, costs4, costs4_last, nit, nfev, status);
+  if (rc) return rc;
+  HIPCHK(c, hipGetLastError());
+  return NEO_OK;
+}
+
+int neo_scene_slot(neo_ctx *c, int scene_id) {
+  if (!c) return -1;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  if (rebuild_tables(c)) return -1;
+  auto it = c->maps.find(scene_id);
+  return it == c->maps.end() ? -1 : it->second.slot;
+}
+
+int neo_optimize_batch(neo_ctx *c, int scene_id, const int32_t *scene_ids, int B, int M, int D, double *x,
+                       const double *head, const double *tail, double *costs4, double *costs4_last, int32_t *nit,
+                       int32_t *nfev, int32_t *status) {
+  int rc = check_shape(c, B, M, D);
+  if (rc) return rc;
+  if (!x || !head || !tail || !costs4 || !nit || !nfev || !status) return fail(c, NEO_ERR_INVALID, "null buffer");
+  if (B == 0) return NEO_OK;
+  const size_t n = (size_t)D * (M - 1) + M, bs = (size_t)B;
+  double *dx, *dh, *dt, *dc4, *dc4l;
+  int *dnit, *dnfev, *dst, *dslots = nullptr;
+  std::vector<int> slots;
+  if (scene_ids) {
+    slots.resize(bs);
+    for (size_t i = 0; i < bs; ++i) {
+      const int s = neo_scene_slot(c, scene_ids[i]);
+      if (s < 0) return fail(c, NEO_ERR_NO_MAP, "no ESDF for one of scene_ids");
+      slots[i] = s;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    hipSetDevice(c->device);
+    const size_t bytes = bs * (n + 6 * D + 8) * sizeof(double) + bs * 4 * sizeof(int) + 10 * 256;
+    rc = ensure_scratch(c, bytes);
+    if (rc) return rc;
+    Carver cv(c->scratch);
+    dx = cv.take<double>(bs * n);
+    dh = cv.take<double>(bs * 3 * D);
+    dt = cv.take<double>(bs * 3 * D);
+    dc4 = cv.take<double>(bs * 4);
+    dc4l = cv.take<double>(bs * 4);
+    dnit = cv.take<int>(bs);
+    dnfev = cv.take<int>(bs);
+    dst = cv.take<int>(bs);
+    dslots = cv.take<int>(bs);
+    HIPCHK(c, hipMemcpyAsync(dx, x, bs * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dh, head, bs * 3 * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dt, tail, bs * 3 * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (scene_ids)
+      HIPCHK(c, hipMemcpyAsync(dslots, slots.data(), bs * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  }
+  rc = neo_optimize_batch_dev(c, scene_ids ? scene_ids[0] : scene_id, scene_ids ? dslots : nullptr, B, M, D, dx, dh,
+                              dt, dc4, dc4l, dnit, dnfev, dst);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipMemcpyAsync(x, dx, bs * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(costs4, dc4, bs * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (costs4_last) HIPCHK(c, hipMemcpyAsync(costs4_last, dc4l, bs * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(nit, dnit, bs * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(nfev, dnfev, bs * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(status, dst, bs * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NEO_OK;
+}
+
+int neo_eval_traj_batch(neo_ctx *c, int B, int M, int D, const double *x, const double *head, const double *tail,
+                        double hz, int K, double *state, int32_t *count) {
+  int rc = check_shape(c, B, M, D);
+  if (rc) return rc;
+  if (!x || !head || !tail || !state || !count || K < 0 || !(hz > 0.0)) return fail(c, NEO_ERR_INVALID, "bad argument");
+  if (B == 0 || K == 0) return NEO_OK;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  const size_t n = (size_t)D * (M - 1) + M, bs = (size_t)B;
+  rc = ensure_scratch(c, bs * (n + 6 * D + (size_t)K * 3 * D) * sizeof(double) + bs * sizeof(int) + 6 * 256);
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  double *dx = cv.take<double>(bs * n), *dh = cv.take<double>(bs * 3 * D), *dt = cv.take<double>(bs * 3 * D);
+  double *ds = cv.take<double>(bs * K * 3 * D);
+  int *dcnt = cv.take<int>(bs);
+  HIPCHK(c, hipMemcpyAsync(dx, x, bs * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dh, head, bs * 3 * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dt, tail, bs * 3 * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (D == 2)
+    hipLaunchKernelGGL((traj_state_kernel<2>), dim3(B), dim3(kWave), 0, c->stream, B, M, c->dev, dx, dh, dt, hz, K, ds,
+                       dcnt);
+  else
+    hipLaunchKernelGGL((traj_state_kernel<3>), dim3(B), dim3(kWave), 0, c->stream, B, M, c->dev, dx, dh, dt, hz, K, ds,
+                       dcnt);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(state, ds, bs * K * 3 * D * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(count, dcnt, bs * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NEO_OK;
+}
+
+int neo_profile_enable(neo_ctx *c, int on) {
+  if (!c) return NEO_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->mu);
+  c->profile = on != 0;
+  return NEO_OK;
+}
+
+int neo_profile_read(neo_ctx *c, int kernel, int64_t *launches, double *total_ms) {
+  if (!c || kernel < 0 || kernel >= NEO_KERNEL_COUNT) return NEO_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  drain_profile(c);
+  if (launches) *launches = c->prof[kernel].launches;
+  if (total_ms) *total_ms = c->prof[kernel].ms;
+  return NEO_OK;
+}
+
+int neo_profile_reset(neo_ctx *c) {
+  if (!c) return NEO_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  drain_profile(c);
+  for (int k = 0; k < NEO_KERNEL_COUNT; ++k) {
+    c->prof[k].launches = 0;
+    c->prof[k].ms = 0.0;
+  }
+  return NEO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,408 @@
+"""
+Host side of the MI355X planner: the reference's Python interface on top of the C ABI.
+
+`MinJerkPlanner` keeps the names, argument meaning, side effects and exceptions of
+traj_planner/expert_planner.py:28-585 (+ traj_utils.py evaluation helpers), so that
+ros_node/traj_planner_node.py-style callers can switch without edits:
+
+    planner = MinJerkPlanner(config)            # PlannerConfig-like object
+    planner.plan(map, head_state, tail_state)   # or warm_start_plan / batch_plan / plan_once
+    planner.int_wpts, planner.ts, planner.iter_num, planner.get_full_state_cmd(hz) ...
+
+All arithmetic of the replan loop (coefficient solve, cost, gradient, L-BFGS-B) runs on the
+GPU through libneo_planner_hip.so; this file only packs arguments, keeps the reference's
+retry/exception control flow, and unpacks results.  `BatchPlanner` is the batched entry the
+reference does not have: B independent replans in one launch.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import _lib
+from .esdf import ESDF, ESDF3D
+
+
+class PlannerConfig:
+    """parameter bag with the attribute names MinJerkPlanner reads (expert_planner.py:33-56,
+    ros_node/traj_planner_node.py:32-46); defaults = launch/config/planner_config.yaml:2-13."""
+
+    def __init__(self, **kw):
+        self.v_max = 1.0
+        self.T_min = 0.5
+        self.T_max = 5.0
+        self.safe_dis = 0.7
+        self.delta_t = 0.1
+        self.weights = [1.0, 1.0, 1.0, 10000.0]
+        self.init_wpts_mode = 'fixed'
+        self.init_seg_len = 2.0
+        self.init_wpts_num = 2
+        self.init_T = 2.5
+        self.collision_cost_tol = 5
+        self.opt_tol = 1e-2
+        self.des_pos_z = 2.0
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def _push_params(ctx, p, sample_dtype, stale_T=True):
+    ctx.set_params(v_max=float(p.v_max), T_min=float(p.T_min), T_max=float(p.T_max), safe_dis=float(p.safe_dis),
+                   delta_t=float(p.delta_t), weights=[float(w) for w in p.weights],
+                   collision_cost_tol=float(p.collision_cost_tol), ftol=1e-4, gtol=1e-4, maxls=20,
+                   maxiter=15000, maxfun=15000, bugcompat_stale_T=int(bool(stale_T)),
+                   sample_dtype={"f64": _lib.NEO_F64, "f32": _lib.NEO_F32}[sample_dtype])
+
+
+def _map_scene(ctx, map, cache):
+    """scene id of `map` on the device.  Our own ESDF classes are already resident; a foreign
+    object with the reference's attribute protocol (esdf.py:17-33) is snapshotted."""
+    if isinstance(map, (ESDF, ESDF3D)):
+        if map.ctx is not ctx:
+            raise ValueError("map and planner live on different contexts")
+        return map.scene_id
+    snap = ESDF.from_arrays(map.esdf_map, map.esdf_grad_x, map.esdf_grad_y, map.map_resolution,
+                            (map.map_origin.x, map.map_origin.y), ctx=ctx)
+    old = cache.get("foreign")
+    if old is not None:
+        ctx.lib.neo_esdf_drop(ctx.h, old.scene_id)
+    cache["foreign"] = snap
+    return snap.scene_id
+
+
+class MinJerkPlanner:
+    """MI355X-backed stand-in for expert_planner.py:MinJerkPlanner"""
+
+    def __init__(self, config=None, ctx=None, sample_dtype="f64", stale_T=True):
+        config = config if config is not None else PlannerConfig()
+        self.ctx = ctx if ctx is not None else _lib.default_context()
+        self.s = 3
+        self.v_max = config.v_max
+        self.T_min = config.T_min
+        self.T_max = config.T_max
+        self.safe_dis = config.safe_dis
+        self.collision_cost_tol = config.collision_cost_tol
+        self.weights = np.array(config.weights, dtype=np.float64)
+        self.delta_t = config.delta_t
+        self.opt_tol = config.opt_tol
+        self.init_wpts_mode = config.init_wpts_mode
+        self.init_seg_len = config.init_seg_len
+        self.init_wpts_num = int(config.init_wpts_num)
+        self.init_T = config.init_T
+        self.batch_num = 3
+        self.iter_num = 0
+        self.opt_running_times = 0
+        self.coeffs = []
+        self.sample_dtype = sample_dtype
+        self.stale_T = stale_T
+        self._cache = {}
+        self._scene = None
+
+    # ------------------------------------------------------------ initial guesses (:82-140)
+    def generate_init_variables(self, head_state, tail_state, seed=0):
+        start, target = head_state[0], tail_state[0]
+        if self.init_wpts_mode == 'adaptive':
+            dist = np.linalg.norm(target - start)
+            count = max(math.ceil(dist / self.init_seg_len - 1), 1)
+        elif self.init_wpts_mode == 'fixed':
+            count = self.init_wpts_num
+        stride = (target - start) / (count + 1)
+        wpts = np.linspace(start + stride, target, count, endpoint=False)
+        if seed != 0:
+            wpts += np.random.normal(0, 0.5, wpts.shape)   # the reference's unseeded global RNG (:94)
+        ts = self.init_T * np.ones((count + 1,))
+        ts[0] *= 1.5
+        ts[-1] *= 1.5
+        return wpts.T, ts
+
+    def batch_generate_init_variables(self, head_state, tail_state):
+        if self.init_wpts_mode != 'fixed':
+            print("Error! init_wpts_mode must be 'fixed'")
+        start, target = head_state[0], tail_state[0]
+        forward = (target - start) / np.linalg.norm(target - start)
+        sideways = np.array([[forward[1], -forward[0]], [-forward[1], forward[0]]])
+        count = self.init_wpts_num
+        out = np.zeros((self.batch_num, count, head_state.shape[1]))
+        stride = (target - start) / (count + 1)
+        out[0] = np.linspace(start + stride, target, count, endpoint=False)
+        which = 0
+        for i in range(1, self.batch_num):
+            out[i] = out[0] + 0.6 * sideways[which]
+            which = 1 - which
+        ts = self.init_T * np.ones((count + 1,))
+        ts[0] *= 1.5
+        ts[-1] *= 1.5
+        return np.transpose(out, (0, 2, 1)), ts
+
+    # ------------------------------------------------------------ entry points (:62-80, :142-237)
+    def read_planning_conditions(self, map, head_state, tail_state, int_wpts, ts):
+        self.map = map
+        self.D = head_state.shape[1]
+        self.M = ts.shape[0]
+        self.head_state = np.zeros((self.s, self.D))
+        self.tail_state = np.zeros((self.s, self.D))
+        for i in range(min(self.s, head_state.shape[0])):
+            self.head_state[i] = head_state[i]
+        for i in range(min(self.s, tail_state.shape[0])):
+            self.tail_state[i] = tail_state[i]
+        self.int_wpts = int_wpts
+        self.ts = ts
+        # snapshot the map now: the reference reads it unlocked while a subscriber thread may
+        # be rewriting it
+        self._scene = _map_scene(self.ctx, map, self._cache)
+
+    def plan(self, map, head_state, tail_state):
+        int_wpts, ts = self.generate_init_variables(head_state, tail_state)
+        self.warm_start_plan(map, head_state, tail_state, int_wpts, ts)
+
+    def warm_start_plan(self, map, head_state, tail_state, int_wpts, ts):
+        self.read_planning_conditions(map, head_state, tail_state, int_wpts, ts)
+        seed = 0
+        while seed < 5:
+            try:
+                self.plan_once()
+                return
+            except Exception as ex:
+                print(f"Re-planning for {ex}, current seed: {seed}")
+                seed += 1
+                self.int_wpts, self.ts = self.generate_init_variables(head_state, tail_state, seed)
+        raise Exception("No solution for the given target")
+
+    def batch_plan(self, map, head_state, tail_state):
+        cands, ts = self.batch_generate_init_variables(head_state, tail_state)
+        best_wpts = np.zeros(cands.shape)
+        best_ts = np.zeros((self.batch_num, len(ts)))
+        cost = np.zeros(self.batch_num)
+        for i in range(self.batch_num):
+            try:
+                self.read_planning_conditions(map, head_state, tail_state, cands[i], ts)
+                self.plan_once()
+                best_wpts[i] = self.int_wpts
+                best_ts[i] = self.ts
+                cost[i] = self.weighted_cost.sum()
+                print(f"batch_cost[{i}] = {cost[i]}")
+            except Exception as ex:
+                print(f"The {i}th attempt is deprecated for {ex}")
+                cost[i] = np.inf
+            # as in the reference the check sits inside the loop (:160-168)
+            if np.min(cost) < np.inf:
+                k = np.argmin(cost)
+                self.int_wpts = best_wpts[k]
+                self.ts = best_ts[k]
+                self.final_cost = cost[k]
+            else:
+                print("All attempts are infeasible! Start re-planning from scratch...")
+                self.warm_start_plan(map, head_state, tail_state, cands[0], ts)
+
+    def _pack_x(self):
+        nq = self.D * (self.M - 1)
+        return np.concatenate((np.reshape(self.int_wpts, (nq,)), self.tau), axis=0)
+
+    def _unpack_x(self, x):
+        nq = self.D * (self.M - 1)
+        self.int_wpts = np.reshape(x[:nq], (self.D, self.M - 1))
+        self.tau = x[nq:]
+        self.ts = self.map_tau2T(self.tau)
+
+    def _sync_params(self):
+        cfg = PlannerConfig(v_max=self.v_max, T_min=self.T_min, T_max=self.T_max, safe_dis=self.safe_dis,
+                            delta_t=self.delta_t, weights=self.weights,
+                            collision_cost_tol=self.collision_cost_tol)
+        _push_params(self.ctx, cfg, self.sample_dtype, self.stale_T)
+
+    def plan_once(self):
+        """expert_planner.py:205-237 -- the L-BFGS-B run happens in one kernel launch"""
+        self.tau = self.map_T2tau(self.ts)
+        x = _lib.as_f64(self._pack_x()).reshape(1, -1).copy()
+        self._sync_params()
+        c = self.ctx
+        costs = np.zeros((1, 4)); last = np.zeros((1, 4))
+        nit = np.zeros(1, np.int32); nfev = np.zeros(1, np.int32); st = np.zeros(1, np.int32)
+        head = _lib.as_f64(self.head_state).reshape(1, 3, self.D)
+        tail = _lib.as_f64(self.tail_state).reshape(1, 3, self.D)
+        c.check(c.lib.neo_optimize_batch(c.h, self._scene, None, 1, self.M, self.D, _lib.ptr(x), _lib.ptr(head),
+                                         _lib.ptr(tail), _lib.ptr(costs), _lib.ptr(last), _lib.ptr(nit),
+                                         _lib.ptr(nfev), _lib.ptr(st)))
+        code = int(st[0]) & 0xff
+        self.last_status, self.last_nit, self.last_nfev = code, int(nit[0]), int(nfev[0])
+        if code == _lib.NEO_TRAJ_NUMERIC_RANGE:
+            raise OverflowError("math range error")          # what math.exp raises at :481
+        self._unpack_x(x[0])
+        self.iter_num += int(nit[0])
+        self.opt_running_times += 1
+        self.costs = last[0].copy()                           # costs of the last evaluated x (:233)
+        self.costs_at_x = costs[0].copy()
+        self.weighted_cost = self.costs * self.weights
+        self.final_cost = self.weighted_cost.sum()
+        if self.weighted_cost[3] > self.collision_cost_tol:
+            raise ValueError("collision cost too large")
+
+    optimize = plan_once
+
+    # ------------------------------------------------------------ callbacks (:539-585)
+    def _device_eval(self, x, want_coeffs=True):
+        self._sync_params()
+        c = self.ctx
+        xx = _lib.as_f64(x).reshape(1, -1)
+        n = xx.shape[1]
+        cost = np.zeros(1); costs = np.zeros((1, 4)); grad = np.zeros((1, n))
+        coeffs = np.zeros((1, 6 * self.M, self.D)); st = np.zeros(1, np.int32)
+        head = _lib.as_f64(self.head_state).reshape(1, 3, self.D)
+        tail = _lib.as_f64(self.tail_state).reshape(1, 3, self.D)
+        c.check(c.lib.neo_cost_grad_batch(c.h, self._scene, 1, self.M, self.D, _lib.ptr(xx), _lib.ptr(head),
+                                          _lib.ptr(tail), _lib.ptr(cost), _lib.ptr(costs), _lib.ptr(grad),
+                                          _lib.ptr(coeffs), _lib.ptr(st)))
+        if int(st[0]) == _lib.NEO_TRAJ_NUMERIC_RANGE:
+            raise OverflowError("math range error")
+        return cost[0], costs[0], grad[0], coeffs[0]
+
+    def get_cost(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        self._unpack_x(x)
+        cost, self.costs, self._grad, self.coeffs = self._device_eval(x)
+        return cost
+
+    def get_grad(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        self._unpack_x(x)
+        _, _, grad, self.coeffs = self._device_eval(x)      # get_grad leaves self.costs alone (:572)
+        return grad
+
+    def get_coeffs(self, int_wpts, ts):
+        """expert_planner.py:261-336 (coefficients only; the device never forms the 6M x 6M matrix)"""
+        self.int_wpts, self.ts = int_wpts, ts
+        self.tau = self.map_T2tau(np.asarray(ts, dtype=np.float64))
+        _, self._eval_costs, _, self.coeffs = self._device_eval(self._pack_x())
+
+    def reset_cost(self):
+        self.costs = np.zeros(len(self.weights))
+
+    # standalone use after get_coeffs(), as all_planner_demo.py:46-51 does
+    def add_energy_cost(self):
+        self.costs[0] += self._eval_costs[0]
+
+    def add_time_cost(self):
+        self.costs[1] += self._eval_costs[1]
+
+    def add_sampled_cost(self):
+        self.costs[2] += self._eval_costs[2]
+        self.costs[3] += self._eval_costs[3]
+
+    # ------------------------------------------------------------ time map (:468-483)
+    def map_T2tau(self, ts):
+        tau = np.zeros(self.M)
+        for i in range(self.M):
+            tau[i] = -math.log((self.T_max - self.T_min) / (ts[i] - self.T_min) - 1)
+        return tau
+
+    def map_tau2T(self, tau):
+        ts = np.zeros(self.M)
+        for i in range(self.M):
+            ts[i] = (self.T_max - self.T_min) / (1 + math.exp(-tau[i])) + self.T_min
+        return ts
+
+    # ------------------------------------------------------------ evaluation (traj_utils.py:85-250)
+    def _states(self, hz):
+        ts = np.asarray(self.ts, dtype=np.float64)
+        K = len(np.arange(0, sum(ts), 1 / hz))
+        self.tau = self.map_T2tau(ts)
+        x = _lib.as_f64(self._pack_x()).reshape(1, -1)
+        state = np.zeros((1, max(K, 1), 3, self.D))
+        cnt = np.zeros(1, np.int32)
+        head = _lib.as_f64(self.head_state).reshape(1, 3, self.D)
+        tail = _lib.as_f64(self.tail_state).reshape(1, 3, self.D)
+        self._sync_params()
+        c = self.ctx
+        if K > 0:
+            c.check(c.lib.neo_eval_traj_batch(c.h, 1, self.M, self.D, _lib.ptr(x), _lib.ptr(head), _lib.ptr(tail),
+                                              float(hz), K, _lib.ptr(state), _lib.ptr(cnt)))
+        return state[0, :K]
+
+    def get_full_state_cmd(self, hz=300):
+        return self._states(hz)
+
+    def get_pos_array(self):
+        return self._states(10.0)[:, 0, :]       # np.arange(0, sum(ts), 0.1): 1/10.0 == 0.1
+
+    def get_vel_array(self):
+        return self._states(10.0)[:, 1, :]
+
+    def get_acc_array(self):
+        return self._states(10.0)[:, 2, :]
+
+    def print_results(self):
+        print("-----------------------Final intermediate waypoints-----------------------")
+        print(np.asarray(self.int_wpts).T)
+        print("-----------------------Final T--------------------------------------------")
+        print(self.ts)
+        self.weighted_cost = self.costs * self.weights
+        print("Energy cost: %f, Time cost: %f, Feasibility cost: %f, Collision cost: %f" % tuple(self.weighted_cost))
+
+
+class BatchPlanner:
+    """B independent replans per call (host arrays in, host arrays out).  For device-resident
+    buffers use `optimize_dev` with torch tensors."""
+
+    def __init__(self, config=None, ctx=None, sample_dtype="f64", stale_T=True):
+        self.cfg = config if config is not None else PlannerConfig()
+        self.ctx = ctx if ctx is not None else _lib.default_context()
+        self.sample_dtype = sample_dtype
+        self.stale_T = stale_T
+
+    def _sync(self):
+        _push_params(self.ctx, self.cfg, self.sample_dtype, self.stale_T)
+
+    def pack_x(self, int_wpts, ts):
+        """int_wpts (B, D, M-1), ts (B, M) -> x (B, n) with tau = map_T2tau(ts) (:468-475)"""
+        B = ts.shape[0]
+        tau = -np.log((self.cfg.T_max - self.cfg.T_min) / (ts - self.cfg.T_min) - 1.0)
+        return np.concatenate([np.asarray(int_wpts, dtype=np.float64).reshape(B, -1), tau], axis=1)
+
+    def unpack_x(self, x, M, D):
+        B = x.shape[0]
+        nq = D * (M - 1)
+        ts = (self.cfg.T_max - self.cfg.T_min) / (1.0 + np.exp(-x[:, nq:])) + self.cfg.T_min
+        return x[:, :nq].reshape(B, D, M - 1), ts
+
+    def cost_grad(self, map, x, head, tail, want_coeffs=False):
+        self._sync()
+        c = self.ctx
+        x = _lib.as_f64(x); head = _lib.as_f64(head); tail = _lib.as_f64(tail)
+        B, n = x.shape
+        D = head.shape[2]
+        M = (n + D) // (D + 1)
+        cost = np.zeros(B); costs = np.zeros((B, 4)); grad = np.zeros((B, n)); st = np.zeros(B, np.int32)
+        coeffs = np.zeros((B, 6 * M, D)) if want_coeffs else None
+        c.check(c.lib.neo_cost_grad_batch(c.h, map.scene_id, B, M, D, _lib.ptr(x), _lib.ptr(head), _lib.ptr(tail),
+                                          _lib.ptr(cost), _lib.ptr(costs), _lib.ptr(grad), _lib.ptr(coeffs),
+                                          _lib.ptr(st)))
+        return dict(cost=cost, costs=costs, grad=grad, coeffs=coeffs, status=st)
+
+    def optimize(self, map, x0, head, tail, scene_ids=None):
+        """map: one map for all trajectories (scene_ids None) or any map of the right kind plus
+        scene_ids (B,) int32 of per-trajectory scene ids."""
+        self._sync()
+        c = self.ctx
+        x = _lib.as_f64(x0).copy(); head = _lib.as_f64(head); tail = _lib.as_f64(tail)
+        B, n = x.shape
+        D = head.shape[2]
+        M = (n + D) // (D + 1)
+        costs = np.zeros((B, 4)); last = np.zeros((B, 4))
+        nit = np.zeros(B, np.int32); nfev = np.zeros(B, np.int32); st = np.zeros(B, np.int32)
+        sid = None if scene_ids is None else np.ascontiguousarray(scene_ids, dtype=np.int32)
+        c.check(c.lib.neo_optimize_batch(c.h, map.scene_id, _lib.ptr(sid), B, M, D, _lib.ptr(x), _lib.ptr(head),
+                                         _lib.ptr(tail), _lib.ptr(costs), _lib.ptr(last), _lib.ptr(nit),
+                                         _lib.ptr(nfev), _lib.ptr(st)))
+        w = np.asarray(self.cfg.weights, dtype=np.float64)
+        return dict(x=x, costs=costs, costs_last=last, nit=nit, nfev=nfev, status=st & 0xff,
+                    collision=(st & _lib.NEO_TRAJ_FLAG_COLLISION) != 0, final_cost=(costs * w).sum(axis=1))
+
+    def optimize_dev(self, map, x, head, tail, costs, costs_last, nit, nfev, status, slots=None):
+        """torch CUDA tensors (float64 / int32), asynchronous on the context's stream.
+        `slots`: optional int32 device tensor of map-table slots (Context.lib.neo_scene_slot)."""
+        B, n = x.shape
+        D = head.shape[2]
+        M = (n + D) // (D + 1)
+        c = self.ctx
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        c.check(c.lib.neo_optimize_batch_dev(c.h, map.scene_id, p(slots), B, M, D, p(x), p(head), p(tail), p(costs),
+                                             p(costs_last), p(nit), p(nfev), p(status)))
