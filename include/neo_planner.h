@@ -186,6 +186,9 @@ int neo_eval_traj_batch(neo_ctx *ctx, int B, int M, int D, const double *x, cons
  * the context stream; neo_profile_read returns launches and summed milliseconds. */
 enum { NEO_KERNEL_EVAL = 0, NEO_KERNEL_OPTIMIZE = 1, NEO_KERNEL_ESDF_BUILD = 2, NEO_KERNEL_COUNT = 3 };
 int neo_profile_enable(neo_ctx *ctx, int on);
+/* optional DEVICE array [B] that the next neo_optimize_batch_dev launches fill with the number of
+ * quadrature samples (ESDF lookups) each trajectory evaluated; NULL switches it off. */
+int neo_optimize_sample_counter(neo_ctx *ctx, int64_t *dev_counts);
 int neo_profile_read(neo_ctx *ctx, int kernel, int64_t *launches, double *total_ms);
 int neo_profile_reset(neo_ctx *ctx);
 

@@ -39,6 +39,7 @@ struct DevBackend {
   double *hist;  // global [2][m][npad] for this trajectory
   int npad, nsl, m;
   double *coeff_out;  // optional [6M][D] (eval kernel)
+  long long samples = 0;  // quadrature samples visited so far (lane-uniform), for the bench's byte count
 
   __device__ DevBackend(const DevParams &p, const MapT &mp) : prm(p), map(mp) {}
 
@@ -128,6 +129,7 @@ struct DevBackend {
       for (int k = 0; k < 4; ++k) costs[k] = 0.0;
       return st;
     }
+    samples += (long long)wave_sum(lane < t.M ? t.ns : 0);
     if (coeff_out != nullptr && lane < t.M) {
 #pragma unroll
       for (int k = 0; k < 6; ++k)
@@ -233,7 +235,8 @@ __global__ __launch_bounds__(kWave) void optimize_kernel(int B, int M, DevParams
                                                           double *__restrict__ costs4,
                                                           double *__restrict__ costs4_last,
                                                           int *__restrict__ nit, int *__restrict__ nfev,
-                                                          int *__restrict__ status) {
+                                                          int *__restrict__ status,
+                                                          long long *__restrict__ nsamples) {
   __shared__ double xs[kSlots * kWave];
   __shared__ double sc[2 * NEO_LBFGS_M];
   const int b = blockIdx.x;
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(kWave) void optimize_kernel(int B, int M, DevParams
     nit[b] = res.nit;
     nfev[b] = res.nfev;
     status[b] = st;
+    if (nsamples) nsamples[b] = be.samples;
   }
 }
 
@@ -343,8 +347,13 @@ __global__ void edt_rows_kernel(const int *__restrict__ g, int W, int H, double 
     z[k + 1] = 1.0e300;
   }
   double *out = dist + (size_t)y * W;
-  if (k < 0) {  // no obstacle anywhere in this row's columns
-    for (int q = 0; q < W; ++q) out[q] = 1.0e300;
+  if (k < 0) {
+    // no occupied cell in the whole map: scipy.ndimage.distance_transform_edt then measures to a
+    // virtual background cell at index (-1, -1); the reference inherits that (esdf.py:29)
+    for (int q = 0; q < W; ++q) {
+      const long long sq = (long long)(y + 1) * (y + 1) + (long long)(q + 1) * (q + 1);
+      out[q] = sqrt((double)sq) * res;
+    }
     return;
   }
   int j = 0;
@@ -529,6 +538,7 @@ struct neo_ctx {
   size_t scratch_bytes = 0;
   bool profile = false;
   ProfileSlot prof[NEO_KERNEL_COUNT];
+  long long *sample_counter = nullptr;  // optional device array [B] (neo_optimize_sample_counter)
 };
 
 namespace {
@@ -685,7 +695,7 @@ int launch_opt(neo_ctx *c, const void *table, const int *slots, int B, int M, do
                const double *tail, double *costs4, double *costs4_last, int *nit, int *nfev, int *status) {
   hipLaunchKernelGGL((optimize_kernel<D, Real, MapT, LookupT>), dim3(B), dim3(kWave), 0, c->stream, B, M, c->dev,
                      static_cast<const MapT *>(table), slots, x, head, tail, c->hist, costs4, costs4_last, nit,
-                     nfev, status);
+                     nfev, status, c->sample_counter);
   return NEO_OK;
 }
 
@@ -1189,6 +1199,13 @@ int neo_eval_traj_batch(neo_ctx *c, int B, int M, int D, const double *x, const 
   HIPCHK(c, hipMemcpyAsync(state, ds, bs * K * 3 * D * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(count, dcnt, bs * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NEO_OK;
+}
+
+int neo_optimize_sample_counter(neo_ctx *c, int64_t *dev_counts) {
+  if (!c) return NEO_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->mu);
+  c->sample_counter = reinterpret_cast<long long *>(dev_counts);
   return NEO_OK;
 }
 

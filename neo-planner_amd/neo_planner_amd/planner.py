@@ -74,7 +74,7 @@ class MinJerkPlanner:
 
     def __init__(self, config=None, ctx=None, sample_dtype="f64", stale_T=True):
         config = config if config is not None else PlannerConfig()
-        self.ctx = ctx if ctx is not None else _lib.default_context()
+        self._ctx = ctx             # created on first device use: host-only helpers work without a GPU
         self.s = 3
         self.v_max = config.v_max
         self.T_min = config.T_min
@@ -96,6 +96,12 @@ class MinJerkPlanner:
         self.stale_T = stale_T
         self._cache = {}
         self._scene = None
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = _lib.default_context()
+        return self._ctx
 
     # ------------------------------------------------------------ initial guesses (:82-140)
     def generate_init_variables(self, head_state, tail_state, seed=0):
@@ -226,6 +232,10 @@ class MinJerkPlanner:
         self.last_status, self.last_nit, self.last_nfev = code, int(nit[0]), int(nfev[0])
         if code == _lib.NEO_TRAJ_NUMERIC_RANGE:
             raise OverflowError("math range error")          # what math.exp raises at :481
+        if code == _lib.NEO_TRAJ_NONFINITE:
+            # the reference leaves minimize() through Python-float overflow in the same situation
+            # (e.g. (jerk)**2 at :382 once a line-search trial point blows the coefficients up)
+            raise OverflowError(34, "Numerical result out of range")
         self._unpack_x(x[0])
         self.iter_num += int(nit[0])
         self.opt_running_times += 1
@@ -344,9 +354,15 @@ class BatchPlanner:
 
     def __init__(self, config=None, ctx=None, sample_dtype="f64", stale_T=True):
         self.cfg = config if config is not None else PlannerConfig()
-        self.ctx = ctx if ctx is not None else _lib.default_context()
+        self._ctx = ctx
         self.sample_dtype = sample_dtype
         self.stale_T = stale_T
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = _lib.default_context()
+        return self._ctx
 
     def _sync(self):
         _push_params(self.ctx, self.cfg, self.sample_dtype, self.stale_T)
