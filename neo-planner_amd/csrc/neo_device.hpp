@@ -501,11 +501,15 @@ __device__ __forceinline__ void minco_sample(const Traj<D> &t, const DevParams &
 // backward pass (PIECE layout): gC = dW/dc incl. sampled part, gT = direct dW/dT incl. sampled part
 // (energy and time parts are added here).  Outputs grad wrt the start-joint position of the lane
 // (gq, valid for lanes 1..M-1) and grad wrt tau (gtau, lanes 0..M-1).
+// Returns 0, or 4 where the reference would leave through OverflowError: it raises Python floats to
+// a power in two places, `(np.dot(c, beta3).item())**2` (:382) and `(1+math.exp(-tau))**2` (:490),
+// and Python raises once such a result exceeds the double range instead of returning inf.
 template <int D>
-__device__ __forceinline__ void minco_backward(const Traj<D> &t, const DevParams &prm, double (&gC)[6][D],
-                                               double gT, double (&gq)[D], double &gtau) {
+__device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams &prm, double (&gC)[6][D],
+                                              double gT, double (&gq)[D], double &gtau) {
   const int lane = lane_id();
   const int M = t.M;
+  int pow_overflow = 0;
   const double T = t.T, T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
   const double w0 = prm.w[0];
   double jerk_end[D], snap_end[D], crackle[D];
@@ -520,6 +524,7 @@ __device__ __forceinline__ void minco_backward(const Traj<D> &t, const DevParams
     jerk_end[d] = 6.0 * c3 + 24.0 * T * c4 + 60.0 * T2 * c5;
     snap_end[d] = 24.0 * c4 + 120.0 * T * c5;
     crackle[d] = 120.0 * c5;
+    if (lane < M && fabs(jerk_end[d]) > 1.3407807929942596e154) pow_overflow = 1;  // sqrt(DBL_MAX)
     gT += w0 * jerk_end[d] * jerk_end[d];
   }
   // gz = H(T)^T gC : sensitivity wrt the end states Z = (p0, v0, a0, p1, v1, a1)
@@ -626,7 +631,10 @@ __device__ __forceinline__ void minco_backward(const Traj<D> &t, const DevParams
   }
   // get_grad_T2tau (:485-492)
   const double ex = exp(-t.tau);
+  // `(1 + math.exp(-tau))**2` (:490) is a Python-float power too: OverflowError beyond sqrt(DBL_MAX)
+  if (lane < M && (1.0 + ex) > 1.3407807929942596e154) pow_overflow = 1;
   gtau = gTt * (prm.T_max - prm.T_min) * ex / ((1.0 + ex) * (1.0 + ex));
+  return __any(pow_overflow) ? 4 : 0;
 }
 
 }  // namespace neo

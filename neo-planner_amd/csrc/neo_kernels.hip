@@ -149,7 +149,8 @@ struct DevBackend {
     costs[3] = uniform(ck);
     f = costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3];
     double gq[D], gtau;
-    minco_backward<D>(t, prm, gC, gT, gq, gtau);
+    const int bst = minco_backward<D>(t, prm, gC, gT, gq, gtau);
+    if (bst != 0) return bst;
     // PIECE -> FLAT
     __syncthreads();
     if (lane >= 1 && lane < t.M) {
@@ -349,9 +350,9 @@ __global__ void edt_rows_kernel(const int *__restrict__ g, int W, int H, double 
   double *out = dist + (size_t)y * W;
   if (k < 0) {
     // no occupied cell in the whole map: scipy.ndimage.distance_transform_edt then measures to a
-    // virtual background cell at index (-1, -1); the reference inherits that (esdf.py:29)
+    // virtual background cell at (row -1, column 0); the reference inherits that (esdf.py:29)
     for (int q = 0; q < W; ++q) {
-      const long long sq = (long long)(y + 1) * (y + 1) + (long long)(q + 1) * (q + 1);
+      const long long sq = (long long)(y + 1) * (y + 1) + (long long)q * q;
       out[q] = sqrt((double)sq) * res;
     }
     return;
