@@ -145,7 +145,7 @@ def main():
     status = torch.zeros_like(nit)
     nsamp = torch.zeros(B, dtype=torch.int64, device=dev)
     ctx.check(ctx.lib.neo_optimize_sample_counter(ctx.h, ctypes.c_void_p(nsamp.data_ptr())))
-    result = torch.empty(B, n + 5, dtype=torch.float32, device=dev)
+    from neo_planner_amd import sharding
     gathered = torch.empty(world * B, n + 5, dtype=torch.float32, device=dev) if world > 1 else None
     w = torch.tensor(bp.cfg.weights, dtype=torch.float64, device=dev)
 
@@ -154,10 +154,7 @@ def main():
         bp.optimize_dev(g3, x, d_head, d_tail, costs, last, nit, nfev, status)
         if world > 1:
             # results to every rank: final x, total cost, 4 cost terms
-            result[:, :n] = x
-            result[:, n] = (costs * w).sum(dim=1)
-            result[:, n + 1:] = costs
-            dist_.all_gather_into_tensor(gathered, result)
+            sharding.gather_results(sharding.pack_results(x, costs, w), world, out=gathered)
 
     def fence():
         torch.cuda.synchronize()

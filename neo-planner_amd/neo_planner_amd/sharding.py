@@ -1,0 +1,45 @@
+"""Scene sharding and result gathering for one-process-per-GPU runs.
+
+Scenes (and the trajectories that belong to them) are independent: rank r of W owns scenes
+r, r+W, r+2W, ... and never exchanges data while optimising.  The only collective is the
+gather of the per-trajectory results at the end: `[B_local, n+5]` fp32 rows
+(final x, total cost, 4 cost terms) -> every rank, RCCL over xGMI on GPUs, gloo in CPU tests."""
+import torch
+import torch.distributed as dist
+
+
+def owned_scenes(n_scenes, rank, world):
+    """round-robin ownership"""
+    return list(range(rank, n_scenes, world))
+
+
+def owner_of(scene, world):
+    return scene % world
+
+
+def pack_results(x, costs, weights):
+    """x [B,n] f64, costs [B,4] f64, weights [4] -> [B, n+5] f32 rows (x, total, 4 terms)"""
+    B, n = x.shape
+    out = torch.empty(B, n + 5, dtype=torch.float32, device=x.device)
+    out[:, :n] = x
+    out[:, n] = (costs * weights).sum(dim=1)
+    out[:, n + 1:] = costs
+    return out
+
+
+def gather_results(local, world, out=None):
+    """all ranks end up with the rows of every rank, rank-major.  Equal B_local on every rank."""
+    if world == 1:
+        return local
+    if out is None:
+        out = torch.empty(world * local.shape[0], local.shape[1], dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out
+
+
+def scene_major_order(gathered, n_scenes, world, rows_per_scene):
+    """reorder rank-major gathered rows (each rank holds its owned scenes in increasing order) into
+    scene order; needs n_scenes divisible by world."""
+    per_rank = n_scenes // world
+    g = gathered.view(world, per_rank, rows_per_scene, gathered.shape[1])
+    return g.permute(1, 0, 2, 3).reshape(n_scenes * rows_per_scene, gathered.shape[1])

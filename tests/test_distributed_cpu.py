@@ -1,0 +1,78 @@
+"""world-size-2 gloo test of the N > 1 path's plumbing (scene ownership, result packing, the one
+gather collective, scene-major reordering) -- runs on CPU; the GPU run uses the same code with RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+from neo_planner_amd import sharding
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _fake_results(scene, rows, n):
+    """stand-in for the optimiser's output of one scene: deterministic in (scene, row)"""
+    g = torch.Generator().manual_seed(1000 + scene)
+    x = torch.rand(rows, n, generator=g, dtype=torch.float64)
+    costs = torch.rand(rows, 4, generator=g, dtype=torch.float64)
+    return x, costs
+
+
+def _worker(rank, world, port, n_scenes, rows, n, q):
+    sys.path.insert(0, os.path.join(REPO, "neo-planner_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = torch.tensor([1.0, 1.0, 1.0, 10000.0], dtype=torch.float64)
+    mine = sharding.owned_scenes(n_scenes, rank, world)
+    local = torch.cat([sharding.pack_results(*_fake_results(s, rows, n), w) for s in mine])
+    allr = sharding.gather_results(local, world)
+    ordered = sharding.scene_major_order(allr, n_scenes, world, rows)
+    dist.barrier()
+    q.put((rank, mine, ordered.numpy()))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_and_gather():
+    world, n_scenes, rows, n = 2, 6, 5, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_scenes, rows, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w = torch.tensor([1.0, 1.0, 1.0, 10000.0], dtype=torch.float64)
+    want = torch.cat([sharding.pack_results(*_fake_results(s, rows, n), w) for s in range(n_scenes)]).numpy()
+    owned = {}
+    for rank, mine, ordered in got:
+        owned[rank] = mine
+        assert np.array_equal(ordered, want)            # every rank holds every scene's rows, in scene order
+    assert owned[0] == [0, 2, 4] and owned[1] == [1, 3, 5]
+    assert sorted(owned[0] + owned[1]) == list(range(n_scenes))
+    assert all(sharding.owner_of(s, world) == r for r, ss in owned.items() for s in ss)
+
+
+def test_pack_results_layout():
+    x = torch.arange(6, dtype=torch.float64).reshape(2, 3)
+    costs = torch.tensor([[1.0, 2.0, 3.0, 4.0], [0.5, 0.0, 0.0, 1e-3]], dtype=torch.float64)
+    w = torch.tensor([1.0, 1.0, 1.0, 10000.0], dtype=torch.float64)
+    r = sharding.pack_results(x, costs, w)
+    assert r.dtype == torch.float32 and r.shape == (2, 8)
+    assert torch.equal(r[:, :3], x.float())
+    assert torch.allclose(r[:, 3], torch.tensor([40006.0, 10.5]))
+    assert torch.equal(r[:, 4:], costs.float())
+    assert sharding.gather_results(r, 1) is r
