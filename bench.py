@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--layout", default="linear", choices=["linear", "brick4"])
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-order", action="store_true", help="dispatch trajectories in index order")
     return ap.parse_args()
 
 
@@ -145,6 +146,10 @@ def main():
     status = torch.zeros_like(nit)
     nsamp = torch.zeros(B, dtype=torch.int64, device=dev)
     ctx.check(ctx.lib.neo_optimize_sample_counter(ctx.h, ctypes.c_void_p(nsamp.data_ptr())))
+    order = None
+    if not a.no_order:
+        order = torch.from_numpy(bp.expected_effort_order(head, tail, ts)).to(dev)
+        ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, ctypes.c_void_p(order.data_ptr())))
     from neo_planner_amd import sharding
     gathered = torch.empty(world * B, n + 5, dtype=torch.float32, device=dev) if world > 1 else None
     w = torch.tensor(bp.cfg.weights, dtype=torch.float64, device=dev)

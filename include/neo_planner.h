@@ -170,8 +170,8 @@ int neo_optimize_batch_dev(neo_ctx *ctx, int scene_id, const int32_t *scene_ids,
 /* slot of a scene in the device-side map table, -1 if it has no map.  Slots change
  * whenever a map is uploaded or dropped. */
 int neo_scene_slot(neo_ctx *ctx, int scene_id);
-/* bytes of device workspace neo_optimize_batch_dev keeps for B trajectories (L-BFGS
- * history); allocated on first use and reused. */
+/* bytes of device (HBM) workspace neo_optimize_batch_dev keeps for B trajectories.  Currently 0:
+ * the L-BFGS history (2 * maxcor * n doubles per trajectory) lives in LDS. */
 size_t neo_optimize_workspace_bytes(int B, int M, int D);
 
 /* ---- trajectory evaluation (traj_utils.py:85-222) --------------------------
@@ -189,6 +189,11 @@ int neo_profile_enable(neo_ctx *ctx, int on);
 /* optional DEVICE array [B] that the next neo_optimize_batch_dev launches fill with the number of
  * quadrature samples (ESDF lookups) each trajectory evaluated; NULL switches it off. */
 int neo_optimize_sample_counter(neo_ctx *ctx, int64_t *dev_counts);
+/* optional DEVICE permutation [B] for the next neo_optimize_batch_dev launches: workgroup i works on
+ * trajectory order[i].  Results stay in the caller's order.  Workgroups start in index order, so
+ * putting the runs expected to be long first shortens the launch (a late long run is its tail);
+ * NULL = identity.  neo_planner_amd.BatchPlanner sorts by time slack (sum(ts) * v_max / distance). */
+int neo_optimize_dispatch_order(neo_ctx *ctx, const int32_t *dev_order);
 int neo_profile_read(neo_ctx *ctx, int kernel, int64_t *launches, double *total_ms);
 int neo_profile_reset(neo_ctx *ctx);
 

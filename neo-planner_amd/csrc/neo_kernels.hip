@@ -26,18 +26,21 @@
 namespace neo {
 
 // ------------------------------------------------------------------ device backend of the optimiser
-template <int D, typename Real, class MapT, class LookupT>
+template <int D, int NS, typename Real, class MapT, class LookupT>
 struct DevBackend {
+  // FLAT layout with NS slots: n <= 64 * NS
   struct Vec {
-    double v[kSlots];
+    double v[NS];
   };
   Traj<D> t;
   const DevParams &prm;
   const MapT &map;
   double *xs;    // LDS [256]: FLAT <-> PIECE staging
   double *sc;    // LDS [2m]: rho / alpha of the two-loop recursion
-  double *hist;  // global [2][m][npad] for this trajectory
-  int npad, nsl, m;
+  LineSearch *lsp;  // LDS: line-search state (wave-uniform)
+  double *cst;      // LDS [12]: cost terms of the last evaluation / current x / previous x
+  double *hist;  // LDS [2][m][n]: the stored (s, y) pairs of this trajectory
+  int npad, m;
   double *coeff_out;  // optional [6M][D] (eval kernel)
   long long samples = 0;  // quadrature samples visited so far (lane-uniform), for the bench's byte count
 
@@ -46,50 +49,49 @@ struct DevBackend {
   __device__ __forceinline__ double dot(const Vec &a, const Vec &b) const {
     double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k)
-      if (k < nsl) s += a.v[k] * b.v[k];
-    return uniform(wave_sum(s));
+    for (int k = 0; k < NS; ++k) s += a.v[k] * b.v[k];
+    return wave_sum(s);
   }
   __device__ __forceinline__ double amax(const Vec &a) const {
     double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k)
-      if (k < nsl) s = fmax(s, fabs(a.v[k]));
-    return uniform(wave_max(s));
+    for (int k = 0; k < NS; ++k) s = fmax(s, fabs(a.v[k]));
+    return wave_max_nonneg(s);
   }
   __device__ __forceinline__ void copy(Vec &d, const Vec &s) const {
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k) d.v[k] = s.v[k];
+    for (int k = 0; k < NS; ++k) d.v[k] = s.v[k];
   }
   __device__ __forceinline__ void neg(Vec &d, const Vec &s) const {
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k) d.v[k] = -s.v[k];
+    for (int k = 0; k < NS; ++k) d.v[k] = -s.v[k];
   }
   __device__ __forceinline__ void axpy(double a, const Vec &x, Vec &y) const {
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k) y.v[k] += a * x.v[k];
+    for (int k = 0; k < NS; ++k) y.v[k] += a * x.v[k];
   }
   __device__ __forceinline__ void lincomb(Vec &o, const Vec &a, double s, const Vec &b) const {
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k) o.v[k] = a.v[k] + s * b.v[k];
+    for (int k = 0; k < NS; ++k) o.v[k] = a.v[k] + s * b.v[k];
   }
   __device__ __forceinline__ void scale(Vec &v, double s) const {
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k) v.v[k] *= s;
+    for (int k = 0; k < NS; ++k) v.v[k] *= s;
   }
   __device__ __forceinline__ void hist_put(int slot, const Vec &s, const Vec &y) {
     const int lane = lane_id();
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k)
-      if (k < nsl) {
-        hist[(size_t)slot * npad + k * kWave + lane] = s.v[k];
-        hist[(size_t)(m + slot) * npad + k * kWave + lane] = y.v[k];
+    for (int k = 0; k < NS; ++k)
+      if (k * kWave + lane < t.n) {
+        hist[slot * t.n + k * kWave + lane] = s.v[k];
+        hist[(m + slot) * t.n + k * kWave + lane] = y.v[k];
       }
+    __syncthreads();
   }
   __device__ __forceinline__ void hist_get(int row, Vec &v) const {
     const int lane = lane_id();
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k) v.v[k] = (k < nsl) ? hist[(size_t)row * npad + k * kWave + lane] : 0.0;
+    for (int k = 0; k < NS; ++k) v.v[k] = (k * kWave + lane < t.n) ? hist[row * t.n + k * kWave + lane] : 0.0;
   }
   __device__ __forceinline__ void hist_get_s(int slot, Vec &v) const { hist_get(slot, v); }
   __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
@@ -98,13 +100,15 @@ struct DevBackend {
     __syncthreads();
   }
   __device__ __forceinline__ double sget(int i) const { return sc[i]; }
+  __device__ __forceinline__ LineSearch &ls() { return *lsp; }
+  __device__ __forceinline__ double *cost_store() { return cst; }
 
   // FLAT x -> PIECE inputs
   __device__ __forceinline__ void scatter_x(const Vec &x) {
     const int lane = lane_id();
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k)
+    for (int k = 0; k < NS; ++k)
       if (k * kWave + lane < t.n) xs[k * kWave + lane] = x.v[k];
     __syncthreads();
     const int M = t.M;
@@ -112,13 +116,13 @@ struct DevBackend {
     t.tau = act ? xs[t.nq + lane] : 0.0;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      t.P0[d] = (lane == 0 || !act) ? t.head[0][d] : xs[d * (M - 1) + lane - 1];
-      t.P1[d] = (lane >= M - 1) ? t.tail[0][d] : xs[d * (M - 1) + lane];
+      t.P0[d] = (lane == 0 || !act) ? t.head[d] : xs[d * (M - 1) + (lane > 0 ? lane - 1 : 0)];
+      t.P1[d] = (lane >= M - 1) ? t.tail[d] : xs[d * (M - 1) + lane];
     }
   }
 
   // one evaluation of cost and gradient (get_cost + get_grad, :539-585)
-  __device__ __forceinline__ int eval(const Vec &x, double &f, Vec &g, double (&costs)[4]) {
+  __device__ __forceinline__ int eval(const Vec &x, double &f, Vec &g, double *costs) {
     const int lane = lane_id();
     scatter_x(x);
     double energy, tsum;
@@ -160,7 +164,7 @@ struct DevBackend {
     if (lane < t.M) xs[t.nq + lane] = gtau;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kSlots; ++k) g.v[k] = (k * kWave + lane < t.n) ? xs[k * kWave + lane] : 0.0;
+    for (int k = 0; k < NS; ++k) g.v[k] = (k * kWave + lane < t.n) ? xs[k * kWave + lane] : 0.0;
     return 0;
   }
 };
@@ -172,13 +176,8 @@ __device__ __forceinline__ void load_boundary(Traj<D> &t, const double *head, co
   t.n = t.nq + M;
   int L = kWave / M;
   t.L = L < 1 ? 1 : L;
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      t.head[k][d] = head[k * D + d];
-      t.tail[k][d] = tail[k * D + d];
-    }
+  t.head = head;
+  t.tail = tail;
 }
 
 struct MapTable {
@@ -186,7 +185,7 @@ struct MapTable {
 };
 
 // ------------------------------------------------------------------ kernels
-template <int D, typename Real, class MapT, class LookupT>
+template <int D, int NS, typename Real, class MapT, class LookupT>
 __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm, MapT map,
                                                       const double *__restrict__ x,
                                                       const double *__restrict__ head,
@@ -194,29 +193,33 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
                                                       double *__restrict__ cost, double *__restrict__ costs4,
                                                       double *__restrict__ grad, double *__restrict__ coeffs,
                                                       int *__restrict__ status) {
-  __shared__ double xs[kSlots * kWave];
+  __shared__ double xs[NS * kWave];
   __shared__ double sc[2 * NEO_LBFGS_M];
+  __shared__ LineSearch lsm;
+  __shared__ double cst[12];
   const int b = blockIdx.x;
   if (b >= B) return;
-  using BE = DevBackend<D, Real, MapT, LookupT>;
+  using BE = DevBackend<D, NS, Real, MapT, LookupT>;
   BE be(prm, map);
   be.xs = xs;
   be.sc = sc;
+  be.lsp = &lsm;
+  be.cst = cst;
   be.hist = nullptr;
   be.m = NEO_LBFGS_M;
   load_boundary<D>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
   const int n = be.t.n;
-  be.nsl = (n + kWave - 1) / kWave;
-  be.npad = be.nsl * kWave;
+  be.npad = NS * kWave;
   be.coeff_out = coeffs ? coeffs + (size_t)b * 6 * M * D : nullptr;
   const int lane = lane_id();
   typename BE::Vec xv, gv;
 #pragma unroll
-  for (int k = 0; k < kSlots; ++k) xv.v[k] = (k * kWave + lane < n) ? x[(size_t)b * n + k * kWave + lane] : 0.0;
-  double f, costs[4];
+  for (int k = 0; k < NS; ++k) xv.v[k] = (k * kWave + lane < n) ? x[(size_t)b * n + k * kWave + lane] : 0.0;
+  double f;
+  double *costs = cst;
   const int st = be.eval(xv, f, gv, costs);
 #pragma unroll
-  for (int k = 0; k < kSlots; ++k)
+  for (int k = 0; k < NS; ++k)
     if (k * kWave + lane < n) grad[(size_t)b * n + k * kWave + lane] = gv.v[k];
   if (lane == 0) {
     cost[b] = f;
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
   }
 }
 
-template <int D, typename Real, class MapT, class LookupT>
+template <int D, int NS, typename Real, class MapT, class LookupT>
 __global__ __launch_bounds__(kWave) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
                                                           const int *__restrict__ scene_slot,
                                                           double *__restrict__ x,
@@ -237,32 +240,40 @@ __global__ __launch_bounds__(kWave) void optimize_kernel(int B, int M, DevParams
                                                           double *__restrict__ costs4_last,
                                                           int *__restrict__ nit, int *__restrict__ nfev,
                                                           int *__restrict__ status,
-                                                          long long *__restrict__ nsamples) {
-  __shared__ double xs[kSlots * kWave];
+                                                          long long *__restrict__ nsamples,
+                                                          const int *__restrict__ order) {
+  __shared__ double xs[NS * kWave];
   __shared__ double sc[2 * NEO_LBFGS_M];
-  const int b = blockIdx.x;
-  if (b >= B) return;
-  using BE = DevBackend<D, Real, MapT, LookupT>;
+  __shared__ LineSearch lsm;
+  __shared__ double cst[12];
+  if ((int)blockIdx.x >= B) return;
+  // workgroups are dispatched in index order: `order` lets the caller start the runs it expects to
+  // be long first (list scheduling: a long run that starts last sets the duration of the launch)
+  const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
+  using BE = DevBackend<D, NS, Real, MapT, LookupT>;
   const MapT map = maps[scene_slot ? scene_slot[b] : 0];
   BE be(prm, map);
   be.xs = xs;
   be.sc = sc;
+  be.lsp = &lsm;
+  be.cst = cst;
   be.m = NEO_LBFGS_M;
   be.coeff_out = nullptr;
   load_boundary<D>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
   const int n = be.t.n;
-  be.nsl = (n + kWave - 1) / kWave;
-  be.npad = be.nsl * kWave;
-  be.hist = hist_ws + (size_t)b * 2 * NEO_LBFGS_M * be.npad;
+  be.npad = NS * kWave;
+  extern __shared__ double dyn_lds[];  // 2 * maxcor * n doubles (launch parameter)
+  be.hist = dyn_lds;
+  (void)hist_ws;
   const int lane = lane_id();
   typename BE::Vec xv;
 #pragma unroll
-  for (int k = 0; k < kSlots; ++k) xv.v[k] = (k * kWave + lane < n) ? x[(size_t)b * n + k * kWave + lane] : 0.0;
+  for (int k = 0; k < NS; ++k) xv.v[k] = (k * kWave + lane < n) ? x[(size_t)b * n + k * kWave + lane] : 0.0;
   LbfgsOpts o{prm.ftol, prm.gtol, prm.maxls, prm.maxiter, prm.maxfun, NEO_LBFGS_M};
   LbfgsResult res;
   lbfgs_minimize(be, xv, o, res);
 #pragma unroll
-  for (int k = 0; k < kSlots; ++k)
+  for (int k = 0; k < NS; ++k)
     if (k * kWave + lane < n) x[(size_t)b * n + k * kWave + lane] = xv.v[k];
   if (lane == 0) {
     int st = res.status;
@@ -433,7 +444,7 @@ __global__ __launch_bounds__(kWave) void traj_state_kernel(int B, int M, DevPara
   };
   DevParams p = prm;
   NoMap nm;
-  DevBackend<D, double, NoMap, NoLookup> be(p, nm);
+  DevBackend<D, kSlots, double, NoMap, NoLookup> be(p, nm);
   be.xs = xs;
   be.sc = sc;
   be.hist = nullptr;
@@ -441,9 +452,8 @@ __global__ __launch_bounds__(kWave) void traj_state_kernel(int B, int M, DevPara
   be.coeff_out = nullptr;
   load_boundary<D>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
   const int n = be.t.n;
-  be.nsl = (n + kWave - 1) / kWave;
   const int lane = lane_id();
-  typename DevBackend<D, double, NoMap, NoLookup>::Vec xv;
+  typename DevBackend<D, kSlots, double, NoMap, NoLookup>::Vec xv;
 #pragma unroll
   for (int k = 0; k < kSlots; ++k) xv.v[k] = (k * kWave + lane < n) ? x[(size_t)b * n + k * kWave + lane] : 0.0;
   be.scatter_x(xv);
@@ -540,6 +550,7 @@ struct neo_ctx {
   bool profile = false;
   ProfileSlot prof[NEO_KERNEL_COUNT];
   long long *sample_counter = nullptr;  // optional device array [B] (neo_optimize_sample_counter)
+  const int *dispatch_order = nullptr;  // optional device permutation [B] (neo_optimize_dispatch_order)
 };
 
 namespace {
@@ -572,6 +583,7 @@ void fill_dev_params(neo_ctx *c) {
   d.maxiter = p.maxiter;
   d.maxfun = p.maxfun;
   d.stale_T = p.bugcompat_stale_T;
+  d.dbg = p.reserved;
 }
 
 struct ProfScope {
@@ -657,75 +669,96 @@ int check_shape(neo_ctx *c, int B, int M, int D) {
   return NEO_OK;
 }
 
-// ---- dispatch over (D, sample dtype, map kind, element type) -------------------
-template <int D, typename Real>
-int launch_eval_2d(neo_ctx *c, const MapEntry &e, int B, int M, const double *x, const double *head,
-                   const double *tail, double *cost, double *costs4, double *grad, double *coeffs, int *status) {
-  hipLaunchKernelGGL((eval_kernel<D, Real, Map2D, Lookup2D<Real>>), dim3(B), dim3(kWave), 0, c->stream, B, M,
-                     c->dev, e.m2, x, head, tail, cost, costs4, grad, coeffs, status);
-  return NEO_OK;
+// ---- dispatch over (D, slots, sample dtype, map kind, element type) ---------------
+int slots_for(int M, int D) {
+  const int n = D * (M - 1) + M;
+  const int ns = (n + kWave - 1) / kWave;
+  return ns <= 1 ? 1 : (ns == 2 ? 2 : 4);
 }
-template <typename Real, typename E>
-int launch_eval_3d(neo_ctx *c, const MapEntry &e, int B, int M, const double *x, const double *head,
-                   const double *tail, double *cost, double *costs4, double *grad, double *coeffs, int *status) {
-  hipLaunchKernelGGL((eval_kernel<3, Real, Map3D, Lookup3D<Real, E>>), dim3(B), dim3(kWave), 0, c->stream, B, M,
-                     c->dev, e.m3, x, head, tail, cost, costs4, grad, coeffs, status);
+
+struct EvalArgs {
+  int B, M;
+  const double *x, *head, *tail;
+  double *cost, *costs4, *grad, *coeffs;
+  int *status;
+};
+
+template <int D, typename Real, class MapT, class LookupT>
+int launch_eval(neo_ctx *c, const MapT &map, const EvalArgs &a) {
+  const dim3 grid(a.B), blk(kWave);
+#define NEO_EVAL(NS)                                                                                         \
+  hipLaunchKernelGGL((eval_kernel<D, NS, Real, MapT, LookupT>), grid, blk, 0, c->stream, a.B, a.M, c->dev, map, \
+                     a.x, a.head, a.tail, a.cost, a.costs4, a.grad, a.coeffs, a.status)
+  switch (slots_for(a.M, D)) {
+    case 1: NEO_EVAL(1); break;
+    case 2: NEO_EVAL(2); break;
+    default: NEO_EVAL(4); break;
+  }
+#undef NEO_EVAL
   return NEO_OK;
 }
 
-int dispatch_eval(neo_ctx *c, const MapEntry &e, int B, int M, int D, const double *x, const double *head,
-                  const double *tail, double *cost, double *costs4, double *grad, double *coeffs, int *status) {
+int dispatch_eval(neo_ctx *c, const MapEntry &e, int D, const EvalArgs &a) {
   const bool f32 = c->params.sample_dtype == NEO_F32;
   if (e.kind == 0) {
     if (D == 2)
-      return f32 ? launch_eval_2d<2, float>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status)
-                 : launch_eval_2d<2, double>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status);
-    return f32 ? launch_eval_2d<3, float>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status)
-               : launch_eval_2d<3, double>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status);
+      return f32 ? launch_eval<2, float, Map2D, Lookup2D<float>>(c, e.m2, a)
+                 : launch_eval<2, double, Map2D, Lookup2D<double>>(c, e.m2, a);
+    return f32 ? launch_eval<3, float, Map2D, Lookup2D<float>>(c, e.m2, a)
+               : launch_eval<3, double, Map2D, Lookup2D<double>>(c, e.m2, a);
   }
   if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
   if (e.elem == NEO_F32)
-    return f32 ? launch_eval_3d<float, float>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status)
-               : launch_eval_3d<double, float>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status);
-  return f32 ? launch_eval_3d<float, __half>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status)
-             : launch_eval_3d<double, __half>(c, e, B, M, x, head, tail, cost, costs4, grad, coeffs, status);
+    return f32 ? launch_eval<3, float, Map3D, Lookup3D<float, float>>(c, e.m3, a)
+               : launch_eval<3, double, Map3D, Lookup3D<double, float>>(c, e.m3, a);
+  return f32 ? launch_eval<3, float, Map3D, Lookup3D<float, __half>>(c, e.m3, a)
+             : launch_eval<3, double, Map3D, Lookup3D<double, __half>>(c, e.m3, a);
 }
 
+struct OptArgs {
+  int B, M;
+  const void *table;
+  const int *slots;
+  double *x;
+  const double *head, *tail;
+  double *costs4, *costs4_last;
+  int *nit, *nfev, *status;
+};
+
 template <int D, typename Real, class MapT, class LookupT>
-int launch_opt(neo_ctx *c, const void *table, const int *slots, int B, int M, double *x, const double *head,
-               const double *tail, double *costs4, double *costs4_last, int *nit, int *nfev, int *status) {
-  hipLaunchKernelGGL((optimize_kernel<D, Real, MapT, LookupT>), dim3(B), dim3(kWave), 0, c->stream, B, M, c->dev,
-                     static_cast<const MapT *>(table), slots, x, head, tail, c->hist, costs4, costs4_last, nit,
-                     nfev, status, c->sample_counter);
+int launch_opt(neo_ctx *c, const OptArgs &a) {
+  const dim3 grid(a.B), blk(kWave);
+  const size_t dyn = (size_t)2 * NEO_LBFGS_M * (D * (a.M - 1) + a.M) * sizeof(double);  // L-BFGS pairs in LDS
+#define NEO_OPT(NS)                                                                                           \
+  hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT>), grid, blk, dyn, c->stream, a.B, a.M, c->dev, \
+                     static_cast<const MapT *>(a.table), a.slots, a.x, a.head, a.tail, c->hist, a.costs4,      \
+                     a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter, c->dispatch_order)
+  switch (slots_for(a.M, D)) {
+    case 1: NEO_OPT(1); break;
+    case 2: NEO_OPT(2); break;
+    default: NEO_OPT(4); break;
+  }
+#undef NEO_OPT
   return NEO_OK;
 }
 
-int dispatch_opt(neo_ctx *c, int kind, int elem, const void *table, const int *slots, int B, int M, int D,
-                 double *x, const double *head, const double *tail, double *costs4, double *costs4_last, int *nit,
-                 int *nfev, int *status) {
+int dispatch_opt(neo_ctx *c, int kind, int elem, int D, const OptArgs &a) {
   const bool f32 = c->params.sample_dtype == NEO_F32;
-#define OPT(DD, RR, MT, LT) \
-  launch_opt<DD, RR, MT, LT>(c, table, slots, B, M, x, head, tail, costs4, costs4_last, nit, nfev, status)
   if (kind == 0) {
-    if (D == 2) return f32 ? OPT(2, float, Map2D, Lookup2D<float>) : OPT(2, double, Map2D, Lookup2D<double>);
-    return f32 ? OPT(3, float, Map2D, Lookup2D<float>) : OPT(3, double, Map2D, Lookup2D<double>);
+    if (D == 2)
+      return f32 ? launch_opt<2, float, Map2D, Lookup2D<float>>(c, a) : launch_opt<2, double, Map2D, Lookup2D<double>>(c, a);
+    return f32 ? launch_opt<3, float, Map2D, Lookup2D<float>>(c, a) : launch_opt<3, double, Map2D, Lookup2D<double>>(c, a);
   }
   if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
-  if (elem == NEO_F32) {
-    using LF = Lookup3D<float, float>;
-    using LD = Lookup3D<double, float>;
-    return f32 ? OPT(3, float, Map3D, LF) : OPT(3, double, Map3D, LD);
-  }
-  using HF = Lookup3D<float, __half>;
-  using HD = Lookup3D<double, __half>;
-  return f32 ? OPT(3, float, Map3D, HF) : OPT(3, double, Map3D, HD);
-#undef OPT
+  if (elem == NEO_F32)
+    return f32 ? launch_opt<3, float, Map3D, Lookup3D<float, float>>(c, a)
+               : launch_opt<3, double, Map3D, Lookup3D<double, float>>(c, a);
+  return f32 ? launch_opt<3, float, Map3D, Lookup3D<float, __half>>(c, a)
+             : launch_opt<3, double, Map3D, Lookup3D<double, __half>>(c, a);
 }
 
-size_t hist_bytes_for(int B, int M, int D) {
-  const int n = D * (M - 1) + M;
-  const size_t npad = (size_t)((n + kWave - 1) / kWave) * kWave;
-  return (size_t)B * 2 * NEO_LBFGS_M * npad * sizeof(double);
+size_t hist_bytes_for(int, int, int) {
+  return 0;  // the L-BFGS pairs live in LDS (2 * maxcor * n doubles per trajectory), not in HBM
 }
 
 void drain_profile(neo_ctx *c) {
@@ -1012,7 +1045,8 @@ int neo_cost_grad_batch_dev(neo_ctx *c, int scene_id, int B, int M, int D, const
   if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for this scene");
   if (B == 0) return NEO_OK;
   ProfScope ps(c, NEO_KERNEL_EVAL);
-  rc = dispatch_eval(c, it->second, B, M, D, x, head, tail, cost, costs4, grad, coeffs, status);
+  const EvalArgs ea{B, M, x, head, tail, cost, costs4, grad, coeffs, status};
+  rc = dispatch_eval(c, it->second, D, ea);
   if (rc) return rc;
   HIPCHK(c, hipGetLastError());
   return NEO_OK;
@@ -1102,7 +1136,8 @@ int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, i
     c->hist_bytes = need;
   }
   ProfScope ps(c, NEO_KERNEL_OPTIMIZE);
-  rc = dispatch_opt(c, kind, elem, table, slots, B, M, D, x, head, tail, costs4, costs4_last, nit, nfev, status);
+  const OptArgs oa{B, M, table, slots, x, head, tail, costs4, costs4_last, nit, nfev, status};
+  rc = dispatch_opt(c, kind, elem, D, oa);
   if (rc) return rc;
   HIPCHK(c, hipGetLastError());
   return NEO_OK;
@@ -1207,6 +1242,13 @@ int neo_optimize_sample_counter(neo_ctx *c, int64_t *dev_counts) {
   if (!c) return NEO_ERR_INVALID;
   std::lock_guard<std::mutex> g(c->mu);
   c->sample_counter = reinterpret_cast<long long *>(dev_counts);
+  return NEO_OK;
+}
+
+int neo_optimize_dispatch_order(neo_ctx *c, const int32_t *dev_order) {
+  if (!c) return NEO_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->mu);
+  c->dispatch_order = dev_order;
   return NEO_OK;
 }
 

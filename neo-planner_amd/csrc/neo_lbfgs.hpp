@@ -54,7 +54,9 @@ struct LbfgsResult {
 //   void scale(Vec& v, double s);
 //   void hist_put(int slot, const Vec& s, const Vec& y); void hist_get_s(int slot, Vec&); hist_get_y
 //   void sput(int idx, double v); double sget(int idx);   2*m wave-uniform scalars
-//   int  eval(const Vec& x, double& f, Vec& g, double costs[4]);   0 = ok
+//   LineSearch& ls(); double* cost_store();   storage for the search state and 3 x 4 cost terms
+//       (on the GPU both live in LDS: wave-uniform data that would otherwise pin ~50 VGPRs)
+//   int  eval(const Vec& x, double& f, Vec& g, double* costs4);   0 = ok
 template <class Backend>
 NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpts &o,
                            LbfgsResult &res) {
@@ -62,7 +64,8 @@ NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpt
   const double epsmch = 2.220446049250313e-16;
   const double big = 1.0e10;
   Vec g, t, r, d, tmp;
-  double f = 0.0, costs[4], cur[4], old[4];
+  double f = 0.0;
+  double *costs = be.cost_store(), *cur = costs + 4, *old = costs + 8;
   int nfev = 0, nit = 0;
   int col = 0, head = 0;  // stored pairs, ring start (oldest)
   double theta = 1.0;
@@ -125,7 +128,7 @@ NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpt
     if (gd >= 0.0) {
       failed = true;  // "ascent direction in projection": info = -4
     } else {
-      LineSearch L;
+      LineSearch &L = be.ls();
       L.ftol = 1.0e-3;
       L.gtol = 0.9;
       L.xtol = 0.1;

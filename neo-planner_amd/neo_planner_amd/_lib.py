@@ -22,7 +22,7 @@ EXPORTS = [
     "neo_esdf_upload_3d", "neo_esdf_drop", "neo_esdf_query", "neo_cost_grad_batch",
     "neo_cost_grad_batch_dev", "neo_optimize_batch", "neo_optimize_batch_dev", "neo_scene_slot",
     "neo_optimize_workspace_bytes", "neo_eval_traj_batch", "neo_profile_enable", "neo_profile_read",
-    "neo_profile_reset", "neo_optimize_sample_counter",
+    "neo_profile_reset", "neo_optimize_sample_counter", "neo_optimize_dispatch_order",
 ]
 
 
@@ -77,6 +77,7 @@ def load():
     L.neo_profile_read.argtypes = [c_p, c_i, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(c_d)]
     L.neo_profile_reset.argtypes = [c_p]
     L.neo_optimize_sample_counter.argtypes = [c_p, c_p]
+    L.neo_optimize_dispatch_order.argtypes = [c_p, c_p]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int or name in ("neo_abi_version",):

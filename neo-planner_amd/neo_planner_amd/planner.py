@@ -412,6 +412,15 @@ class BatchPlanner:
         return dict(x=x, costs=costs, costs_last=last, nit=nit, nfev=nfev, status=st & 0xff,
                     collision=(st & _lib.NEO_TRAJ_FLAG_COLLISION) != 0, final_cost=(costs * w).sum(axis=1))
 
+    def expected_effort_order(self, head, tail, ts):
+        """permutation that starts the runs expected to be long first.  Proxy: time slack of the initial
+        guess, sum(ts) * v_max / distance -- a guess that is far too slow needs many iterations to shed
+        duration (measured on the cfg2 batch: rank correlation 0.5 with the evaluation count)."""
+        head = np.asarray(head); tail = np.asarray(tail); ts = np.asarray(ts)
+        dist = np.linalg.norm(tail[:, 0] - head[:, 0], axis=1)
+        slack = ts.sum(axis=1) * self.cfg.v_max / np.maximum(dist, 1e-9)
+        return np.argsort(-slack, kind="stable").astype(np.int32)
+
     def optimize_dev(self, map, x, head, tail, costs, costs_last, nit, nfev, status, slots=None):
         """torch CUDA tensors (float64 / int32), asynchronous on the context's stream.
         `slots`: optional int32 device tensor of map-table slots (Context.lib.neo_scene_slot)."""

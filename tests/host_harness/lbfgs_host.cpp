@@ -18,6 +18,10 @@ struct HostBackend {
   eval_cb cb;
   void *user;
   std::vector<double> S, Y, scal;
+  neo::LineSearch lsearch;
+  double cost12[12];
+  neo::LineSearch &ls() { return lsearch; }
+  double *cost_store() { return cost12; }
   HostBackend(int n_, int m_, eval_cb cb_, void *u)
       : n(n_), m(m_), cb(cb_), user(u), S(size_t(n_) * m_), Y(size_t(n_) * m_), scal(2 * m_) {}
   static void fit(Vec &v, int n) {
@@ -56,7 +60,7 @@ struct HostBackend {
   void hist_get_y(int slot, Vec &v) { v.assign(&Y[size_t(slot) * n], &Y[size_t(slot) * n] + n); }
   void sput(int i, double v) { scal[i] = v; }
   double sget(int i) { return scal[i]; }
-  int eval(const Vec &x, double &f, Vec &g, double costs[4]) {
+  int eval(const Vec &x, double &f, Vec &g, double *costs) {
     fit(g, n);
     return cb(x.data(), n, &f, g.data(), costs, user);
   }

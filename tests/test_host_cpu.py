@@ -41,9 +41,8 @@ def test_params_default_matches_the_ros_yaml(lib):
 
 
 def test_workspace_size(lib):
-    # B * 2 * maxcor * npad doubles, npad = n rounded up to whole wavefronts
-    assert lib.neo_optimize_workspace_bytes(4096, 21, 3) == 4096 * 2 * 10 * 128 * 8
-    assert lib.neo_optimize_workspace_bytes(1, 3, 2) == 2 * 10 * 64 * 8
+    # the L-BFGS history lives in LDS: no HBM workspace
+    assert lib.neo_optimize_workspace_bytes(4096, 21, 3) == 0
 
 
 def test_null_context_is_rejected(lib):

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""dump per-trajectory optimiser statistics of the cfg2 batch for offline analysis"""
+import os, sys
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "neo-planner_amd"))
+import numpy as np
+import neo_planner_amd as npa
+from neo_planner_amd import synth
+grid = 300; res = 30.0 / grid
+dist = synth.esdf_3d(0, n=grid, res=res)
+B, M = 4096, 21
+head, tail, wp, ts = synth.replan_requests(0, B, M - 1, D=3)
+g3 = npa.ESDF3D(dist, res, synth.DOMAIN_ORIGIN, store="f32")
+bp = npa.BatchPlanner(sample_dtype="f32")
+x0 = bp.pack_x(wp, ts)
+e0 = bp.cost_grad(g3, x0, head, tail)
+r = bp.optimize(g3, x0, head, tail)
+np.savez_compressed(os.path.join(REPO, "gpurun_out", "nfev_dump.npz"), nfev=r["nfev"], nit=r["nit"], status=r["status"],
+                    cost0=e0["cost"], costs0=e0["costs"], gnorm0=np.abs(e0["grad"]).max(axis=1), final=r["final_cost"],
+                    length=np.linalg.norm(tail[:, 0] - head[:, 0], axis=1))
+print("dumped")
