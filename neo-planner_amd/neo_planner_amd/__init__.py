@@ -9,6 +9,7 @@ there is no CPU fallback.
 from ._lib import Context, NeoError, default_context  # noqa: F401
 from .esdf import ESDF, ESDF3D  # noqa: F401
 from .planner import BatchPlanner, MinJerkPlanner, PlannerConfig  # noqa: F401
+# the initializer network (torch) is imported on demand: `from neo_planner_amd import initializer`
 
 __all__ = ["Context", "NeoError", "default_context", "ESDF", "ESDF3D", "BatchPlanner", "MinJerkPlanner",
            "PlannerConfig"]
