@@ -188,6 +188,44 @@ def main():
     kms = ctypes.c_double()
     ctx.check(ctx.lib.neo_profile_read(ctx.h, _lib.NEO_KERNEL_OPTIMIZE, ctypes.byref(launches), ctypes.byref(kms)))
     kernel_ms = kms.value / max(launches.value, 1)
+
+    # ---- the ESDF-lookup kernel on its own (outside the timed region): add_sampled_cost +
+    # add_sampled_grad_CT for the whole batch at the initial guess, coefficients resident in HBM
+    esdf = None
+    if rank == 0:
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())
+        coeffs = torch.zeros(B, 6 * M, D, dtype=torch.float64, device=dev)
+        cost1 = torch.zeros(B, dtype=torch.float64, device=dev)
+        grad1 = torch.zeros(B, n, dtype=torch.float64, device=dev)
+        st1 = torch.zeros(B, dtype=torch.int32, device=dev)
+        ctx.check(ctx.lib.neo_cost_grad_batch_dev(ctx.h, g3.scene_id, B, M, D, pp(x0), pp(d_head), pp(d_tail), pp(cost1),
+                                                  pp(costs), pp(grad1), pp(coeffs), pp(st1)))
+        d_ts = torch.from_numpy(np.ascontiguousarray(ts)).to(dev)
+        c2 = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+        gC = torch.zeros_like(coeffs)
+        gT = torch.zeros(B, M, dtype=torch.float64, device=dev)
+        run = lambda: ctx.check(ctx.lib.neo_sampled_terms_batch_dev(ctx.h, g3.scene_id, B, M, D, pp(coeffs), pp(d_ts),
+                                                                    pp(c2), pp(gC), pp(gT)))
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        ctx.check(ctx.lib.neo_profile_reset(ctx.h))
+        ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
+        for _ in range(50):
+            run()
+        torch.cuda.synchronize()
+        ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
+        l2 = ctypes.c_int64(); m2 = ctypes.c_double()
+        ctx.check(ctx.lib.neo_profile_read(ctx.h, _lib.NEO_KERNEL_ESDF_SAMPLE, ctypes.byref(l2), ctypes.byref(m2)))
+        us = 1e3 * m2.value / max(l2.value, 1)
+        n_samples = int(np.floor(ts / bp.cfg.delta_t).astype(np.int64).sum())
+        # algorithmic bytes: 8 corners x 4 B per sample, plus this kernel's own operands
+        # (coefficients in, their partials out, durations in / partials out, 2 cost terms)
+        by = n_samples * 32.0 + B * (2 * 6 * M * D * 8 + 2 * M * 8 + 16)
+        esdf = {"kernel": "sample_kernel", "bound": "hbm", "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "kernel_us": us, "launches": int(l2.value),
+                "samples_per_launch": n_samples, "algorithmic_bytes_per_launch": by,
+                "lookups_per_s": n_samples / (us * 1e-6)}
     nfev_h = nfev.cpu().numpy().astype(np.int64)
     nsamp_h = nsamp.cpu().numpy()
     status_h = status.cpu().numpy()
@@ -213,6 +251,7 @@ def main():
                          "kernel_ms": kernel_ms, "launches": int(launches.value),
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "evals_per_launch": int(nfev_h.sum()), "samples_per_launch": int(nsamp_h.sum())},
+            "esdf_kernel": esdf,
             "cpu_baseline": cpu,
             "optimizer": {"mean_nfev": float(nfev_h.mean()), "max_nfev": int(nfev_h.max()),
                           "mean_nit": float(nit.float().mean().item()),

@@ -148,6 +148,17 @@ int neo_cost_grad_batch_dev(neo_ctx *ctx, int scene_id, int B, int M, int D, con
                             const double *head, const double *tail, double *cost, double *costs4,
                             double *grad, double *coeffs, int32_t *status);
 
+/* ---- sampled terms alone (expert_planner.py:392-466: add_sampled_cost + add_sampled_grad_CT) ----
+ * The ESDF-lookup kernel on its own, as the reference uses it after get_coeffs()
+ * (all_planner_demo.py:46-51).  coeffs[B][6M][D], ts[B][M]  ->
+ *   costs2[B][2]      unweighted feasibility and collision cost            (:413, :422)
+ *   grad_C[B][6M][D]  weighted partials w.r.t. the coefficients            (:450, :465)
+ *   grad_T[B][M]      weighted partials w.r.t. the durations               (:451, :466) */
+int neo_sampled_terms_batch(neo_ctx *ctx, int scene_id, int B, int M, int D, const double *coeffs,
+                            const double *ts, double *costs2, double *grad_C, double *grad_T);
+int neo_sampled_terms_batch_dev(neo_ctx *ctx, int scene_id, int B, int M, int D, const double *coeffs,
+                                const double *ts, double *costs2, double *grad_C, double *grad_T);
+
 /* ---- optimiser (expert_planner.py:205-237: plan_once) ----------------------
  * Runs L-BFGS-B(maxcor 10, no bounds) from x to termination for every trajectory,
  * entirely on the device.  scene_ids[B] selects the map per trajectory (NULL = all
@@ -184,7 +195,7 @@ int neo_eval_traj_batch(neo_ctx *ctx, int B, int M, int D, const double *x, cons
 /* ---- timing of the device work (bench.py) ----------------------------------
  * When enabled, every kernel launch of the named family is bracketed by HIP events on
  * the context stream; neo_profile_read returns launches and summed milliseconds. */
-enum { NEO_KERNEL_EVAL = 0, NEO_KERNEL_OPTIMIZE = 1, NEO_KERNEL_ESDF_BUILD = 2, NEO_KERNEL_COUNT = 3 };
+enum { NEO_KERNEL_EVAL = 0, NEO_KERNEL_OPTIMIZE = 1, NEO_KERNEL_ESDF_BUILD = 2, NEO_KERNEL_ESDF_SAMPLE = 3, NEO_KERNEL_COUNT = 4 };
 int neo_profile_enable(neo_ctx *ctx, int on);
 /* optional DEVICE array [B] that the next neo_optimize_batch_dev launches fill with the number of
  * quadrature samples (ESDF lookups) each trajectory evaluated; NULL switches it off. */

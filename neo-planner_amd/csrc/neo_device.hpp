@@ -52,6 +52,7 @@ struct Map3D {
   int layout;  // 0 linear [z][y][x], 1 = 4x4x4 bricks
   int bx, by;  // bricks per axis (layout 1)
   double res, ox, oy, oz;
+  unsigned int bytes;  // size of the stored field (buffer-descriptor range)
 };
 
 // ------------------------------------------------------------------ wave helpers
@@ -203,17 +204,44 @@ __device__ __forceinline__ float elem_to_float<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ float elem_to_float<__half>(__half v) { return __half2float(v); }
 
-// two x-adjacent voxels in one (dword-aligned) load
+// two x-adjacent voxels in ONE load that is only element-aligned: an integer of twice the element
+// size with reduced alignment (gfx950 global loads accept dword-aligned dwordx2), split afterwards.
+// (Loading a two-member struct instead gets scalarised into two loads before the backend sees it.)
+typedef unsigned long long u64_align4 __attribute__((aligned(4)));
+typedef unsigned int u32_align2 __attribute__((aligned(2)));
 template <typename E>
-struct __attribute__((packed, aligned(sizeof(E)))) Pair {
-  E a, b;
-};
+__device__ __forceinline__ void load_pair(const E *p, float &a, float &b);
+template <>
+__device__ __forceinline__ void load_pair<float>(const float *p, float &a, float &b) {
+  const unsigned long long u = *reinterpret_cast<const u64_align4 *>(p);
+  a = __uint_as_float((unsigned int)(u & 0xffffffffull));
+  b = __uint_as_float((unsigned int)(u >> 32));
+}
+// The compiler splits a dword-aligned 8-byte *global* load into two dword loads; a raw buffer load
+// of 8 bytes at a dword-aligned offset is one instruction and returns the right data on gfx950
+// (tools/probe/unaligned_pair.hip).  `off` = byte offset into the field.
+__device__ __forceinline__ void buffer_load_pair_f32(__amdgpu_buffer_rsrc_t rsrc, unsigned int off, float &a, float &b) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off, 0, 0);
+  a = __uint_as_float(v[0]);
+  b = __uint_as_float(v[1]);
+}
+template <>
+__device__ __forceinline__ void load_pair<__half>(const __half *p, float &a, float &b) {
+  const unsigned int u = *reinterpret_cast<const u32_align2 *>(p);
+  a = __half2float(__ushort_as_half((unsigned short)(u & 0xffffu)));
+  b = __half2float(__ushort_as_half((unsigned short)(u >> 16)));
+}
 
 // trilinear distance + analytic gradient (oracle/minco_np.py:Grid3DESDF defines the semantics)
-template <typename Real, typename E>
+// LAYOUT is a template parameter (0 linear, 1 bricks): a run-time branch on the layout inside the sample
+// loop makes the compiler join the two load paths and wait for each sample's loads right there,
+// which defeats keeping several samples' gathers in flight.
+template <typename Real, typename E, int LAYOUT>
 struct Lookup3D {
   const Map3D &m;
-  __device__ __forceinline__ explicit Lookup3D(const Map3D &m_) : m(m_) {}
+  __amdgpu_buffer_rsrc_t rsrc;
+  __device__ __forceinline__ explicit Lookup3D(const Map3D &m_)
+      : m(m_), rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(m_.data), 0, (int)m_.bytes, 0x00020000)) {}
   struct Addr {
     int i0[3];
     Real fr[3];
@@ -224,7 +252,7 @@ struct Lookup3D {
   };
 
   __device__ __forceinline__ size_t addr(int ix, int iy, int iz) const {
-    if (m.layout == 0) return ((size_t)iz * m.ny + iy) * m.nx + ix;
+    if (LAYOUT == 0 || (LAYOUT == 2 && m.layout == 0)) return ((size_t)iz * m.ny + iy) * m.nx + ix;
     const size_t brick = ((size_t)(iz >> 2) * m.by + (iy >> 2)) * m.bx + (ix >> 2);
     return brick * 64 + ((iz & 3) << 4) + ((iy & 3) << 2) + (ix & 3);
   }
@@ -245,12 +273,9 @@ struct Lookup3D {
         u = (pos[k] - (Real)org[k]) * (Real)(1.0 / m.res);
       if (!(u >= Real(0) && u < (Real)n[k])) a.inside = false;
       u -= Real(0.5);
-      int i = (int)floor(u);
-      i = i < 0 ? 0 : (i > n[k] - 2 ? n[k] - 2 : i);
-      Real f = u - (Real)i;
-      f = f < Real(0) ? Real(0) : (f > Real(1) ? Real(1) : f);
-      a.i0[k] = a.inside ? i : 0;
-      a.fr[k] = f;
+      const int i = min(max((int)floor(u), 0), n[k] - 2);
+      a.i0[k] = i;
+      a.fr[k] = fmin(fmax(u - (Real)i, Real(0)), Real(1));
     }
     if (!a.inside) a.i0[0] = a.i0[1] = a.i0[2] = 0;
     return a;
@@ -258,14 +283,20 @@ struct Lookup3D {
   __device__ __forceinline__ Raw load(const Addr &a) const {
     const E *vox = static_cast<const E *>(m.data);
     Raw q;
-    if (m.layout == 0) {
+    if (LAYOUT == 0 || (LAYOUT == 2 && m.layout == 0)) {  // LAYOUT 2 = decided at run time (point queries)
+      // 32-bit element index of corner (0,0,0); the other three x-pairs sit at +nx, +nx*ny, +nx*ny+nx
+      const unsigned int base = __umul24(__umul24((unsigned)a.i0[2], (unsigned)m.ny) + (unsigned)a.i0[1], (unsigned)m.nx) +
+                                (unsigned)a.i0[0];
+      const unsigned int sy = (unsigned)m.nx, sz = (unsigned)m.nx * (unsigned)m.ny;
 #pragma unroll
       for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
-          const Pair<E> p = *reinterpret_cast<const Pair<E> *>(vox + addr(a.i0[0], a.i0[1] + dy, a.i0[2] + dz));
-          q.c[dz][dy][0] = elem_to_float<E>(p.a);
-          q.c[dz][dy][1] = elem_to_float<E>(p.b);
+          const unsigned int e = base + (dy ? sy : 0u) + (dz ? sz : 0u);
+          if constexpr (sizeof(E) == 4)
+            buffer_load_pair_f32(rsrc, e * 4u, q.c[dz][dy][0], q.c[dz][dy][1]);
+          else
+            load_pair<E>(vox + e, q.c[dz][dy][0], q.c[dz][dy][1]);
         }
     } else {
 #pragma unroll
@@ -552,23 +583,24 @@ __device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, d
 }
 
 // sampled feasibility + collision terms (:392-466), SAMPLE layout.
-// Outputs in PIECE layout: gC (added to), gT (added to); costs wave-uniform.
-template <typename Real, int D, class LookupT>
-__device__ __forceinline__ void minco_sample(const Traj<D> &t, const DevParams &prm, const LookupT &lk,
-                                             double (&gC)[6][D], double &gT, double &cost_feas,
-                                             double &cost_coll) {
+// In (PIECE layout): cp = coefficients of the lane's piece, ns_piece = its sample count.
+// Out (PIECE layout): gC, gT = weighted partials of the two sampled terms; costs wave-uniform.
+// U = samples per lane whose gathers are put in flight together.
+template <typename Real, int D, class LookupT, int U>
+__device__ __forceinline__ void minco_sample(int M, int L, int ns_piece, const Real (&cp)[6][D],
+                                             const DevParams &prm, const LookupT &lk, Real (&gC)[6][D], Real &gT,
+                                             double &cost_feas, double &cost_coll) {
   const int lane = lane_id();
-  const int L = t.L;
   const int piece = lane / L, r = lane - piece * L;
-  const bool act = piece < t.M;
+  const bool act = piece < M;
   // hand the piece data to its L sample lanes
   Real c[6][D];
 #pragma unroll
   for (int k = 0; k < 6; ++k)
 #pragma unroll
-    for (int d = 0; d < D; ++d) c[k][d] = __shfl((Real)t.c[k][d], piece, kWave);
-  const int ns_piece = __shfl(t.ns, piece, kWave);
-  const int ns = act ? ns_piece : 0;
+    for (int d = 0; d < D; ++d) c[k][d] = __shfl(cp[k][d], piece, kWave);
+  const int ns_sh = __shfl(ns_piece, piece, kWave);
+  const int ns = act ? ns_sh : 0;
   const int iters = (prm.dbg & 1) ? 0 : wave_max_nonneg((ns + L - 1) / L);
 
   const Real dt = (Real)prm.delta_t, vmax2 = (Real)(prm.v_max * prm.v_max), safe = (Real)prm.safe_dis;
@@ -582,8 +614,7 @@ __device__ __forceinline__ void minco_sample(const Traj<D> &t, const DevParams &
   Real aT = Real(0), aF = Real(0), aK = Real(0);
 
   // U samples per lane are prepared together and their gathers issued back to back before any of
-  // them is consumed: the loop is bound by the latency of the (Infinity-Cache resident) field.
-  constexpr int U = sizeof(Real) == 4 ? 4 : 2;
+  // them is consumed
   for (int it0 = 0; it0 < iters; it0 += U) {
     Real sv[U], pos[U][D], vel[U][D];
     typename LookupT::Addr ad[U];
@@ -655,21 +686,21 @@ __device__ __forceinline__ void minco_sample(const Traj<D> &t, const DevParams &
     }
   }
   // fold the L lanes of each piece (fixed tree), then move lane piece*L -> lane piece
-  auto fold = [&](Real v) -> double {
+  auto fold = [&](Real v) -> Real {
     for (int sft = 1; sft < L; sft <<= 1) {
       const Real o = __shfl_down(v, sft, kWave);
       if (r + sft < L) v += o;
     }
-    return (double)__shfl(v, lane * L, kWave);
+    return __shfl(v, lane * L, kWave);
   };
 #pragma unroll
   for (int k = 0; k < 6; ++k)
 #pragma unroll
-    for (int d = 0; d < D; ++d) gC[k][d] += fold(aC[k][d]);
-  gT += fold(aT);
-  const double pf = fold(aF), pk = fold(aK);
-  cost_feas = wave_sum(lane < t.M ? pf : 0.0);
-  cost_coll = wave_sum(lane < t.M ? pk : 0.0);
+    for (int d = 0; d < D; ++d) gC[k][d] = fold(aC[k][d]);
+  gT = fold(aT);
+  const Real pf = fold(aF), pk = fold(aK);
+  cost_feas = wave_sum(lane < M ? (double)pf : 0.0);
+  cost_coll = wave_sum(lane < M ? (double)pk : 0.0);
 }
 
 // backward pass (PIECE layout): gC = dW/dc incl. sampled part, gT = direct dW/dT incl. sampled part

@@ -141,12 +141,20 @@ struct DevBackend {
         for (int d = 0; d < D; ++d) coeff_out[(size_t)(6 * lane + k) * D + d] = t.c[k][d];
     }
     double gC[6][D], gT = 0.0, cf, ck;
+    {
+      Real cr[6][D], gCr[6][D], gTr;
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
+      for (int k = 0; k < 6; ++k)
 #pragma unroll
-      for (int d = 0; d < D; ++d) gC[k][d] = 0.0;
-    LookupT lk(map);
-    minco_sample<Real, D, LookupT>(t, prm, lk, gC, gT, cf, ck);
+        for (int d = 0; d < D; ++d) cr[k][d] = (Real)t.c[k][d];
+      LookupT lk(map);
+      minco_sample<Real, D, LookupT, (sizeof(Real) == 4 ? 4 : 2)>(t.M, t.L, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int d = 0; d < D; ++d) gC[k][d] = (double)gCr[k][d];
+      gT = (double)gTr;
+    }
     costs[0] = uniform(energy);
     costs[1] = uniform(tsum);
     costs[2] = uniform(cf);
@@ -288,6 +296,44 @@ __global__ __launch_bounds__(kWave) void optimize_kernel(int B, int M, DevParams
     nfev[b] = res.nfev;
     status[b] = st;
     if (nsamples) nsamples[b] = be.samples;
+  }
+}
+
+// add_sampled_cost + add_sampled_grad_CT (expert_planner.py:392-466) as a kernel of its own: the ESDF
+// lookup kernel.  Input: polynomial coefficients and durations; output: the two sampled cost terms and
+// their partials w.r.t. coefficients and durations.  One wavefront per trajectory, SAMPLE layout.
+template <int D, typename Real, class MapT, class LookupT>
+__global__ __launch_bounds__(kWave, 3) void sample_kernel(int B, int M, DevParams prm, MapT map,
+                                                           const double *__restrict__ coeffs,
+                                                           const double *__restrict__ ts,
+                                                           double *__restrict__ costs2, double *__restrict__ grad_C,
+                                                           double *__restrict__ grad_T) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int lane = lane_id();
+  int L = kWave / M;
+  L = L < 1 ? 1 : L;
+  const bool act = lane < M;
+  const double T = act ? ts[(size_t)b * M + lane] : 1.0;
+  const int ns = act ? (int)(T / prm.delta_t) : 0;
+  Real c[6][D], gC[6][D], gT;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int d = 0; d < D; ++d) c[k][d] = act ? (Real)coeffs[((size_t)b * 6 * M + 6 * lane + k) * D + d] : Real(0);
+  double cf, ck;
+  LookupT lk(map);
+  minco_sample<Real, D, LookupT, 2>(M, L, ns, c, prm, lk, gC, gT, cf, ck);
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int d = 0; d < D; ++d) grad_C[((size_t)b * 6 * M + 6 * lane + k) * D + d] = (double)gC[k][d];
+    grad_T[(size_t)b * M + lane] = (double)gT;
+  }
+  if (lane == 0) {
+    costs2[(size_t)b * 2 + 0] = cf;
+    costs2[(size_t)b * 2 + 1] = ck;
   }
 }
 
@@ -708,11 +754,15 @@ int dispatch_eval(neo_ctx *c, const MapEntry &e, int D, const EvalArgs &a) {
                : launch_eval<3, double, Map2D, Lookup2D<double>>(c, e.m2, a);
   }
   if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
-  if (e.elem == NEO_F32)
-    return f32 ? launch_eval<3, float, Map3D, Lookup3D<float, float>>(c, e.m3, a)
-               : launch_eval<3, double, Map3D, Lookup3D<double, float>>(c, e.m3, a);
-  return f32 ? launch_eval<3, float, Map3D, Lookup3D<float, __half>>(c, e.m3, a)
-             : launch_eval<3, double, Map3D, Lookup3D<double, __half>>(c, e.m3, a);
+#define NEO_3D(LAY)                                                                                  \
+  if (e.elem == NEO_F32)                                                                             \
+    return f32 ? launch_eval<3, float, Map3D, Lookup3D<float, float, LAY>>(c, e.m3, a)               \
+               : launch_eval<3, double, Map3D, Lookup3D<double, float, LAY>>(c, e.m3, a);            \
+  return f32 ? launch_eval<3, float, Map3D, Lookup3D<float, __half, LAY>>(c, e.m3, a)                \
+             : launch_eval<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, e.m3, a);
+  if (e.m3.layout == 0) { NEO_3D(0) }
+  NEO_3D(1)
+#undef NEO_3D
 }
 
 struct OptArgs {
@@ -742,7 +792,7 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
   return NEO_OK;
 }
 
-int dispatch_opt(neo_ctx *c, int kind, int elem, int D, const OptArgs &a) {
+int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArgs &a) {
   const bool f32 = c->params.sample_dtype == NEO_F32;
   if (kind == 0) {
     if (D == 2)
@@ -750,11 +800,49 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int D, const OptArgs &a) {
     return f32 ? launch_opt<3, float, Map2D, Lookup2D<float>>(c, a) : launch_opt<3, double, Map2D, Lookup2D<double>>(c, a);
   }
   if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
-  if (elem == NEO_F32)
-    return f32 ? launch_opt<3, float, Map3D, Lookup3D<float, float>>(c, a)
-               : launch_opt<3, double, Map3D, Lookup3D<double, float>>(c, a);
-  return f32 ? launch_opt<3, float, Map3D, Lookup3D<float, __half>>(c, a)
-             : launch_opt<3, double, Map3D, Lookup3D<double, __half>>(c, a);
+#define NEO_3D(LAY)                                                                       \
+  if (elem == NEO_F32)                                                                    \
+    return f32 ? launch_opt<3, float, Map3D, Lookup3D<float, float, LAY>>(c, a)           \
+               : launch_opt<3, double, Map3D, Lookup3D<double, float, LAY>>(c, a);        \
+  return f32 ? launch_opt<3, float, Map3D, Lookup3D<float, __half, LAY>>(c, a)            \
+             : launch_opt<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, a);
+  if (layout == 0) { NEO_3D(0) }
+  NEO_3D(1)
+#undef NEO_3D
+}
+
+struct SampleArgs {
+  int B, M;
+  const double *coeffs, *ts;
+  double *costs2, *grad_C, *grad_T;
+};
+
+template <int D, typename Real, class MapT, class LookupT>
+int launch_sample(neo_ctx *c, const MapT &map, const SampleArgs &a) {
+  hipLaunchKernelGGL((sample_kernel<D, Real, MapT, LookupT>), dim3(a.B), dim3(kWave), 0, c->stream, a.B, a.M, c->dev,
+                     map, a.coeffs, a.ts, a.costs2, a.grad_C, a.grad_T);
+  return NEO_OK;
+}
+
+int dispatch_sample(neo_ctx *c, const MapEntry &e, int D, const SampleArgs &a) {
+  const bool f32 = c->params.sample_dtype == NEO_F32;
+  if (e.kind == 0) {
+    if (D == 2)
+      return f32 ? launch_sample<2, float, Map2D, Lookup2D<float>>(c, e.m2, a)
+                 : launch_sample<2, double, Map2D, Lookup2D<double>>(c, e.m2, a);
+    return f32 ? launch_sample<3, float, Map2D, Lookup2D<float>>(c, e.m2, a)
+               : launch_sample<3, double, Map2D, Lookup2D<double>>(c, e.m2, a);
+  }
+  if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
+#define NEO_3D(LAY)                                                                                  \
+  if (e.elem == NEO_F32)                                                                             \
+    return f32 ? launch_sample<3, float, Map3D, Lookup3D<float, float, LAY>>(c, e.m3, a)             \
+               : launch_sample<3, double, Map3D, Lookup3D<double, float, LAY>>(c, e.m3, a);          \
+  return f32 ? launch_sample<3, float, Map3D, Lookup3D<float, __half, LAY>>(c, e.m3, a)              \
+             : launch_sample<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, e.m3, a);
+  if (e.m3.layout == 0) { NEO_3D(0) }
+  NEO_3D(1)
+#undef NEO_3D
 }
 
 size_t hist_bytes_for(int, int, int) {
@@ -997,7 +1085,8 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
                        layout, bx, by, (__half *)e.data);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (staged) hipFree(staged);
-  e.m3 = Map3D{e.data, nx, ny, nz, layout, bx, by, res, origin[0], origin[1], origin[2]};
+  e.m3 = Map3D{e.data, nx, ny, nz, layout, bx, by, res, origin[0], origin[1], origin[2],
+               (unsigned int)((nstore + 64) * dsz)};
   c->maps[scene_id] = e;
   c->table_dirty = true;
   return NEO_OK;
@@ -1022,10 +1111,10 @@ int neo_esdf_query(neo_ctx *c, int scene_id, int n, const double *pts, double *d
     hipLaunchKernelGGL((query_kernel<double, Map2D, Lookup2D<double>, 2>), grid, blk, 0, c->stream, n, e.m2, d_p, d_d,
                        d_g);
   else if (e.elem == NEO_F32)
-    hipLaunchKernelGGL((query_kernel<double, Map3D, Lookup3D<double, float>, 3>), grid, blk, 0, c->stream, n, e.m3,
+    hipLaunchKernelGGL((query_kernel<double, Map3D, Lookup3D<double, float, 2>, 3>), grid, blk, 0, c->stream, n, e.m3,
                        d_p, d_d, d_g);
   else
-    hipLaunchKernelGGL((query_kernel<double, Map3D, Lookup3D<double, __half>, 3>), grid, blk, 0, c->stream, n, e.m3,
+    hipLaunchKernelGGL((query_kernel<double, Map3D, Lookup3D<double, __half, 2>, 3>), grid, blk, 0, c->stream, n, e.m3,
                        d_p, d_d, d_g);
   HIPCHK(c, hipMemcpyAsync(dist, d_d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (grad) HIPCHK(c, hipMemcpyAsync(grad, d_g, (size_t)n * dm * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1093,6 +1182,56 @@ int neo_cost_grad_batch(neo_ctx *c, int scene_id, int B, int M, int D, const dou
   return NEO_OK;
 }
 
+int neo_sampled_terms_batch_dev(neo_ctx *c, int scene_id, int B, int M, int D, const double *coeffs,
+                                const double *ts, double *costs2, double *grad_C, double *grad_T) {
+  int rc = check_shape(c, B, M, D);
+  if (rc) return rc;
+  if (!coeffs || !ts || !costs2 || !grad_C || !grad_T) return fail(c, NEO_ERR_INVALID, "null buffer");
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  auto it = c->maps.find(scene_id);
+  if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for this scene");
+  if (B == 0) return NEO_OK;
+  ProfScope ps(c, NEO_KERNEL_ESDF_SAMPLE);
+  const SampleArgs sa{B, M, coeffs, ts, costs2, grad_C, grad_T};
+  rc = dispatch_sample(c, it->second, D, sa);
+  if (rc) return rc;
+  HIPCHK(c, hipGetLastError());
+  return NEO_OK;
+}
+
+int neo_sampled_terms_batch(neo_ctx *c, int scene_id, int B, int M, int D, const double *coeffs, const double *ts,
+                            double *costs2, double *grad_C, double *grad_T) {
+  int rc = check_shape(c, B, M, D);
+  if (rc) return rc;
+  if (!coeffs || !ts || !costs2 || !grad_C || !grad_T) return fail(c, NEO_ERR_INVALID, "null buffer");
+  if (B == 0) return NEO_OK;
+  const size_t bs = (size_t)B, nc = (size_t)6 * M * D;
+  double *dco, *dts, *dc2, *dgc, *dgt;
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    hipSetDevice(c->device);
+    rc = ensure_scratch(c, bs * (2 * nc + 2 * M + 2) * sizeof(double) + 6 * 256);
+    if (rc) return rc;
+    Carver cv(c->scratch);
+    dco = cv.take<double>(bs * nc);
+    dts = cv.take<double>(bs * M);
+    dc2 = cv.take<double>(bs * 2);
+    dgc = cv.take<double>(bs * nc);
+    dgt = cv.take<double>(bs * M);
+    HIPCHK(c, hipMemcpyAsync(dco, coeffs, bs * nc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dts, ts, bs * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  rc = neo_sampled_terms_batch_dev(c, scene_id, B, M, D, dco, dts, dc2, dgc, dgt);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipMemcpyAsync(costs2, dc2, bs * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(grad_C, dgc, bs * nc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(grad_T, dgt, bs * M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NEO_OK;
+}
+
 size_t neo_optimize_workspace_bytes(int B, int M, int D) { return hist_bytes_for(B, M, D); }
 
 int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, int B, int M, int D, double *x,
@@ -1107,7 +1246,7 @@ int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, i
   rc = rebuild_tables(c);
   if (rc) return rc;
   // scene_ids (device array) holds map-table SLOTS when given; a single scene_id is looked up here
-  int kind, elem;
+  int kind, elem, layout = 0;
   const void *table;
   const int *slots = scene_ids;
   std::vector<int> one;
@@ -1117,12 +1256,14 @@ int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, i
     if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for the reference scene");
     kind = it->second.kind;
     elem = it->second.elem;
+    layout = it->second.m3.layout;
     table = kind == 0 ? c->table2d : c->table3d;
   } else {
     auto it = c->maps.find(scene_id);
     if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for this scene");
     kind = it->second.kind;
     elem = it->second.elem;
+    layout = it->second.m3.layout;
     const char *base = static_cast<const char *>(kind == 0 ? c->table2d : c->table3d);
     table = base + (size_t)it->second.slot * (kind == 0 ? sizeof(Map2D) : sizeof(Map3D));
   }
@@ -1137,7 +1278,7 @@ int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, i
   }
   ProfScope ps(c, NEO_KERNEL_OPTIMIZE);
   const OptArgs oa{B, M, table, slots, x, head, tail, costs4, costs4_last, nit, nfev, status};
-  rc = dispatch_opt(c, kind, elem, D, oa);
+  rc = dispatch_opt(c, kind, elem, layout, D, oa);
   if (rc) return rc;
   HIPCHK(c, hipGetLastError());
   return NEO_OK;

@@ -13,7 +13,7 @@ NEO_LAYOUT_LINEAR, NEO_LAYOUT_BRICK4 = 0, 1
 NEO_TRAJ_CONVERGED_GRAD, NEO_TRAJ_CONVERGED_F, NEO_TRAJ_ABNORMAL = 0, 1, 2
 NEO_TRAJ_MAXITER, NEO_TRAJ_NUMERIC_RANGE, NEO_TRAJ_NONFINITE = 3, 4, 5
 NEO_TRAJ_FLAG_COLLISION = 0x100
-NEO_KERNEL_EVAL, NEO_KERNEL_OPTIMIZE, NEO_KERNEL_ESDF_BUILD = 0, 1, 2
+NEO_KERNEL_EVAL, NEO_KERNEL_OPTIMIZE, NEO_KERNEL_ESDF_BUILD, NEO_KERNEL_ESDF_SAMPLE = 0, 1, 2, 3
 
 # every symbol include/neo_planner.h declares (tests check the library exports them all)
 EXPORTS = [
@@ -23,6 +23,7 @@ EXPORTS = [
     "neo_cost_grad_batch_dev", "neo_optimize_batch", "neo_optimize_batch_dev", "neo_scene_slot",
     "neo_optimize_workspace_bytes", "neo_eval_traj_batch", "neo_profile_enable", "neo_profile_read",
     "neo_profile_reset", "neo_optimize_sample_counter", "neo_optimize_dispatch_order",
+    "neo_sampled_terms_batch", "neo_sampled_terms_batch_dev",
 ]
 
 
@@ -78,6 +79,8 @@ def load():
     L.neo_profile_reset.argtypes = [c_p]
     L.neo_optimize_sample_counter.argtypes = [c_p, c_p]
     L.neo_optimize_dispatch_order.argtypes = [c_p, c_p]
+    L.neo_sampled_terms_batch.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 5
+    L.neo_sampled_terms_batch_dev.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 5
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int or name in ("neo_abi_version",):

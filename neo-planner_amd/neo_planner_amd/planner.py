@@ -393,6 +393,18 @@ class BatchPlanner:
                                           _lib.ptr(st)))
         return dict(cost=cost, costs=costs, grad=grad, coeffs=coeffs, status=st)
 
+    def sampled_terms(self, map, coeffs, ts):
+        """add_sampled_cost + add_sampled_grad_CT (:392-466) for B trajectories: coeffs (B, 6M, D), ts (B, M)"""
+        self._sync()
+        c = self.ctx
+        coeffs = _lib.as_f64(coeffs); ts = _lib.as_f64(ts)
+        B, M = ts.shape
+        D = coeffs.shape[2]
+        costs2 = np.zeros((B, 2)); gC = np.zeros((B, 6 * M, D)); gT = np.zeros((B, M))
+        c.check(c.lib.neo_sampled_terms_batch(c.h, map.scene_id, B, M, D, _lib.ptr(coeffs), _lib.ptr(ts),
+                                              _lib.ptr(costs2), _lib.ptr(gC), _lib.ptr(gT)))
+        return dict(costs2=costs2, grad_C=gC, grad_T=gT)
+
     def optimize(self, map, x0, head, tail, scene_ids=None):
         """map: one map for all trajectories (scene_ids None) or any map of the right kind plus
         scene_ids (B,) int32 of per-trajectory scene ids."""

@@ -179,6 +179,26 @@ def test_cost_grad_trilinear_matches_oracle():
                     assert rel_err(out["grad"][b], g) < tol * 5
 
 
+def test_sampled_terms_kernel_matches_oracle():
+    """the ESDF-lookup kernel alone: add_sampled_cost + add_sampled_grad_CT (:392-466)"""
+    d = load(golden("g1_eval_s1.npz")[0])
+    m = _gpu_map(d)
+    o2 = _oracle_map(d)
+    for M in (3, 21, 41):
+        t = f"M{M}_"
+        pl = onp.OraclePlanner(onp.PlannerParams())
+        x = d[t + "x"]
+        pl.read_planning_conditions(o2, d[t + "head"], d[t + "tail"], x[:2 * (M - 1)].reshape(2, M - 1), d[t + "ts"])
+        pl.get_cost(x)
+        pl.reset_cost(); pl.add_sampled_cost()
+        pl.reset_grad_CT(); pl.add_sampled_grad_CT()
+        for dtype, tol in (("f64", 1e-11), ("f32", 2e-5)):
+            out = npa.BatchPlanner(sample_dtype=dtype).sampled_terms(m, pl.coeffs[None], pl.ts[None])
+            assert rel_err(out["costs2"][0], pl.costs[2:]) < tol
+            assert rel_err(out["grad_C"][0], pl.grad_C) < tol
+            assert rel_err(out["grad_T"][0], pl.grad_T) < tol
+
+
 def test_3d_problem_on_z_constant_field_reproduces_2d_costs():
     """D = 3 with v_z = 0 on the 2-D map gives the D = 2 costs"""
     rng = np.random.default_rng(9)
