@@ -110,12 +110,16 @@ def main():
     from neo_planner_amd import synth
     res = 30.0 / a.grid
     t_setup = time.time()
-    dist = synth.esdf_3d(rank, n=a.grid, res=res)                      # scene = rank (weak scaling)
+    occ = synth.occupancy_3d(rank, n=a.grid, res=res)                  # scene = rank (weak scaling)
     head, tail, wp, ts = synth.replan_requests(rank, B, M - 1, D=D)
 
-    cpu, cpu_done = None, []
+    cpu, cpu_done, dist_host = None, [], None
     if world == 1 and rank == 0 and not a.no_cpu:
-        cpu, cpu_done = cpu_baseline(dist, res, synth.DOMAIN_ORIGIN, head, tail, wp, ts, a.cpu_seconds)
+        # the CPU port needs the field on the host, before this process touches the GPU (fork safety):
+        # SciPy's exact EDT; the GPU scene below is built on the device and checked against it
+        from scipy import ndimage
+        dist_host = (ndimage.distance_transform_edt(1 - occ) * res).astype(np.float32)
+        cpu, cpu_done = cpu_baseline(dist_host, res, synth.DOMAIN_ORIGIN, head, tail, wp, ts, a.cpu_seconds)
 
     # ---------------- GPU side
     import torch
@@ -134,7 +138,9 @@ def main():
     ctx = npa.Context(local_rank, stream=tstream.cuda_stream)
     bp = npa.BatchPlanner(ctx=ctx, sample_dtype=a.dtype)
     bp._sync()
-    g3 = npa.ESDF3D(torch.from_numpy(dist).to(dev), res, synth.DOMAIN_ORIGIN, store="f32", layout=a.layout, ctx=ctx)
+    g3 = npa.ESDF3D.from_occupancy(torch.from_numpy(occ).to(dev), res, synth.DOMAIN_ORIGIN, store="f32", layout=a.layout,
+                                   ctx=ctx, want_dist=dist_host is not None)
+    esdf_equal = None if dist_host is None else bool(np.array_equal(g3.dist, dist_host))
     x0 = torch.from_numpy(bp.pack_x(wp, ts)).to(dev)
     d_head = torch.from_numpy(head).to(dev)
     d_tail = torch.from_numpy(tail).to(dev)
@@ -257,20 +263,32 @@ def main():
                           "mean_nit": float(nit.float().mean().item()),
                           "status_hist": np.bincount(status_h & 0xff, minlength=6).tolist(),
                           "collision_flag_frac": float(((status_h & 0x100) != 0).mean())},
-            "setup_s": t_gpu0 - t_setup,
+            "setup_s": t_gpu0 - t_setup, "device_edt_equals_scipy": esdf_equal,
         }
         if cpu_done:
             # final-cost delta of the GPU result against the CPU optimiser on the same trajectories
-            fc = (costs * w).sum(dim=1).cpu().numpy()
-            lc = (last * w).sum(dim=1).cpu().numpy()
+            # (cost of the last evaluated point, as the reference reports it, expert_planner.py:233)
             idx = np.array([r[0] for r in cpu_done])
             ref = np.array([r[1] for r in cpu_done])
             good = np.isfinite(ref)
-            rel = np.abs(lc[idx][good] - ref[good]) / np.maximum(np.abs(ref[good]), 1e-12)
-            out["final_cost_delta_vs_cpu"] = {"n": int(good.sum()), "median_rel": float(np.median(rel)),
-                                              "frac_within_1e-4": float((rel <= 1e-4).mean()),
-                                              "frac_within_1e-2": float((rel <= 1e-2).mean()),
-                                              "gpu_mean": float(lc[idx][good].mean()), "cpu_mean": float(ref[good].mean())}
+
+            def delta(last_t, nfev_t):
+                lc = (last_t * w).sum(dim=1).cpu().numpy()[idx][good]
+                rel = np.abs(lc - ref[good]) / np.maximum(np.abs(ref[good]), 1e-12)
+                same = nfev_t.cpu().numpy()[idx][good] == np.array([r[2] for r in cpu_done])[good]
+                return {"n": int(good.sum()), "median_rel": float(np.median(rel)),
+                        "frac_within_1e-4": float((rel <= 1e-4).mean()), "frac_within_1e-2": float((rel <= 1e-2).mean()),
+                        "frac_same_nfev_as_cpu": float(same.mean()),
+                        "gpu_median_cost": float(np.median(lc)), "cpu_median_cost": float(np.median(ref[good]))}
+            out["final_cost_delta_vs_cpu"] = delta(last, nfev)
+            if a.dtype != "f64":
+                # the same batch once more with fp64 sampling (parity mode), outside the timed region
+                bp64 = npa.BatchPlanner(ctx=ctx, sample_dtype="f64")
+                bp64._sync()
+                x.copy_(x0)
+                bp64.optimize_dev(g3, x, d_head, d_tail, costs, last, nit, nfev, status)
+                torch.cuda.synchronize()
+                out["final_cost_delta_vs_cpu_f64_sampling"] = delta(last, nfev)
         print(json.dumps(out))
     if world > 1:
         dist_.destroy_process_group()

@@ -127,6 +127,13 @@ int neo_esdf_build_2d(neo_ctx *ctx, int scene_id, const int8_t *occupancy, int w
 int neo_esdf_upload_3d(neo_ctx *ctx, int scene_id, const void *dist, int src_dtype,
                        int src_is_device, int nx, int ny, int nz, double resolution,
                        const double origin[3], int store_dtype, int layout);
+/* 3-D counterpart of neo_esdf_build_2d (esdf.py:23-29 in three dimensions): uint8 occupancy
+ * [nz][ny][nx] (non-zero = occupied; host pointer, or device pointer when occ_is_device != 0) ->
+ * exact Euclidean distance * resolution on the device, stored as for neo_esdf_upload_3d.
+ * out_dist: optional HOST buffer [nz][ny][nx] float32 receiving the distances. */
+int neo_esdf_build_3d(neo_ctx *ctx, int scene_id, const uint8_t *occupancy, int occ_is_device, int nx,
+                      int ny, int nz, double resolution, const double origin[3], int store_dtype,
+                      int layout, float *out_dist);
 int neo_esdf_drop(neo_ctx *ctx, int scene_id);
 /* point queries, replaces get_edt_dis / get_edt_grad called from Python
  * (astar_planner.py:134, traj_planner_node.py:474).  pts[n][D_map], grad[n][D_map]. */

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -421,6 +422,94 @@ __global__ void edt_rows_kernel(const int *__restrict__ g, int W, int H, double 
     const long long dq = q - p;
     const long long sq = dq * dq + (long long)f[p] * f[p];
     out[q] = sqrt((double)sq) * res;
+  }
+}
+
+// ---- 3-D exact EDT (north-star scenes): three separable passes over integer squared distances.
+// pass X: binary occupancy -> squared distance to the nearest occupied voxel along x (two sweeps);
+// pass Y, pass Z: 1-D squared-distance transform of a sampled function (lower envelope of parabolas,
+// Felzenszwalb & Huttenlocher) along y, then z.  All arithmetic on integers, so the result equals
+// scipy.ndimage.distance_transform_edt exactly; the final sqrt * resolution is rounded to fp32.
+__global__ void edt3_x_kernel(const uint8_t *__restrict__ occ, int nx, int ny, int nz, int *__restrict__ g) {
+  const size_t line = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (z, y)
+  if (line >= (size_t)ny * nz) return;
+  const uint8_t *o = occ + line * nx;
+  int *out = g + line * nx;
+  int d = kEdtInf;
+  for (int x = 0; x < nx; ++x) {
+    d = o[x] ? 0 : (d >= kEdtInf ? kEdtInf : d + 1);
+    out[x] = d;
+  }
+  d = kEdtInf;
+  for (int x = nx - 1; x >= 0; --x) {
+    d = o[x] ? 0 : (d >= kEdtInf ? kEdtInf : d + 1);
+    const int m = out[x] < d ? out[x] : d;
+    out[x] = m >= kEdtInf ? kEdtInf : m * m;  // squared
+  }
+}
+
+// 1-D squared-distance transform of f (squared distances or kEdtInf) along a strided line of length n.
+// Scratch v (int) and z (float) are per-thread slices of global arrays.
+__device__ __forceinline__ void dt1d_sq(const int *f, int *out, int n, size_t stride, int *v, double *z) {
+  int k = -1;
+  for (int q = 0; q < n; ++q) {
+    const int fq = f[q * stride];
+    if (fq >= kEdtInf) continue;
+    const double hq = (double)fq + (double)q * q;
+    double s = 0.0;
+    while (k >= 0) {
+      const int p = v[k];
+      const double hp = (double)f[p * stride] + (double)p * p;
+      s = (hq - hp) / (2.0 * q - 2.0 * p);
+      if (s <= z[k]) --k; else break;
+    }
+    ++k;
+    v[k] = q;
+    z[k] = (k == 0) ? -1.0e300 : s;
+    z[k + 1] = 1.0e300;
+  }
+  if (k < 0) {
+    for (int q = 0; q < n; ++q) out[q * stride] = kEdtInf;
+    return;
+  }
+  // the envelope reads f while out may alias it: collect first, then write back
+  int j = 0;
+  for (int q = 0; q < n; ++q) {
+    while (z[j + 1] < (double)q) ++j;
+    const int p = v[j];
+    const long long dq = q - p;
+    const long long val = dq * dq + (long long)f[p * stride];
+    z[n + 1 + q] = (double)val;  // parked after the envelope (z has 2n+2 slots)
+  }
+  for (int q = 0; q < n; ++q) {
+    const double val = z[n + 1 + q];
+    out[q * stride] = val >= (double)kEdtInf ? kEdtInf : (int)val;
+  }
+}
+
+__global__ void edt3_y_kernel(int *__restrict__ g, int nx, int ny, int nz, int *__restrict__ vbuf,
+                              double *__restrict__ zbuf) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (z, x)
+  if (t >= (size_t)nx * nz) return;
+  const int x = (int)(t % nx), zc = (int)(t / nx);
+  int *line = g + (size_t)zc * ny * nx + x;
+  dt1d_sq(line, line, ny, (size_t)nx, vbuf + t * ny, zbuf + t * (2 * (size_t)ny + 2));
+}
+
+template <typename OutT>
+__global__ void edt3_z_kernel(int *__restrict__ g, int nx, int ny, int nz, double res, int *__restrict__ vbuf,
+                              double *__restrict__ zbuf, OutT *__restrict__ dist) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (y, x)
+  if (t >= (size_t)nx * ny) return;
+  int *line = g + t;
+  const size_t stride = (size_t)nx * ny;
+  dt1d_sq(line, line, nz, stride, vbuf + t * nz, zbuf + t * (2 * (size_t)nz + 2));
+  for (int q = 0; q < nz; ++q) {
+    const int sq = line[q * stride];
+    // no occupied voxel at all: keep a large finite distance (scipy's convention there is an
+    // artefact of its virtual background voxel; 3-D scenes always contain the ground slab)
+    const double d = sq >= kEdtInf ? 1.0e4 : sqrt((double)sq) * res;
+    dist[t + q * stride] = (OutT)d;
   }
 }
 
@@ -1090,6 +1179,50 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
   c->maps[scene_id] = e;
   c->table_dirty = true;
   return NEO_OK;
+}
+
+int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_device, int nx, int ny, int nz,
+                      double res, const double origin[3], int store_dtype, int layout, float *out_dist) {
+  if (!c || !occ || !origin || nx < 2 || ny < 2 || nz < 2 || !(res > 0.0)) return NEO_ERR_INVALID;
+  if (store_dtype != NEO_F32 && store_dtype != NEO_F16) return fail(c, NEO_ERR_INVALID, "store_dtype must be f32 or f16");
+  const size_t nvox = (size_t)nx * ny * nz;
+  float *d_dist = nullptr;
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    hipSetDevice(c->device);
+    const size_t lines = (size_t)std::max(nx * ny, std::max(nx * nz, ny * nz));
+    const size_t nmax = (size_t)std::max(nx, std::max(ny, nz));
+    void *d_occ = nullptr, *d_g = nullptr, *d_v = nullptr, *d_z = nullptr;
+    const uint8_t *src = occ;
+    if (!occ_is_device) {
+      HIPCHK(c, hipMalloc(&d_occ, nvox));
+      HIPCHK(c, hipMemcpyAsync(d_occ, occ, nvox, hipMemcpyHostToDevice, c->stream));
+      src = static_cast<const uint8_t *>(d_occ);
+    }
+    HIPCHK(c, hipMalloc(&d_g, nvox * sizeof(int)));
+    HIPCHK(c, hipMalloc(&d_v, lines * nmax * sizeof(int)));
+    HIPCHK(c, hipMalloc(&d_z, lines * (2 * nmax + 2) * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&d_dist, nvox * sizeof(float)));
+    {
+      ProfScope ps(c, NEO_KERNEL_ESDF_BUILD);
+      const int blk = 64;
+      hipLaunchKernelGGL(edt3_x_kernel, dim3((unsigned)(((size_t)ny * nz + blk - 1) / blk)), dim3(blk), 0, c->stream, src,
+                         nx, ny, nz, (int *)d_g);
+      hipLaunchKernelGGL(edt3_y_kernel, dim3((unsigned)(((size_t)nx * nz + blk - 1) / blk)), dim3(blk), 0, c->stream,
+                         (int *)d_g, nx, ny, nz, (int *)d_v, (double *)d_z);
+      hipLaunchKernelGGL((edt3_z_kernel<float>), dim3((unsigned)(((size_t)nx * ny + blk - 1) / blk)), dim3(blk), 0,
+                         c->stream, (int *)d_g, nx, ny, nz, res, (int *)d_v, (double *)d_z, d_dist);
+    }
+    if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, d_dist, nvox * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (d_occ) hipFree(d_occ);
+    hipFree(d_g);
+    hipFree(d_v);
+    hipFree(d_z);
+  }
+  const int rc = neo_esdf_upload_3d(c, scene_id, d_dist, NEO_F32, 1, nx, ny, nz, res, origin, store_dtype, layout);
+  hipFree(d_dist);
+  return rc;
 }
 
 int neo_esdf_query(neo_ctx *c, int scene_id, int n, const double *pts, double *dist, double *grad) {

@@ -23,7 +23,7 @@ EXPORTS = [
     "neo_cost_grad_batch_dev", "neo_optimize_batch", "neo_optimize_batch_dev", "neo_scene_slot",
     "neo_optimize_workspace_bytes", "neo_eval_traj_batch", "neo_profile_enable", "neo_profile_read",
     "neo_profile_reset", "neo_optimize_sample_counter", "neo_optimize_dispatch_order",
-    "neo_sampled_terms_batch", "neo_sampled_terms_batch_dev",
+    "neo_sampled_terms_batch", "neo_sampled_terms_batch_dev", "neo_esdf_build_3d",
 ]
 
 
@@ -64,6 +64,7 @@ def load():
     L.neo_esdf_upload_2d.argtypes = [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_d]
     L.neo_esdf_build_2d.argtypes = [c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_d, c_p, c_p, c_p]
     L.neo_esdf_upload_3d.argtypes = [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_i]
+    L.neo_esdf_build_3d.argtypes = [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_i, c_p]
     L.neo_esdf_drop.argtypes = [c_p, c_i]
     L.neo_esdf_query.argtypes = [c_p, c_i, c_i, c_p, c_p, c_p]
     L.neo_cost_grad_batch.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 8

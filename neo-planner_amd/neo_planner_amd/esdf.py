@@ -107,6 +107,8 @@ class ESDF3D:
         self.version = 1
         self.resolution = float(resolution)
         self.origin = np.asarray(origin_xyz, dtype=np.float64)
+        if dist is None:
+            return
         src_dev = False
         try:
             import torch
@@ -132,6 +134,40 @@ class ESDF3D:
                                          self.resolution, ctypes.cast(org, ctypes.c_void_p),
                                          {"f32": _lib.NEO_F32, "f16": _lib.NEO_F16}[store],
                                          {"linear": _lib.NEO_LAYOUT_LINEAR, "brick4": _lib.NEO_LAYOUT_BRICK4}[layout]))
+
+    @classmethod
+    def from_occupancy(cls, occ, resolution, origin_xyz, store="f32", layout="linear", ctx=None, want_dist=False):
+        """occupancy [z, y, x] (non-zero = occupied; NumPy uint8 or a torch CUDA uint8 tensor) -> exact EDT
+        on the GPU (3-D counterpart of occupancy_map_cb).  `want_dist` copies the float32 field back
+        into `self.dist`."""
+        self = cls(None, resolution, origin_xyz, ctx=ctx)
+        on_dev = False
+        try:
+            import torch
+            if isinstance(occ, torch.Tensor):
+                occ = occ.contiguous()
+                assert occ.dtype == torch.uint8
+                on_dev = occ.is_cuda
+                self.shape = tuple(occ.shape)
+                pointer = ctypes.c_void_p(occ.data_ptr())
+                if not on_dev:
+                    occ = occ.numpy()
+        except ImportError:
+            pass
+        if not on_dev:
+            occ = np.ascontiguousarray(occ, dtype=np.uint8)
+            self.shape = occ.shape
+            pointer = _lib.ptr(occ)
+        nz, ny, nx = self.shape
+        self.dist = np.empty(self.shape, dtype=np.float32) if want_dist else None
+        org = (ctypes.c_double * 3)(*self.origin)
+        c = self.ctx
+        c.check(c.lib.neo_esdf_build_3d(c.h, self.scene_id, pointer, int(on_dev), nx, ny, nz, self.resolution,
+                                        ctypes.cast(org, ctypes.c_void_p),
+                                        {"f32": _lib.NEO_F32, "f16": _lib.NEO_F16}[store],
+                                        {"linear": _lib.NEO_LAYOUT_LINEAR, "brick4": _lib.NEO_LAYOUT_BRICK4}[layout],
+                                        _lib.ptr(self.dist)))
+        return self
 
     def query(self, pts):
         p = np.ascontiguousarray(np.asarray(pts, dtype=np.float64).reshape(-1, 3))

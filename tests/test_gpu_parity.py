@@ -69,6 +69,31 @@ def test_esdf_build_matches_scipy_on_odd_shapes(shape, seed):
     assert np.array_equal(m.esdf_grad_y, o.esdf_grad_y)
 
 
+@pytest.mark.parametrize("shape,seed", [((48, 48, 48), 0), ((20, 33, 47), 1), ((5, 64, 9), 2)])
+def test_esdf_build_3d_is_the_exact_edt(shape, seed):
+    """device-side 3-D EDT against scipy.ndimage.distance_transform_edt: equal after the same fp32 rounding"""
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    occ = (rng.random(shape) < 0.01).astype(np.uint8)
+    occ[0] = 1                                            # ground slab, as every synthetic scene has
+    want = (ndimage.distance_transform_edt(1 - occ) * 0.1).astype(np.float32)
+    for layout in ("linear", "brick4"):
+        g3 = npa.ESDF3D.from_occupancy(occ, 0.1, (0.0, -1.0, 0.0), layout=layout, want_dist=True)
+        assert np.array_equal(g3.dist, want)
+        pts = rng.uniform([0, -1, 0], [shape[2] * 0.1, -1 + shape[1] * 0.1, shape[0] * 0.1], (500, 3))
+        o3 = onp.Grid3DESDF(want, 0.1, (0.0, -1.0, 0.0))
+        dis, _ = g3.query(pts)
+        assert np.max(np.abs(dis - np.array([o3.lookup(p)[0] for p in pts]))) < 1e-12
+
+
+def test_esdf_build_3d_full_scene_matches_scipy():
+    from scipy import ndimage
+    occ = synth.occupancy_3d(1, n=160, res=30.0 / 160)
+    want = (ndimage.distance_transform_edt(1 - occ) * (30.0 / 160)).astype(np.float32)
+    g3 = npa.ESDF3D.from_occupancy(occ, 30.0 / 160, synth.DOMAIN_ORIGIN, want_dist=True)
+    assert np.array_equal(g3.dist, want)
+
+
 def test_trilinear_lookup_matches_oracle_and_ties_back_to_2d():
     d = load(golden("g2_esdf_0.npz")[0])
     res = float(d["res"])
@@ -346,8 +371,7 @@ def test_optimize_batch_matches_cpu_optimizer(M, B):
 @pytest.fixture(scope="module")
 def cfg2():
     """BASELINE.json configs[1]: 4096 trajectories, 20 waypoints, one 300^3 fp32 field"""
-    dist = synth.esdf_3d(0)
-    g3 = npa.ESDF3D(dist, synth.RES, synth.DOMAIN_ORIGIN, store="f32")
+    g3 = npa.ESDF3D.from_occupancy(synth.occupancy_3d(0), synth.RES, synth.DOMAIN_ORIGIN, store="f32")
     head, tail, wp, ts = synth.replan_requests(0, 4096, 20, D=3)
     return g3, head, tail, wp, ts
 
