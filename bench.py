@@ -40,6 +40,23 @@ import numpy as np
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak
 
 
+def pmc_traffic(kernel, default_workload):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_pmc.json: FETCH_SIZE and WRITE_SIZE, separate passes, KB per dispatch, raw).  PMC
+    counters cannot be collected from inside the process, so this is the profile's figure, or None
+    when the workload differs from the profiled one."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc.json")))
+    if not files or not default_workload:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["kernels"][kernel]
+        return (k["FETCH_SIZE"]["mean_per_dispatch"] + k["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0, \
+            os.path.relpath(files[-1], REPO)
+    except Exception:
+        return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,6 +70,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-order", action="store_true", help="dispatch trajectories in index order")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="BASELINE.json configs[1..4]; cfg2 is the headline (default).  cfg3: 65536 trajectories, M=3, "
+                         "warm-started by the initializer net; cfg4: --scenes scenes x 4096 per GPU; cfg5: 40 waypoints, "
+                         "600^3 fp16 field")
+    ap.add_argument("--scenes", type=int, default=8, help="cfg4: scenes per GPU")
     return ap.parse_args()
 
 
@@ -105,13 +127,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         a.gpus = world
+    store = "f32"
+    n_scenes = 1
+    if a.config == "cfg3":
+        a.batch, a.waypoints, a.no_cpu = 65536, 2, True
+    elif a.config == "cfg4":
+        n_scenes, a.no_cpu = a.scenes, True
+        a.batch = 4096 * n_scenes
+    elif a.config == "cfg5":
+        a.waypoints, a.grid, store, a.no_cpu = 40, 600, "f16", True
     M, D, B = a.waypoints + 1, 3, a.batch
     n = D * (M - 1) + M
     from neo_planner_amd import synth
     res = 30.0 / a.grid
     t_setup = time.time()
     occ = synth.occupancy_3d(rank, n=a.grid, res=res)                  # scene = rank (weak scaling)
-    head, tail, wp, ts = synth.replan_requests(rank, B, M - 1, D=D)
+    if n_scenes == 1:
+        lr = (4.0, 6.0) if a.config == "cfg3" else (10.0, 28.0)       # cfg3: 5 m local targets, like the reference's M = 3
+        head, tail, wp, ts = synth.replan_requests(rank, B, M - 1, D=D, length_range=lr)
+    else:
+        parts = [synth.replan_requests(rank * n_scenes + s, 4096, M - 1, D=D) for s in range(n_scenes)]
+        head, tail, wp, ts = (np.concatenate([p[k] for p in parts]) for k in range(4))
 
     cpu, cpu_done, dist_host = None, [], None
     if world == 1 and rank == 0 and not a.no_cpu:
@@ -138,9 +174,37 @@ def main():
     ctx = npa.Context(local_rank, stream=tstream.cuda_stream)
     bp = npa.BatchPlanner(ctx=ctx, sample_dtype=a.dtype)
     bp._sync()
-    g3 = npa.ESDF3D.from_occupancy(torch.from_numpy(occ).to(dev), res, synth.DOMAIN_ORIGIN, store="f32", layout=a.layout,
+    g3 = npa.ESDF3D.from_occupancy(torch.from_numpy(occ).to(dev), res, synth.DOMAIN_ORIGIN, store=store, layout=a.layout,
                                    ctx=ctx, want_dist=dist_host is not None)
     esdf_equal = None if dist_host is None else bool(np.array_equal(g3.dist, dist_host))
+    slots = None
+    scenes = [g3]
+    if n_scenes > 1:
+        # cfg4: every scene's field resident in this GPU's HBM, trajectories carry their scene's table slot
+        for s_ in range(1, n_scenes):
+            o_ = synth.occupancy_3d(rank * n_scenes + s_, n=a.grid, res=res)
+            scenes.append(npa.ESDF3D.from_occupancy(torch.from_numpy(o_).to(dev), res, synth.DOMAIN_ORIGIN, store=store,
+                                                    layout=a.layout, ctx=ctx))
+        sl = [ctx.lib.neo_scene_slot(ctx.h, sc.scene_id) for sc in scenes]
+        slots = torch.tensor(np.repeat(sl, 4096), dtype=torch.int32, device=dev)
+    init = None
+    if a.config == "cfg3":
+        # initializer warm start (random weights: the reference's trained ones are not in its tree).  One
+        # synthetic depth image per scene through the backbone once; the dense head runs per trajectory.
+        from neo_planner_amd import initializer as ini
+        torch.manual_seed(1234 + rank)
+        init = ini.BatchInitializer(device=dev)
+        rng_i = np.random.default_rng(77 + rank)
+        depth = (255 * rng_i.random((ini.IMG_HEIGHT, ini.IMG_WIDTH))).astype(np.uint8)
+        feat = init.scene_feature(depth)
+        goal_dir = tail[:, 0] - head[:, 0]
+        motion = np.concatenate([head[:, 1], np.tile(np.eye(3).reshape(-1), (B, 1)), np.zeros((B, 3)), head[:, 1],
+                                 goal_dir, tail[:, 1]], axis=1)
+        d_motion = torch.from_numpy(motion.astype(np.float32)).to(dev)
+        d_R = torch.eye(3, dtype=torch.float64, device=dev).expand(B, 3, 3).contiguous()
+        d_p0 = torch.from_numpy(head[:, 0]).to(dev)
+        line = torch.from_numpy(np.stack([head[:, 0] + goal_dir * f for f in (1 / 3, 2 / 3)], axis=2)).to(dev)   # [B,3,2]
+        T_lo, T_hi = bp.cfg.T_min, bp.cfg.T_max
     x0 = torch.from_numpy(bp.pack_x(wp, ts)).to(dev)
     d_head = torch.from_numpy(head).to(dev)
     d_tail = torch.from_numpy(tail).to(dev)
@@ -160,9 +224,25 @@ def main():
     gathered = torch.empty(world * B, n + 5, dtype=torch.float32, device=dev) if world > 1 else None
     w = torch.tensor(bp.cfg.weights, dtype=torch.float64, device=dev)
 
+    def warm_start():
+        """network output -> x0: body-frame waypoints (a small correction on the straight line, the net
+        being untrained) and durations clamped into (T_min, T_max), then tau = map_T2tau(ts)"""
+        out = init.net.head(feat, d_motion).double()
+        local = out[:, :6].reshape(B, 2, 3)
+        world = torch.einsum("bij,bwj->bwi", d_R, local) + d_p0[:, None, :]
+        wp_ = line + 0.05 * (world.transpose(1, 2) - d_p0[:, :, None])
+        eps = 1e-3 * (T_hi - T_lo)
+        ts_ = (2.5 + out[:, 6:]).clamp(T_lo + eps, T_hi - eps)
+        tau_ = -torch.log((T_hi - T_lo) / (ts_ - T_lo) - 1.0)
+        x0[:, :D * (M - 1)] = wp_.reshape(B, -1)
+        x0[:, D * (M - 1):] = tau_
+
     def step():
+        if init is not None:
+            with torch.no_grad():
+                warm_start()
         x.copy_(x0)
-        bp.optimize_dev(g3, x, d_head, d_tail, costs, last, nit, nfev, status)
+        bp.optimize_dev(g3, x, d_head, d_tail, costs, last, nit, nfev, status, slots=slots)
         if world > 1:
             # results to every rank: final x, total cost, 4 cost terms (SURVEY.md 8.e1)
             sharding.gather_results(sharding.pack_results(x, costs, w), world, out=gathered)
@@ -198,7 +278,7 @@ def main():
     # ---- the ESDF-lookup kernel on its own (outside the timed region): add_sampled_cost +
     # add_sampled_grad_CT for the whole batch at the initial guess, coefficients resident in HBM
     esdf = None
-    if rank == 0:
+    if rank == 0 and n_scenes == 1:
         pp = lambda t: ctypes.c_void_p(t.data_ptr())
         coeffs = torch.zeros(B, 6 * M, D, dtype=torch.float64, device=dev)
         cost1 = torch.zeros(B, dtype=torch.float64, device=dev)
@@ -231,7 +311,8 @@ def main():
         esdf = {"kernel": "sample_kernel", "bound": "hbm", "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "kernel_us": us, "launches": int(l2.value),
                 "samples_per_launch": n_samples, "algorithmic_bytes_per_launch": by,
-                "lookups_per_s": n_samples / (us * 1e-6)}
+                "lookups_per_s": n_samples / (us * 1e-6),
+                "traffic": pmc_traffic("sample_kernel", default_workload)[0]}
     nfev_h = nfev.cpu().numpy().astype(np.int64)
     nsamp_h = nsamp.cpu().numpy()
     status_h = status.cpu().numpy()
@@ -239,6 +320,9 @@ def main():
     bytes_launch = float(nsamp_h.sum()) * 8 * 4 + float(nfev_h.sum()) * (2 * n * 4 + 20)
     achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
     value = world * B * a.steps / elapsed
+    default_workload = (a.config == "cfg2" and a.batch == 4096 and a.waypoints == 20 and a.grid == 300
+                        and a.dtype == "f32" and a.layout == "linear")
+    traffic, traffic_src = pmc_traffic("optimize_kernel", default_workload)
 
     if rank == 0:
         out = {
@@ -246,14 +330,15 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"cfg2: B={B} trajectories x {M - 1} waypoints (M={M} pieces, D=3, n={n}) per GPU, "
-                                   f"one {a.grid}^3 fp32 ESDF per GPU (trilinear, layout {a.layout}), each optimised "
-                                   "to L-BFGS-B termination (maxcor 10, maxls 20, tol 1e-4)",
+            "config": {"workload": f"{a.config}: B={B} trajectories x {M - 1} waypoints (M={M} pieces, D=3, n={n}) per GPU, "
+                                   f"{n_scenes} x {a.grid}^3 {store} ESDF per GPU (trilinear, layout {a.layout}), each optimised "
+                                   "to L-BFGS-B termination (maxcor 10, maxls 20, tol 1e-4)"
+                                   + ("; x0 from the initializer net (random weights) each step" if init is not None else ""),
                        "batch_per_gpu": B, "pieces": M, "dims": D, "esdf_voxels": a.grid ** 3,
                        "sampling_arithmetic": a.dtype, "solve_and_optimiser_arithmetic": "f64",
                        "parallelism": f"scene-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "optimize_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kernel_ms, "launches": int(launches.value),
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "evals_per_launch": int(nfev_h.sum()), "samples_per_launch": int(nsamp_h.sum())},
