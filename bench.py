@@ -138,6 +138,8 @@ def main():
         a.waypoints, a.grid, store, a.no_cpu = 40, 600, "f16", True
     M, D, B = a.waypoints + 1, 3, a.batch
     n = D * (M - 1) + M
+    default_workload = (a.config == "cfg2" and a.batch == 4096 and a.waypoints == 20 and a.grid == 300
+                        and a.dtype == "f32" and a.layout == "linear")
     from neo_planner_amd import synth
     res = 30.0 / a.grid
     t_setup = time.time()
@@ -320,8 +322,6 @@ def main():
     bytes_launch = float(nsamp_h.sum()) * 8 * 4 + float(nfev_h.sum()) * (2 * n * 4 + 20)
     achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
     value = world * B * a.steps / elapsed
-    default_workload = (a.config == "cfg2" and a.batch == 4096 and a.waypoints == 20 and a.grid == 300
-                        and a.dtype == "f32" and a.layout == "linear")
     traffic, traffic_src = pmc_traffic("optimize_kernel", default_workload)
 
     if rank == 0:

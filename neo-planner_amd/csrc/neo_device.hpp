@@ -363,32 +363,50 @@ struct Traj {
 // factorisation, no second set of divisions.
 __device__ __forceinline__ void thomas_factor(int M, const double (&Lo)[2][2], const double (&Di)[2][2],
                                               const double (&Up)[2][2], double (&N)[2][2], double (&E)[2][2]) {
+  // The recurrence E_p = (Di_p - Lo_p E_{p-1})^-1 Up_p is carried as a fraction E = Eh / dl so that the
+  // loop-carried chain holds no division:  Dh = dl_{p-1} Di_p - Lo_p Eh_{p-1} (= dl_{p-1} D_p),
+  // Eh_p = s dl_{p-1} adj(Dh) Up_p,  dl_p = s det(Dh),  s = a power of two that brings dl_p to
+  // [0.5, 1) so nothing over/underflows.  Each lane keeps its own Dh and dl_{p-1} and forms
+  // N_p = dl_{p-1} adj(Dh)/det(Dh) and E_p = Eh_p/dl_p after the loop, all lanes in parallel.
   const int lane = lane_id();
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      E[a][b] = 0.0;
-      N[a][b] = 0.0;
-    }
+  double Eh[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, dl = 1.0;  // lane 0: E_0 = 0
+  double Dh[2][2] = {{1.0, 0.0}, {0.0, 1.0}}, dprev = 1.0;
   for (int p = 1; p < M; ++p) {
-    const double e00 = rdlane(E[0][0], p - 1), e01 = rdlane(E[0][1], p - 1);
-    const double e10 = rdlane(E[1][0], p - 1), e11 = rdlane(E[1][1], p - 1);
-    const double d00 = Di[0][0] - (Lo[0][0] * e00 + Lo[0][1] * e10);
-    const double d01 = Di[0][1] - (Lo[0][0] * e01 + Lo[0][1] * e11);
-    const double d10 = Di[1][0] - (Lo[1][0] * e00 + Lo[1][1] * e10);
-    const double d11 = Di[1][1] - (Lo[1][0] * e01 + Lo[1][1] * e11);
-    const double idet = 1.0 / (d00 * d11 - d01 * d10);
+    const double e00 = rdlane(Eh[0][0], p - 1), e01 = rdlane(Eh[0][1], p - 1);
+    const double e10 = rdlane(Eh[1][0], p - 1), e11 = rdlane(Eh[1][1], p - 1);
+    const double dp = rdlane(dl, p - 1);
+    const double h00 = dp * Di[0][0] - (Lo[0][0] * e00 + Lo[0][1] * e10);
+    const double h01 = dp * Di[0][1] - (Lo[0][0] * e01 + Lo[0][1] * e11);
+    const double h10 = dp * Di[1][0] - (Lo[1][0] * e00 + Lo[1][1] * e10);
+    const double h11 = dp * Di[1][1] - (Lo[1][0] * e01 + Lo[1][1] * e11);
+    const double det = h00 * h11 - h01 * h10;
+    const int ex = -__builtin_amdgcn_frexp_exp(det);
+    // adj(Dh) Up, scaled by dl_{p-1} and the power of two
+    const double g00 = dp * (h11 * Up[0][0] - h01 * Up[1][0]), g01 = dp * (h11 * Up[0][1] - h01 * Up[1][1]);
+    const double g10 = dp * (h00 * Up[1][0] - h10 * Up[0][0]), g11 = dp * (h00 * Up[1][1] - h10 * Up[0][1]);
     if (lane == p) {
-      N[0][0] = d11 * idet;
-      N[0][1] = -d01 * idet;
-      N[1][0] = -d10 * idet;
-      N[1][1] = d00 * idet;
-      E[0][0] = N[0][0] * Up[0][0] + N[0][1] * Up[1][0];
-      E[0][1] = N[0][0] * Up[0][1] + N[0][1] * Up[1][1];
-      E[1][0] = N[1][0] * Up[0][0] + N[1][1] * Up[1][0];
-      E[1][1] = N[1][0] * Up[0][1] + N[1][1] * Up[1][1];
+      Eh[0][0] = ldexp(g00, ex);
+      Eh[0][1] = ldexp(g01, ex);
+      Eh[1][0] = ldexp(g10, ex);
+      Eh[1][1] = ldexp(g11, ex);
+      dl = ldexp(det, ex);
+      Dh[0][0] = h00; Dh[0][1] = h01; Dh[1][0] = h10; Dh[1][1] = h11;
+      dprev = dp;
     }
+  }
+  {
+    const double det = Dh[0][0] * Dh[1][1] - Dh[0][1] * Dh[1][0];
+    const double sc = dprev / det;
+    const bool in = lane >= 1 && lane < M;
+    N[0][0] = in ? Dh[1][1] * sc : 0.0;
+    N[0][1] = in ? -Dh[0][1] * sc : 0.0;
+    N[1][0] = in ? -Dh[1][0] * sc : 0.0;
+    N[1][1] = in ? Dh[0][0] * sc : 0.0;
+    const double idl = 1.0 / dl;
+    E[0][0] = in ? Eh[0][0] * idl : 0.0;
+    E[0][1] = in ? Eh[0][1] * idl : 0.0;
+    E[1][0] = in ? Eh[1][0] * idl : 0.0;
+    E[1][1] = in ? Eh[1][1] * idl : 0.0;
   }
 }
 
@@ -526,7 +544,7 @@ __device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, d
     double Lo[2][2], Di[2][2], Up[2][2], E[2][2], R[2][D], y0[2][D], yM[2][D], y[2][D];
     const double a1 = from_prev(t.i1, 1.0), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;
     joint_blocks(t, a1, a2, a3, Lo, Di, Up);
-    thomas_factor((prm.dbg & 2) ? 1 : t.M, Lo, Di, Up, t.N, E);
+    thomas_factor((prm.dbg & (2 | 8)) ? 1 : t.M, Lo, Di, Up, t.N, E);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       // displacement of piece p-1 and of piece p
@@ -539,7 +557,7 @@ __device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, d
       yM[0][d] = t.tail[1 * D + d];
       yM[1][d] = t.tail[2 * D + d];
     }
-    thomas_solve<D>((prm.dbg & 2) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);
+    thomas_solve<D>((prm.dbg & (2 | 16)) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       t.V0[d] = lane == 0 ? t.head[1 * D + d] : y[0][d];
@@ -635,53 +653,66 @@ __device__ __forceinline__ void minco_sample(int M, int L, int ns_piece, const R
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) rw[u] = lk.load(ad[u]);
+    // violations are rare: first only the two penalties' arguments for the U samples, one test for the
+    // whole group, and the per-sample accumulation code only if some lane of the wave needs it
+    Real vv[U], vd[U];
+    bool any_violation = false;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (!on[u]) continue;
-      const int j = r + (it0 + u) * L;
-      const Real s = sv[u];
-      const Real omg = (j == 0 || j == ns - 1) ? Real(0.5) : Real(1);
-      const Real s2 = s * s, s3 = s2 * s, s4 = s2 * s2, s5 = s4 * s;
-      // dynamic feasibility
       Real v2 = Real(0);
 #pragma unroll
       for (int d = 0; d < D; ++d) v2 += vel[u][d] * vel[u][d];
-      const Real vv = v2 - vmax2;
-      if (vv > Real(0)) {
-        aF += omg * dt * vv * vv * vv;
-        Real av = Real(0);
+      vv[u] = v2 - vmax2;
+      Real gdrop[D];
+      vd[u] = safe - lk.template finish<D>(ad[u], rw[u], gdrop);
+      if (on[u] && (vv[u] > Real(0) || vd[u] > Real(0))) any_violation = true;
+    }
+    if (any_violation) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const Real acc = Real(2) * c[2][d] + s * (Real(6) * c[3][d] + s * (Real(12) * c[4][d] + s * (Real(20) * c[5][d])));
-          av += acc * vel[u][d];
+      for (int u = 0; u < U; ++u) {
+        if (!on[u]) continue;
+        const int j = r + (it0 + u) * L;
+        const Real s = sv[u];
+        const Real omg = (j == 0 || j == ns - 1) ? Real(0.5) : Real(1);
+        const Real s2 = s * s, s3 = s2 * s, s4 = s2 * s2, s5 = s4 * s;
+        // dynamic feasibility
+        if (vv[u] > Real(0)) {
+          const Real vq = vv[u];
+          aF += omg * dt * vq * vq * vq;
+          Real av = Real(0);
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            const Real acc = Real(2) * c[2][d] + s * (Real(6) * c[3][d] + s * (Real(12) * c[4][d] + s * (Real(20) * c[5][d])));
+            av += acc * vel[u][d];
+          }
+          const Real dK = Real(3) * dt * omg * vq * vq;
+          const Real b1[6] = {Real(0), Real(1), Real(2) * s, Real(3) * s2, Real(4) * s3, Real(5) * s4};
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            const Real uu = w2 * dK * Real(2) * vel[u][d];
+#pragma unroll
+            for (int k = 1; k < 6; ++k) aC[k][d] += b1[k] * uu;
+          }
+          aT += w2 * (omg * vq * vq * vq * inv_ns + dK * Real(2) * av * (Real)j * inv_ns);
         }
-        const Real dK = Real(3) * dt * omg * vv * vv;
-        const Real b1[6] = {Real(0), Real(1), Real(2) * s, Real(3) * s2, Real(4) * s3, Real(5) * s4};
+        // collision
+        if (vd[u] > Real(0)) {
+          Real g[D];
+          (void)lk.template finish<D>(ad[u], rw[u], g);
+          const Real vq = vd[u];
+          aK += omg * dt * vq * vq * vq;
+          const Real dK = Real(3) * dt * omg * vq * vq;
+          const Real b0[6] = {Real(1), s, s2, s3, s4, s5};
+          Real gv = Real(0);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const Real uu = w2 * dK * Real(2) * vel[u][d];
+          for (int d = 0; d < D; ++d) {
+            gv += g[d] * vel[u][d];
+            const Real uu = -(w3 * dK * g[d]);
 #pragma unroll
-          for (int k = 1; k < 6; ++k) aC[k][d] += b1[k] * uu;
+            for (int k = 0; k < 6; ++k) aC[k][d] += b0[k] * uu;
+          }
+          aT += w3 * (omg * vq * vq * vq * inv_ns + dK * (-gv) * (Real)j * inv_ns);
         }
-        aT += w2 * (omg * vv * vv * vv * inv_ns + dK * Real(2) * av * (Real)j * inv_ns);
-      }
-      // collision
-      Real g[D];
-      const Real dist = lk.template finish<D>(ad[u], rw[u], g);
-      const Real vd = safe - dist;
-      if (vd > Real(0)) {
-        aK += omg * dt * vd * vd * vd;
-        const Real dK = Real(3) * dt * omg * vd * vd;
-        const Real b0[6] = {Real(1), s, s2, s3, s4, s5};
-        Real gv = Real(0);
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          gv += g[d] * vel[u][d];
-          const Real uu = -(w3 * dK * g[d]);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) aC[k][d] += b0[k] * uu;
-        }
-        aT += w3 * (omg * vd * vd * vd * inv_ns + dK * (-gv) * (Real)j * inv_ns);
       }
     }
   }
@@ -777,7 +808,7 @@ __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams 
       R[1][d] = S[2][d];
       z0[0][d] = z0[1][d] = 0.0;
     }
-    thomas_solve<D>((prm.dbg & 2) ? 1 : M, LoT, NT, ET, R, z0, z0, y);
+    thomas_solve<D>((prm.dbg & (2 | 16)) ? 1 : M, LoT, NT, ET, R, z0, z0, y);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       lam[0][d] = (lane >= 1 && lane < M) ? y[0][d] : 0.0;

@@ -64,7 +64,7 @@ for Bs in (1, 64, 1024, 4096):
           f"{dt/nf.sum()*1e9:.1f} ns per eval amortised")
 
 print("--- single-wave latency split (B=1, f32)")
-for dbg, name in ((0, "full"), (1, "no sample loop"), (2, "no joint sweeps"), (3, "neither")):
+for dbg, name in ((0, "full"), (1, "no sample loop"), (2, "no joint sweeps"), (8, "no factor sweep"), (16, "no scans"), (3, "neither")):
     bp._sync(); ctx.set_params(reserved=dbg)
     def run():
         ctx.check(ctx.lib.neo_cost_grad_batch_dev(ctx.h, g3.scene_id, 1, M, D, p(x0), p(h), p(tl), p(cost), p(c4), p(g), None, p(stt)))
