@@ -75,6 +75,9 @@ def parse():
                          "warm-started by the initializer net; cfg4: --scenes scenes x 4096 per GPU; cfg5: 40 waypoints, "
                          "600^3 fp16 field")
     ap.add_argument("--scenes", type=int, default=8, help="cfg4: scenes per GPU")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to "
+                    "exercise the multi-rank code path on a single-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: all ranks use cuda:0")
     return ap.parse_args()
 
 
@@ -163,11 +166,16 @@ def main():
     import torch
     import neo_planner_amd as npa
     from neo_planner_amd import _lib
+    if a.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist_
-        dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.dist_backend == "nccl":
+            dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist_.init_process_group(a.dist_backend, rank=rank, world_size=world)
     # one explicit (non-default) stream for everything: torch copies, our kernels, RCCL.  The default
     # stream has handle 0, which the C ABI reads as "create your own stream".
     tstream = torch.cuda.Stream(device=dev)
