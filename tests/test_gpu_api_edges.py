@@ -1,0 +1,170 @@
+"""Edge cases of the C ABI and the host classes on the GPU: empty and single-element batches, the
+smallest and largest shapes, error codes, map updates, foreign map objects, fp16 fields."""
+import ctypes
+import types
+
+import numpy as np
+import pytest
+
+from helpers import golden, load, rel_err
+
+pytestmark = pytest.mark.gpu
+
+import neo_planner_amd as npa
+from neo_planner_amd import _lib, synth
+from oracle import minco_np as onp
+
+
+@pytest.fixture(scope="module")
+def scene():
+    occ = synth.occupancy_2d(6)
+    m = npa.ESDF()
+    m.occupancy_map_cb(synth.OccupancyGridMsg(occ))
+    return occ, m, onp.GridESDF(occ, synth.RES, 300, 300, (0.0, -15.0))
+
+
+def test_empty_batch_is_a_no_op(scene):
+    _, m, _ = scene
+    bp = npa.BatchPlanner()
+    out = bp.cost_grad(m, np.zeros((0, 7)), np.zeros((0, 3, 2)), np.zeros((0, 3, 2)))
+    assert out["cost"].shape == (0,)
+    res = bp.optimize(m, np.zeros((0, 7)), np.zeros((0, 3, 2)), np.zeros((0, 3, 2)))
+    assert res["x"].shape == (0, 7)
+
+
+def test_error_codes(scene):
+    _, m, _ = scene
+    c = m.ctx
+    x = np.zeros((1, 7)); h = np.zeros((1, 3, 2)); t = np.zeros((1, 3, 2))
+    cost = np.zeros(1); c4 = np.zeros((1, 4)); g = np.zeros((1, 7))
+    p = _lib.ptr
+    # unknown scene
+    assert c.lib.neo_cost_grad_batch(c.h, 9999, 1, 3, 2, p(x), p(h), p(t), p(cost), p(c4), p(g), None, None) == 3
+    assert b"no ESDF" in c.lib.neo_last_error(c.h)
+    # shapes out of range: M > 64, D = 4
+    assert c.lib.neo_cost_grad_batch(c.h, m.scene_id, 1, 65, 2, p(x), p(h), p(t), p(cost), p(c4), p(g), None, None) == 1
+    assert c.lib.neo_cost_grad_batch(c.h, m.scene_id, 1, 3, 4, p(x), p(h), p(t), p(cost), p(c4), p(g), None, None) == 1
+    # null buffers
+    assert c.lib.neo_cost_grad_batch(c.h, m.scene_id, 1, 3, 2, None, p(h), p(t), p(cost), p(c4), p(g), None, None) == 1
+    # a 3-D field needs D = 3
+    vol = np.ones((4, 4, 4), np.float32)
+    g3 = npa.ESDF3D(vol, 0.5, (0, 0, 0))
+    assert c.lib.neo_cost_grad_batch(c.h, g3.scene_id, 1, 3, 2, p(x), p(h), p(t), p(cost), p(c4), p(g), None, None) == 1
+    with pytest.raises(_lib.NeoError):
+        npa.BatchPlanner().cost_grad(g3, x, h, t)
+    # bad parameters are rejected and leave the old ones in place
+    bad = _lib.NeoParams()
+    c.lib.neo_params_default(ctypes.byref(bad))
+    bad.T_max = bad.T_min
+    assert c.lib.neo_params_set(c.h, ctypes.byref(bad)) == 1
+
+
+def test_single_trajectory_and_largest_shape(scene):
+    occ, m, o2 = scene
+    rng = np.random.default_rng(4)
+    for M, D in ((2, 2), (64, 3), (64, 2), (43, 3)):           # n = 5, 253 (4 slots), 190, 169 (3 -> 4 slots)
+        head = np.zeros((1, 3, D)); tail = np.zeros((1, 3, D))
+        head[0, 0, :2] = [1.0, 0.5]; tail[0, 0, :2] = [27.0, -1.0]
+        if D == 3:
+            head[0, 0, 2] = tail[0, 0, 2] = 2.0
+        k = np.arange(1, M)[None, :] / M
+        wp = (head[0, 0][:, None] + (tail[0, 0] - head[0, 0])[:, None] * k + rng.normal(0, 0.2, (D, M - 1)))[None]
+        ts = rng.uniform(0.6, 1.5, (1, M))
+        bp = npa.BatchPlanner()
+        x = bp.pack_x(wp, ts)
+        out = bp.cost_grad(m, x, head, tail, want_coeffs=True)
+        pl = onp.OraclePlanner(onp.PlannerParams())
+        pl.read_planning_conditions(o2, head[0], tail[0], wp[0], ts[0])
+        c = pl.get_cost(x[0]); g = pl.get_grad(x[0])
+        assert abs(out["cost"][0] - c) <= 1e-10 * abs(c)
+        assert rel_err(out["grad"][0], g) < 1e-9
+        assert rel_err(out["coeffs"][0], pl.coeffs) < 1e-10
+        res = bp.optimize(m, x, head, tail)
+        assert res["status"][0] in (0, 1, 2, 4, 5)        # 4/5: the reference would leave through OverflowError
+        if res["status"][0] <= 2:
+            assert res["final_cost"][0] <= out["cost"][0] * (1 + 1e-12)
+
+
+def test_map_update_is_picked_up_and_foreign_maps_are_snapshotted(scene):
+    occ, _, _ = scene
+    m = npa.ESDF()
+    m.occupancy_map_cb(synth.OccupancyGridMsg(np.zeros_like(occ)))
+    v0 = m.version
+    head = np.array([[1.0, 0.0], [0.0, 0.0]]); tail = np.array([[6.0, 0.0], [0.5, 0.0]])
+    pl = npa.MinJerkPlanner(npa.PlannerConfig())
+    pl.plan(m, head, tail)
+    free_cost = pl.final_cost
+    blocked = np.zeros_like(occ)
+    blocked[140:160, 30:40] = 100                                   # a wall across the straight path (y in [-1,1], x in [3,4])
+    m.occupancy_map_cb(synth.OccupancyGridMsg(blocked))
+    assert m.version == v0 + 1
+    pl2 = npa.MinJerkPlanner(npa.PlannerConfig())
+    try:
+        pl2.plan(m, head, tail)
+        assert pl2.final_cost > free_cost                            # has to go around
+    except Exception as ex:                                          # or the reference's "No solution" path
+        assert "No solution" in str(ex)
+    # a map object that only follows the reference's attribute protocol (e.g. the original ESDF class)
+    o = onp.GridESDF(blocked, synth.RES, 300, 300, (0.0, -15.0))
+    foreign = types.SimpleNamespace(esdf_map=o.esdf_map, esdf_grad_x=o.esdf_grad_x, esdf_grad_y=o.esdf_grad_y,
+                                    map_resolution=synth.RES, map_origin=types.SimpleNamespace(x=0.0, y=-15.0),
+                                    map_width=300, map_height=300)
+    pl3 = npa.MinJerkPlanner(npa.PlannerConfig())
+    pl3.read_planning_conditions(foreign, head, tail, *pl3.generate_init_variables(head, tail))
+    pl3.tau = pl3.map_T2tau(pl3.ts)
+    x = pl3._pack_x()
+    ref = onp.OraclePlanner(onp.PlannerParams())
+    ref.read_planning_conditions(o, head, tail, pl3.int_wpts, pl3.ts)
+    assert abs(pl3.get_cost(x) - ref.get_cost(x)) <= 1e-10 * abs(ref.get_cost(x))
+    assert rel_err(pl3.get_grad(x), ref.get_grad(x)) < 1e-9
+    assert rel_err(pl3.costs, ref.costs) < 1e-10 or np.allclose(pl3.costs, ref.costs, atol=1e-12)
+
+
+def test_standalone_cost_terms_like_all_planner_demo(scene):
+    """all_planner_demo.py:46-51: get_coeffs, reset_cost, add_sampled_cost on a given (int_wpts, ts)"""
+    occ, m, o2 = scene
+    head = np.array([[1.0, 0.2], [0.3, 0.0]]); tail = np.array([[6.0, -0.4], [0.6, 0.1]])
+    pl = npa.MinJerkPlanner(npa.PlannerConfig())
+    wp, ts = pl.generate_init_variables(head, tail)
+    pl.read_planning_conditions(m, head, tail, wp, ts)
+    pl.get_coeffs(wp, ts); pl.reset_cost(); pl.add_sampled_cost(); pl.add_energy_cost(); pl.add_time_cost()
+    ref = onp.OraclePlanner(onp.PlannerParams())
+    ref.read_planning_conditions(o2, head, tail, wp, ts)
+    ref.get_coeffs(wp, ts); ref.reset_cost(); ref.add_sampled_cost(); ref.add_energy_cost(); ref.add_time_cost()
+    assert rel_err(pl.coeffs, ref.coeffs) < 1e-11
+    assert np.allclose(pl.costs, ref.costs, rtol=1e-10, atol=1e-14)
+
+
+def test_fp16_field_cost_and_gradient():
+    """cfg5 storage: fp16 field, fp32 arithmetic -- against the oracle on the fp16-rounded field"""
+    rng = np.random.default_rng(8)
+    occ = synth.occupancy_3d(2, n=64, res=30.0 / 64)
+    g3 = npa.ESDF3D.from_occupancy(occ, 30.0 / 64, synth.DOMAIN_ORIGIN, store="f16", want_dist=True)
+    o3 = onp.Grid3DESDF(g3.dist.astype(np.float16).astype(np.float32), 30.0 / 64, synth.DOMAIN_ORIGIN)
+    head, tail, wp, ts = synth.replan_requests(2, 6, 40, D=3)
+    bp = npa.BatchPlanner(sample_dtype="f32")
+    x = bp.pack_x(wp, ts)
+    out = bp.cost_grad(g3, x, head, tail)
+    for b in range(6):
+        pl = onp.OraclePlanner(onp.PlannerParams())
+        pl.read_planning_conditions(o3, head[b], tail[b], wp[b], ts[b])
+        c = pl.get_cost(x[b]); g = pl.get_grad(x[b])
+        assert abs(out["cost"][b] - c) <= 5e-5 * abs(c)
+        assert rel_err(out["grad"][b], g) < 2e-4
+
+
+def test_two_contexts_do_not_interfere(scene):
+    occ, m, _ = scene
+    ctx2 = npa.Context(0)
+    m2 = npa.ESDF(ctx2)
+    m2.occupancy_map_cb(synth.OccupancyGridMsg(np.zeros_like(occ)))
+    head, tail, wp, ts = synth.replan_requests(9, 32, 2, D=2, length_range=(4.0, 6.0))
+    bp1 = npa.BatchPlanner(ctx=m.ctx); bp2 = npa.BatchPlanner(ctx=ctx2)
+    x = bp1.pack_x(wp, ts)
+    a = bp1.optimize(m, x, head, tail); b = bp2.optimize(m2, x, head, tail)
+    a2 = bp1.optimize(m, x, head, tail)
+    assert np.array_equal(a["x"], a2["x"]) and not np.array_equal(a["x"], b["x"])
+    with pytest.raises(ValueError):
+        pl = npa.MinJerkPlanner(ctx=ctx2)
+        pl.read_planning_conditions(m, head[0], tail[0], wp[0], ts[0])      # map lives on another context
+    ctx2.close()
