@@ -2,7 +2,7 @@
 """dump per-trajectory optimiser statistics of the cfg2 batch for offline analysis"""
 import os, sys
 os.environ.setdefault("OMP_NUM_THREADS", "1")
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "neo-planner_amd"))
 import numpy as np
 import neo_planner_amd as npa

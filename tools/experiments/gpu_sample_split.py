@@ -3,7 +3,7 @@
 samples presented as half/third trajectories (more lanes per piece, more waves)"""
 import ctypes, os, sys, time
 os.environ.setdefault("OMP_NUM_THREADS", "1")
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "neo-planner_amd"))
 import numpy as np, torch
 import neo_planner_amd as npa
