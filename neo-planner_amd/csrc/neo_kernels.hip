@@ -21,6 +21,12 @@
 #include <vector>
 
 #include "../../include/neo_planner.h"
+#ifndef NEO_FUSED_U
+#define NEO_FUSED_U (sizeof(Real) == 4 ? 4 : 2)
+#endif
+#ifndef NEO_OPT_WAVES
+#define NEO_OPT_WAVES 1
+#endif
 #include "neo_device.hpp"
 #include "neo_lbfgs.hpp"
 
@@ -149,7 +155,7 @@ struct DevBackend {
 #pragma unroll
         for (int d = 0; d < D; ++d) cr[k][d] = (Real)t.c[k][d];
       LookupT lk(map);
-      minco_sample<Real, D, LookupT, (sizeof(Real) == 4 ? 4 : 2)>(t.M, t.L, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
+      minco_sample<Real, D, LookupT, NEO_FUSED_U>(t.M, t.L, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
 #pragma unroll
       for (int k = 0; k < 6; ++k)
 #pragma unroll
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
 }
 
 template <int D, int NS, typename Real, class MapT, class LookupT>
-__global__ __launch_bounds__(kWave) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
+__global__ __launch_bounds__(kWave, NEO_OPT_WAVES) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
                                                           const int *__restrict__ scene_slot,
                                                           double *__restrict__ x,
                                                           const double *__restrict__ head,
