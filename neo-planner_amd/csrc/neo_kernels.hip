@@ -107,8 +107,16 @@ struct DevBackend {
     __syncthreads();
   }
   __device__ __forceinline__ double sget(int i) const { return sc[i]; }
+#ifndef NEO_LS_IN_REGS  // measured: LDS is faster (registers spill: 14.0 vs 15.5 ms at cfg2)
   __device__ __forceinline__ LineSearch &ls() { return *lsp; }
   __device__ __forceinline__ double *cost_store() { return cst; }
+#else
+  // registers: with one wave per SIMD the file is not the binding constraint, LDS round trips are
+  LineSearch ls_reg;
+  double cst_reg[12];
+  __device__ __forceinline__ LineSearch &ls() { return ls_reg; }
+  __device__ __forceinline__ double *cost_store() { return cst_reg; }
+#endif
 
   // FLAT x -> PIECE inputs
   __device__ __forceinline__ void scatter_x(const Vec &x) {
