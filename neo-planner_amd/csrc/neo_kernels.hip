@@ -685,7 +685,7 @@ struct neo_ctx {
   DevParams dev{};
   std::map<int, MapEntry> maps;
   std::string err;
-  std::mutex mu;
+  std::recursive_mutex mu;  // recursive: the host-pointer entry points hold it across their *_dev call
   // optimiser workspace
   double *hist = nullptr;
   size_t hist_bytes = 0;
@@ -1047,7 +1047,7 @@ int neo_params_set(neo_ctx *c, const neo_params *p) {
     return fail(c, NEO_ERR_INVALID, "bad parameters");
   if (p->sample_dtype != NEO_F64 && p->sample_dtype != NEO_F32)
     return fail(c, NEO_ERR_INVALID, "sample_dtype must be NEO_F64 or NEO_F32");
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   c->params = *p;
   fill_dev_params(c);
   return NEO_OK;
@@ -1072,7 +1072,7 @@ static int drop_locked(neo_ctx *c, int scene_id) {
 
 int neo_esdf_drop(neo_ctx *c, int scene_id) {
   if (!c) return NEO_ERR_INVALID;
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   return drop_locked(c, scene_id);
 }
@@ -1080,7 +1080,7 @@ int neo_esdf_drop(neo_ctx *c, int scene_id) {
 int neo_esdf_upload_2d(neo_ctx *c, int scene_id, const double *dist, const double *gx, const double *gy, int W,
                        int H, double res, double ox, double oy) {
   if (!c || !dist || !gx || !gy || W < 1 || H < 1 || !(res > 0.0)) return NEO_ERR_INVALID;
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   drop_locked(c, scene_id);
   const size_t ncell = (size_t)W * H;
@@ -1107,7 +1107,7 @@ int neo_esdf_upload_2d(neo_ctx *c, int scene_id, const double *dist, const doubl
 int neo_esdf_build_2d(neo_ctx *c, int scene_id, const int8_t *occ, int W, int H, double res, double ox, double oy,
                       double *out_dist, double *out_gx, double *out_gy) {
   if (!c || !occ || W < 1 || H < 1 || !(res > 0.0)) return NEO_ERR_INVALID;
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   drop_locked(c, scene_id);
   const size_t ncell = (size_t)W * H;
@@ -1153,7 +1153,7 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
   if (store_dtype != NEO_F32 && store_dtype != NEO_F16)
     return fail(c, NEO_ERR_INVALID, "store_dtype must be f32 or f16");
   if (layout != NEO_LAYOUT_LINEAR && layout != NEO_LAYOUT_BRICK4) return fail(c, NEO_ERR_INVALID, "bad layout");
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   drop_locked(c, scene_id);
   const size_t nvox = (size_t)nx * ny * nz;
@@ -1202,7 +1202,7 @@ int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_d
   const size_t nvox = (size_t)nx * ny * nz;
   float *d_dist = nullptr;
   {
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     hipSetDevice(c->device);
     const size_t lines = (size_t)std::max(nx * ny, std::max(nx * nz, ny * nz));
     const size_t nmax = (size_t)std::max(nx, std::max(ny, nz));
@@ -1241,7 +1241,7 @@ int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_d
 
 int neo_esdf_query(neo_ctx *c, int scene_id, int n, const double *pts, double *dist, double *grad) {
   if (!c || n < 0 || !pts || !dist) return NEO_ERR_INVALID;
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   auto it = c->maps.find(scene_id);
   if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for this scene");
@@ -1275,7 +1275,7 @@ int neo_cost_grad_batch_dev(neo_ctx *c, int scene_id, int B, int M, int D, const
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
   if (!x || !head || !tail || !cost || !costs4 || !grad) return fail(c, NEO_ERR_INVALID, "null buffer");
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   auto it = c->maps.find(scene_id);
   if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for this scene");
@@ -1295,11 +1295,12 @@ int neo_cost_grad_batch(neo_ctx *c, int scene_id, int B, int M, int D, const dou
   if (rc) return rc;
   if (!x || !head || !tail || !cost || !costs4 || !grad) return fail(c, NEO_ERR_INVALID, "null buffer");
   if (B == 0) return NEO_OK;
+  std::lock_guard<std::recursive_mutex> whole_call(c->mu);  // scratch buffers stay ours until the copies back are done
   const size_t n = (size_t)D * (M - 1) + M, bs = (size_t)B;
   double *dx, *dh, *dt, *dc, *dc4, *dg, *dco;
   int *dst;
   {
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     hipSetDevice(c->device);
     const size_t bytes = bs * (2 * n + 6 * D + 5 + 6 * M * D) * sizeof(double) + bs * sizeof(int) + 8 * 256;
     rc = ensure_scratch(c, bytes);
@@ -1319,7 +1320,7 @@ int neo_cost_grad_batch(neo_ctx *c, int scene_id, int B, int M, int D, const dou
   }
   rc = neo_cost_grad_batch_dev(c, scene_id, B, M, D, dx, dh, dt, dc, dc4, dg, coeffs ? dco : nullptr, dst);
   if (rc) return rc;
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   HIPCHK(c, hipMemcpyAsync(cost, dc, bs * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(costs4, dc4, bs * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(grad, dg, bs * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1334,7 +1335,7 @@ int neo_sampled_terms_batch_dev(neo_ctx *c, int scene_id, int B, int M, int D, c
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
   if (!coeffs || !ts || !costs2 || !grad_C || !grad_T) return fail(c, NEO_ERR_INVALID, "null buffer");
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   auto it = c->maps.find(scene_id);
   if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for this scene");
@@ -1353,10 +1354,11 @@ int neo_sampled_terms_batch(neo_ctx *c, int scene_id, int B, int M, int D, const
   if (rc) return rc;
   if (!coeffs || !ts || !costs2 || !grad_C || !grad_T) return fail(c, NEO_ERR_INVALID, "null buffer");
   if (B == 0) return NEO_OK;
+  std::lock_guard<std::recursive_mutex> whole_call(c->mu);  // scratch buffers stay ours until the copies back are done
   const size_t bs = (size_t)B, nc = (size_t)6 * M * D;
   double *dco, *dts, *dc2, *dgc, *dgt;
   {
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     hipSetDevice(c->device);
     rc = ensure_scratch(c, bs * (2 * nc + 2 * M + 2) * sizeof(double) + 6 * 256);
     if (rc) return rc;
@@ -1371,7 +1373,7 @@ int neo_sampled_terms_batch(neo_ctx *c, int scene_id, int B, int M, int D, const
   }
   rc = neo_sampled_terms_batch_dev(c, scene_id, B, M, D, dco, dts, dc2, dgc, dgt);
   if (rc) return rc;
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   HIPCHK(c, hipMemcpyAsync(costs2, dc2, bs * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(grad_C, dgc, bs * nc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(grad_T, dgt, bs * M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1387,7 +1389,7 @@ int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, i
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
   if (!x || !head || !tail || !costs4 || !nit || !nfev || !status) return fail(c, NEO_ERR_INVALID, "null buffer");
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   if (B == 0) return NEO_OK;
   rc = rebuild_tables(c);
@@ -1433,7 +1435,7 @@ int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, i
 
 int neo_scene_slot(neo_ctx *c, int scene_id) {
   if (!c) return -1;
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   if (rebuild_tables(c)) return -1;
   auto it = c->maps.find(scene_id);
@@ -1447,6 +1449,7 @@ int neo_optimize_batch(neo_ctx *c, int scene_id, const int32_t *scene_ids, int B
   if (rc) return rc;
   if (!x || !head || !tail || !costs4 || !nit || !nfev || !status) return fail(c, NEO_ERR_INVALID, "null buffer");
   if (B == 0) return NEO_OK;
+  std::lock_guard<std::recursive_mutex> whole_call(c->mu);  // scratch buffers stay ours until the copies back are done
   const size_t n = (size_t)D * (M - 1) + M, bs = (size_t)B;
   double *dx, *dh, *dt, *dc4, *dc4l;
   int *dnit, *dnfev, *dst, *dslots = nullptr;
@@ -1460,7 +1463,7 @@ int neo_optimize_batch(neo_ctx *c, int scene_id, const int32_t *scene_ids, int B
     }
   }
   {
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::recursive_mutex> g(c->mu);
     hipSetDevice(c->device);
     const size_t bytes = bs * (n + 6 * D + 8) * sizeof(double) + bs * 4 * sizeof(int) + 10 * 256;
     rc = ensure_scratch(c, bytes);
@@ -1484,7 +1487,7 @@ int neo_optimize_batch(neo_ctx *c, int scene_id, const int32_t *scene_ids, int B
   rc = neo_optimize_batch_dev(c, scene_ids ? scene_ids[0] : scene_id, scene_ids ? dslots : nullptr, B, M, D, dx, dh,
                               dt, dc4, dc4l, dnit, dnfev, dst);
   if (rc) return rc;
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   HIPCHK(c, hipMemcpyAsync(x, dx, bs * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(costs4, dc4, bs * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (costs4_last) HIPCHK(c, hipMemcpyAsync(costs4_last, dc4l, bs * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1501,7 +1504,7 @@ int neo_eval_traj_batch(neo_ctx *c, int B, int M, int D, const double *x, const 
   if (rc) return rc;
   if (!x || !head || !tail || !state || !count || K < 0 || !(hz > 0.0)) return fail(c, NEO_ERR_INVALID, "bad argument");
   if (B == 0 || K == 0) return NEO_OK;
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   const size_t n = (size_t)D * (M - 1) + M, bs = (size_t)B;
   rc = ensure_scratch(c, bs * (n + 6 * D + (size_t)K * 3 * D) * sizeof(double) + bs * sizeof(int) + 6 * 256);
@@ -1528,28 +1531,28 @@ int neo_eval_traj_batch(neo_ctx *c, int B, int M, int D, const double *x, const 
 
 int neo_optimize_sample_counter(neo_ctx *c, int64_t *dev_counts) {
   if (!c) return NEO_ERR_INVALID;
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   c->sample_counter = reinterpret_cast<long long *>(dev_counts);
   return NEO_OK;
 }
 
 int neo_optimize_dispatch_order(neo_ctx *c, const int32_t *dev_order) {
   if (!c) return NEO_ERR_INVALID;
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   c->dispatch_order = dev_order;
   return NEO_OK;
 }
 
 int neo_profile_enable(neo_ctx *c, int on) {
   if (!c) return NEO_ERR_INVALID;
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   c->profile = on != 0;
   return NEO_OK;
 }
 
 int neo_profile_read(neo_ctx *c, int kernel, int64_t *launches, double *total_ms) {
   if (!c || kernel < 0 || kernel >= NEO_KERNEL_COUNT) return NEO_ERR_INVALID;
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   drain_profile(c);
   if (launches) *launches = c->prof[kernel].launches;
@@ -1559,7 +1562,7 @@ int neo_profile_read(neo_ctx *c, int kernel, int64_t *launches, double *total_ms
 
 int neo_profile_reset(neo_ctx *c) {
   if (!c) return NEO_ERR_INVALID;
-  std::lock_guard<std::mutex> g(c->mu);
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   drain_profile(c);
   for (int k = 0; k < NEO_KERNEL_COUNT; ++k) {

@@ -168,3 +168,34 @@ def test_two_contexts_do_not_interfere(scene):
         pl = npa.MinJerkPlanner(ctx=ctx2)
         pl.read_planning_conditions(m, head[0], tail[0], wp[0], ts[0])      # map lives on another context
     ctx2.close()
+
+
+def test_concurrent_callers_on_one_context_are_serialised(scene):
+    """rospy calls the planner from timer / action threads: two threads hammering the
+    same context must get the answers a single thread gets"""
+    import threading
+    _, m, _ = scene
+    bp = npa.BatchPlanner()
+    sets = []
+    for k in range(2):
+        head, tail, wp, ts = synth.replan_requests(20 + k, 257 + 100 * k, 2 + 18 * k, D=2, length_range=(4.0, 9.0))
+        sets.append((bp.pack_x(wp, ts), head, tail))
+    want = [bp.cost_grad(m, *a) for a in sets]
+    want_opt = [bp.optimize(m, *a) for a in sets]
+    errors = []
+
+    def worker(k):
+        try:
+            for _ in range(15):
+                got = bp.cost_grad(m, *sets[k])
+                assert np.array_equal(got["grad"], want[k]["grad"]) and np.array_equal(got["cost"], want[k]["cost"])
+                opt = bp.optimize(m, *sets[k])
+                assert np.array_equal(opt["x"], want_opt[k]["x"])
+        except Exception as ex:               # pragma: no cover
+            errors.append(repr(ex))
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
