@@ -229,7 +229,7 @@ def main():
     order = None
     if not a.no_order:
         order = torch.from_numpy(bp.expected_effort_order(head, tail, ts)).to(dev)
-        ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, ctypes.c_void_p(order.data_ptr())))
+        ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, ctypes.c_void_p(order.data_ptr()), B))
     from neo_planner_amd import sharding
     gathered = torch.empty(world * B, n + 5, dtype=torch.float32, device=dev) if world > 1 else None
     w = torch.tensor(bp.cfg.weights, dtype=torch.float64, device=dev)

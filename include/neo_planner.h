@@ -210,8 +210,12 @@ int neo_optimize_sample_counter(neo_ctx *ctx, int64_t *dev_counts);
 /* optional DEVICE permutation [B] for the next neo_optimize_batch_dev launches: workgroup i works on
  * trajectory order[i].  Results stay in the caller's order.  Workgroups start in index order, so
  * putting the runs expected to be long first shortens the launch (a late long run is its tail);
- * NULL = identity.  neo_planner_amd.BatchPlanner sorts by time slack (sum(ts) * v_max / distance). */
-int neo_optimize_dispatch_order(neo_ctx *ctx, const int32_t *dev_order);
+ * NULL = identity; it must be a permutation of 0..B-1 and is ignored by launches of another batch size.
+ * neo_planner_amd.BatchPlanner sorts by time slack (sum(ts) * v_max / distance). */
+int neo_optimize_dispatch_order(neo_ctx *ctx, const int32_t *dev_order, int B);
+/* the same from a HOST permutation (copied into a context-owned device buffer); NULL or B = 0 resets.
+ * Either way the permutation only applies to launches of exactly B trajectories. */
+int neo_optimize_dispatch_order_host(neo_ctx *ctx, const int32_t *host_order, int B);
 int neo_profile_read(neo_ctx *ctx, int kernel, int64_t *launches, double *total_ms);
 int neo_profile_reset(neo_ctx *ctx);
 

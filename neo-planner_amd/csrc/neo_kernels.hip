@@ -700,6 +700,9 @@ struct neo_ctx {
   ProfileSlot prof[NEO_KERNEL_COUNT];
   long long *sample_counter = nullptr;  // optional device array [B] (neo_optimize_sample_counter)
   const int *dispatch_order = nullptr;  // optional device permutation [B] (neo_optimize_dispatch_order)
+  int order_B = 0;                      // batch size the permutation was given for (ignored for any other B)
+  int *order_buf = nullptr;             // device copy of a host permutation (neo_optimize_dispatch_order_host)
+  size_t order_cap = 0;
 };
 
 namespace {
@@ -885,7 +888,8 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
 #define NEO_OPT(NS)                                                                                           \
   hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT>), grid, blk, dyn, c->stream, a.B, a.M, c->dev, \
                      static_cast<const MapT *>(a.table), a.slots, a.x, a.head, a.tail, c->hist, a.costs4,      \
-                     a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter, c->dispatch_order)
+                     a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter,                                \
+                     (c->order_B == a.B ? c->dispatch_order : nullptr))
   switch (slots_for(a.M, D)) {
     case 1: NEO_OPT(1); break;
     case 2: NEO_OPT(2); break;
@@ -1031,6 +1035,7 @@ int neo_ctx_destroy(neo_ctx *c) {
   for (auto &kv : c->maps)
     if (kv.second.data) hipFree(kv.second.data);
   if (c->hist) hipFree(c->hist);
+  if (c->order_buf) hipFree(c->order_buf);
   if (c->table2d) hipFree(c->table2d);
   if (c->table3d) hipFree(c->table3d);
   if (c->scratch) hipFree(c->scratch);
@@ -1420,6 +1425,7 @@ int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, i
   if (need > c->hist_bytes) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->hist) hipFree(c->hist);
+  if (c->order_buf) hipFree(c->order_buf);
     c->hist = nullptr;
     c->hist_bytes = 0;
     HIPCHK(c, hipMalloc((void **)&c->hist, need));
@@ -1536,10 +1542,35 @@ int neo_optimize_sample_counter(neo_ctx *c, int64_t *dev_counts) {
   return NEO_OK;
 }
 
-int neo_optimize_dispatch_order(neo_ctx *c, const int32_t *dev_order) {
-  if (!c) return NEO_ERR_INVALID;
+int neo_optimize_dispatch_order(neo_ctx *c, const int32_t *dev_order, int B) {
+  if (!c || B < 0) return NEO_ERR_INVALID;
   std::lock_guard<std::recursive_mutex> g(c->mu);
-  c->dispatch_order = dev_order;
+  c->dispatch_order = (dev_order && B > 0) ? dev_order : nullptr;
+  c->order_B = c->dispatch_order ? B : 0;
+  return NEO_OK;
+}
+
+int neo_optimize_dispatch_order_host(neo_ctx *c, const int32_t *host_order, int B) {
+  if (!c || B < 0) return NEO_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> g(c->mu);
+  hipSetDevice(c->device);
+  if (!host_order || B == 0) {
+    c->dispatch_order = nullptr;
+    c->order_B = 0;
+    return NEO_OK;
+  }
+  if ((size_t)B > c->order_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->order_buf) hipFree(c->order_buf);
+    c->order_buf = nullptr;
+    c->order_cap = 0;
+    HIPCHK(c, hipMalloc((void **)&c->order_buf, (size_t)B * sizeof(int)));
+    c->order_cap = (size_t)B;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->order_buf, host_order, (size_t)B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the host array may go away after the call
+  c->dispatch_order = c->order_buf;
+  c->order_B = B;
   return NEO_OK;
 }
 

@@ -405,15 +405,21 @@ class BatchPlanner:
                                               _lib.ptr(costs2), _lib.ptr(gC), _lib.ptr(gT)))
         return dict(costs2=costs2, grad_C=gC, grad_T=gT)
 
-    def optimize(self, map, x0, head, tail, scene_ids=None):
+    def optimize(self, map, x0, head, tail, scene_ids=None, order=True):
         """map: one map for all trajectories (scene_ids None) or any map of the right kind plus
-        scene_ids (B,) int32 of per-trajectory scene ids."""
+        scene_ids (B,) int32 of per-trajectory scene ids.  `order`: start the runs expected to be long
+        first (`expected_effort_order`); results are in the caller's order either way."""
         self._sync()
         c = self.ctx
         x = _lib.as_f64(x0).copy(); head = _lib.as_f64(head); tail = _lib.as_f64(tail)
         B, n = x.shape
         D = head.shape[2]
         M = (n + D) // (D + 1)
+        perm = None
+        if order and B > 1024:
+            _, ts0 = self.unpack_x(x, M, D)
+            perm = self.expected_effort_order(head, tail, ts0)
+        c.check(c.lib.neo_optimize_dispatch_order_host(c.h, _lib.ptr(perm), 0 if perm is None else B))
         costs = np.zeros((B, 4)); last = np.zeros((B, 4))
         nit = np.zeros(B, np.int32); nfev = np.zeros(B, np.int32); st = np.zeros(B, np.int32)
         sid = None if scene_ids is None else np.ascontiguousarray(scene_ids, dtype=np.int32)

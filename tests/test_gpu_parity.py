@@ -394,10 +394,14 @@ def test_full_size_batch_properties(cfg2, dtype):
     # costs reported for the final x are what one more evaluation at that x gives
     e1 = bp.cost_grad(g3, r1["x"], head, tail)
     assert rel_err(e1["costs"][ok], r1["costs"][ok]) < (1e-12 if dtype == "f64" else 1e-5)
-    # a trajectory's result does not depend on its batch neighbours
+    # a trajectory's result does not depend on its batch neighbours, nor on the dispatch order
     pick = np.array([0, 1, 777, 2048, 4095])
     r3 = bp.optimize(g3, x0[pick], head[pick], tail[pick])
     assert np.array_equal(r3["x"], r1["x"][pick])
+    r4 = bp.optimize(g3, x0, head, tail, order=False)
+    assert np.array_equal(r4["x"], r1["x"]) and np.array_equal(r4["nfev"], r1["nfev"])
+    perm = bp.expected_effort_order(head, tail, ts)
+    assert sorted(perm.tolist()) == list(range(4096))
     # every iteration count is sane and evaluations >= iterations
     assert np.all(r1["nfev"] >= r1["nit"]) and r1["nfev"].max() < 15000
 
