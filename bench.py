@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--waypoints", type=int, default=20)
     ap.add_argument("--grid", type=int, default=300)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--layout", default="linear", choices=["linear", "brick4"])
+    ap.add_argument("--layout", default="linear", choices=["linear", "brick4", "cell8"])
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-order", action="store_true", help="dispatch trajectories in index order")

@@ -74,6 +74,8 @@ enum { NEO_F64 = 0, NEO_F32 = 1, NEO_F16 = 2 };
 enum {
   NEO_LAYOUT_LINEAR = 0, /* [z][y][x] */
   NEO_LAYOUT_BRICK4 = 1, /* 4x4x4 bricks (256 B for f32), bricks in [bz][by][bx] order */
+  NEO_LAYOUT_CELL8 = 2,  /* cell-packed: the 2x2x2 corners of every interpolation cell contiguous (8x the
+                            memory; one aligned 32-byte read per lookup instead of four gathers) */
 };
 
 /* planner parameters: DefaultConfig / PlannerConfig fields (expert_planner.py:12-25,

@@ -49,7 +49,7 @@ struct Map2D {
 struct Map3D {
   const void *data;
   int nx, ny, nz;
-  int layout;  // 0 linear [z][y][x], 1 = 4x4x4 bricks
+  int layout;  // 0 linear [z][y][x], 1 = 4x4x4 bricks, 2 = cell-packed (8 corners of every cell contiguous)
   int bx, by;  // bricks per axis (layout 1)
   double res, ox, oy, oz;
   unsigned int bytes;  // size of the stored field (buffer-descriptor range)
@@ -233,7 +233,8 @@ __device__ __forceinline__ void load_pair<__half>(const __half *p, float &a, flo
 }
 
 // trilinear distance + analytic gradient (oracle/minco_np.py:Grid3DESDF defines the semantics)
-// LAYOUT is a template parameter (0 linear, 1 bricks): a run-time branch on the layout inside the sample
+// LAYOUT is a template parameter (0 linear, 1 bricks, 2 cell-packed, 9 = read Map3D::layout at run time,
+// for the point-query kernel only): a run-time branch on the layout inside the sample
 // loop makes the compiler join the two load paths and wait for each sample's loads right there,
 // which defeats keeping several samples' gathers in flight.
 template <typename Real, typename E, int LAYOUT>
@@ -252,7 +253,7 @@ struct Lookup3D {
   };
 
   __device__ __forceinline__ size_t addr(int ix, int iy, int iz) const {
-    if (LAYOUT == 0 || (LAYOUT == 2 && m.layout == 0)) return ((size_t)iz * m.ny + iy) * m.nx + ix;
+    if (LAYOUT == 0 || (LAYOUT == 9 && m.layout == 0)) return ((size_t)iz * m.ny + iy) * m.nx + ix;
     const size_t brick = ((size_t)(iz >> 2) * m.by + (iy >> 2)) * m.bx + (ix >> 2);
     return brick * 64 + ((iz & 3) << 4) + ((iy & 3) << 2) + (ix & 3);
   }
@@ -283,7 +284,27 @@ struct Lookup3D {
   __device__ __forceinline__ Raw load(const Addr &a) const {
     const E *vox = static_cast<const E *>(m.data);
     Raw q;
-    if (LAYOUT == 0 || (LAYOUT == 2 && m.layout == 0)) {  // LAYOUT 2 = decided at run time (point queries)
+    if (LAYOUT == 2 || (LAYOUT == 9 && m.layout == 2)) {
+      // cell-packed: the 8 corners [dz][dy][dx] of cell (ix, iy, iz) are contiguous and 16-byte aligned:
+      // one lookup = one 32-byte (fp32) or 16-byte (fp16) read instead of four gathers
+      const unsigned int cell = __umul24(__umul24((unsigned)a.i0[2], (unsigned)m.ny) + (unsigned)a.i0[1], (unsigned)m.nx) +
+                                (unsigned)a.i0[0];
+      if constexpr (sizeof(E) == 4) {
+        const auto lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cell * 32u), 0, 0);
+        const auto hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cell * 32u + 16u), 0, 0);
+        q.c[0][0][0] = __uint_as_float(lo[0]); q.c[0][0][1] = __uint_as_float(lo[1]);
+        q.c[0][1][0] = __uint_as_float(lo[2]); q.c[0][1][1] = __uint_as_float(lo[3]);
+        q.c[1][0][0] = __uint_as_float(hi[0]); q.c[1][0][1] = __uint_as_float(hi[1]);
+        q.c[1][1][0] = __uint_as_float(hi[2]); q.c[1][1][1] = __uint_as_float(hi[3]);
+      } else {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cell * 16u), 0, 0);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          q.c[w >> 1][w & 1][0] = __half2float(__ushort_as_half((unsigned short)(v[w] & 0xffffu)));
+          q.c[w >> 1][w & 1][1] = __half2float(__ushort_as_half((unsigned short)(v[w] >> 16)));
+        }
+      }
+    } else if (LAYOUT == 0 || (LAYOUT == 9 && m.layout == 0)) {
       // 32-bit element index of corner (0,0,0); the other three x-pairs sit at +nx, +nx*ny, +nx*ny+nx
       const unsigned int base = __umul24(__umul24((unsigned)a.i0[2], (unsigned)m.ny) + (unsigned)a.i0[1], (unsigned)m.nx) +
                                 (unsigned)a.i0[0];

@@ -573,6 +573,24 @@ __global__ void pack3d_kernel(const SrcT *__restrict__ src, int nx, int ny, int 
     dst[o] = (DstT)v;
 }
 
+// cell-packed layout: dst[cell][dz][dy][dx] = src at (ix+dx, iy+dy, iz+dz), clamped at the upper faces
+template <typename SrcT, typename DstT>
+__global__ void pack3d_cell8_kernel(const SrcT *__restrict__ src, int nx, int ny, int nz, DstT *__restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)nx * ny * nz;
+  if (i >= total) return;
+  const int ix = (int)(i % nx), iy = (int)((i / nx) % ny), iz = (int)(i / ((size_t)nx * ny));
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    const int x = min(ix + (w & 1), nx - 1), y = min(iy + ((w >> 1) & 1), ny - 1), z = min(iz + (w >> 2), nz - 1);
+    const float v = (float)src[((size_t)z * ny + y) * nx + x];
+    if constexpr (sizeof(DstT) == 2)
+      dst[i * 8 + w] = __float2half(v);
+    else
+      dst[i * 8 + w] = (DstT)v;
+  }
+}
+
 // get_full_state_cmd (traj_utils.py:85-195): one wavefront per trajectory solves the
 // coefficients, then its lanes walk the sample times.
 template <int D>
@@ -867,6 +885,7 @@ int dispatch_eval(neo_ctx *c, const MapEntry &e, int D, const EvalArgs &a) {
   return f32 ? launch_eval<3, float, Map3D, Lookup3D<float, __half, LAY>>(c, e.m3, a)                \
              : launch_eval<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, e.m3, a);
   if (e.m3.layout == 0) { NEO_3D(0) }
+  if (e.m3.layout == 2) { NEO_3D(2) }
   NEO_3D(1)
 #undef NEO_3D
 }
@@ -914,6 +933,7 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
   return f32 ? launch_opt<3, float, Map3D, Lookup3D<float, __half, LAY>>(c, a)            \
              : launch_opt<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, a);
   if (layout == 0) { NEO_3D(0) }
+  if (layout == 2) { NEO_3D(2) }
   NEO_3D(1)
 #undef NEO_3D
 }
@@ -948,6 +968,7 @@ int dispatch_sample(neo_ctx *c, const MapEntry &e, int D, const SampleArgs &a) {
   return f32 ? launch_sample<3, float, Map3D, Lookup3D<float, __half, LAY>>(c, e.m3, a)              \
              : launch_sample<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, e.m3, a);
   if (e.m3.layout == 0) { NEO_3D(0) }
+  if (e.m3.layout == 2) { NEO_3D(2) }
   NEO_3D(1)
 #undef NEO_3D
 }
@@ -1157,14 +1178,16 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
   if (src_dtype != NEO_F64 && src_dtype != NEO_F32) return fail(c, NEO_ERR_INVALID, "src_dtype must be f64 or f32");
   if (store_dtype != NEO_F32 && store_dtype != NEO_F16)
     return fail(c, NEO_ERR_INVALID, "store_dtype must be f32 or f16");
-  if (layout != NEO_LAYOUT_LINEAR && layout != NEO_LAYOUT_BRICK4) return fail(c, NEO_ERR_INVALID, "bad layout");
+  if (layout != NEO_LAYOUT_LINEAR && layout != NEO_LAYOUT_BRICK4 && layout != NEO_LAYOUT_CELL8)
+    return fail(c, NEO_ERR_INVALID, "bad layout");
   std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   drop_locked(c, scene_id);
   const size_t nvox = (size_t)nx * ny * nz;
   const size_t ssz = src_dtype == NEO_F64 ? 8 : 4, dsz = store_dtype == NEO_F32 ? 4 : 2;
   const int bx = (nx + 3) / 4, by = (ny + 3) / 4, bz = (nz + 3) / 4;
-  const size_t nstore = layout == NEO_LAYOUT_BRICK4 ? (size_t)bx * by * bz * 64 : nvox;
+  const size_t nstore = layout == NEO_LAYOUT_BRICK4 ? (size_t)bx * by * bz * 64 : (layout == NEO_LAYOUT_CELL8 ? nvox * 8 : nvox);
+  if ((nstore + 64) * dsz >= (size_t)4 << 30) return fail(c, NEO_ERR_INVALID, "field too large for 32-bit buffer offsets in this layout");
   const void *src = dist;
   void *staged = nullptr;
   if (!src_is_device) {
@@ -1179,7 +1202,16 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
   HIPCHK(c, hipMalloc(&e.data, (nstore + 64) * dsz));
   HIPCHK(c, hipMemsetAsync(e.data, 0, (nstore + 64) * dsz, c->stream));
   const dim3 grid((unsigned)((nvox + 255) / 256)), blk(256);
-  if (src_dtype == NEO_F64 && store_dtype == NEO_F32)
+  if (layout == NEO_LAYOUT_CELL8) {
+    if (src_dtype == NEO_F64 && store_dtype == NEO_F32)
+      hipLaunchKernelGGL((pack3d_cell8_kernel<double, float>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz, (float *)e.data);
+    else if (src_dtype == NEO_F64)
+      hipLaunchKernelGGL((pack3d_cell8_kernel<double, __half>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz, (__half *)e.data);
+    else if (store_dtype == NEO_F32)
+      hipLaunchKernelGGL((pack3d_cell8_kernel<float, float>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz, (float *)e.data);
+    else
+      hipLaunchKernelGGL((pack3d_cell8_kernel<float, __half>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz, (__half *)e.data);
+  } else if (src_dtype == NEO_F64 && store_dtype == NEO_F32)
     hipLaunchKernelGGL((pack3d_kernel<double, float>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz,
                        layout, bx, by, (float *)e.data);
   else if (src_dtype == NEO_F64)
@@ -1263,10 +1295,10 @@ int neo_esdf_query(neo_ctx *c, int scene_id, int n, const double *pts, double *d
     hipLaunchKernelGGL((query_kernel<double, Map2D, Lookup2D<double>, 2>), grid, blk, 0, c->stream, n, e.m2, d_p, d_d,
                        d_g);
   else if (e.elem == NEO_F32)
-    hipLaunchKernelGGL((query_kernel<double, Map3D, Lookup3D<double, float, 2>, 3>), grid, blk, 0, c->stream, n, e.m3,
+    hipLaunchKernelGGL((query_kernel<double, Map3D, Lookup3D<double, float, 9>, 3>), grid, blk, 0, c->stream, n, e.m3,
                        d_p, d_d, d_g);
   else
-    hipLaunchKernelGGL((query_kernel<double, Map3D, Lookup3D<double, __half, 2>, 3>), grid, blk, 0, c->stream, n, e.m3,
+    hipLaunchKernelGGL((query_kernel<double, Map3D, Lookup3D<double, __half, 9>, 3>), grid, blk, 0, c->stream, n, e.m3,
                        d_p, d_d, d_g);
   HIPCHK(c, hipMemcpyAsync(dist, d_d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (grad) HIPCHK(c, hipMemcpyAsync(grad, d_g, (size_t)n * dm * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(PKG, "libneo_planner_hip.so")
 
 NEO_OK = 0
 NEO_F64, NEO_F32, NEO_F16 = 0, 1, 2
-NEO_LAYOUT_LINEAR, NEO_LAYOUT_BRICK4 = 0, 1
+NEO_LAYOUT_LINEAR, NEO_LAYOUT_BRICK4, NEO_LAYOUT_CELL8 = 0, 1, 2
 NEO_TRAJ_CONVERGED_GRAD, NEO_TRAJ_CONVERGED_F, NEO_TRAJ_ABNORMAL = 0, 1, 2
 NEO_TRAJ_MAXITER, NEO_TRAJ_NUMERIC_RANGE, NEO_TRAJ_NONFINITE = 3, 4, 5
 NEO_TRAJ_FLAG_COLLISION = 0x100

@@ -77,7 +77,7 @@ def test_esdf_build_3d_is_the_exact_edt(shape, seed):
     occ = (rng.random(shape) < 0.01).astype(np.uint8)
     occ[0] = 1                                            # ground slab, as every synthetic scene has
     want = (ndimage.distance_transform_edt(1 - occ) * 0.1).astype(np.float32)
-    for layout in ("linear", "brick4"):
+    for layout in ("linear", "brick4", "cell8"):
         g3 = npa.ESDF3D.from_occupancy(occ, 0.1, (0.0, -1.0, 0.0), layout=layout, want_dist=True)
         assert np.array_equal(g3.dist, want)
         pts = rng.uniform([0, -1, 0], [shape[2] * 0.1, -1 + shape[1] * 0.1, shape[0] * 0.1], (500, 3))
@@ -103,7 +103,7 @@ def test_trilinear_lookup_matches_oracle_and_ties_back_to_2d():
     rng = np.random.default_rng(1)
     h, w = d["esdf_map"].shape
     pts = rng.uniform([origin[0] - 0.2, origin[1] - 0.2, -0.1], [origin[0] + w * res + 0.2, origin[1] + h * res + 0.2, 0.7], (3000, 3))
-    for layout in ("linear", "brick4"):
+    for layout in ("linear", "brick4", "cell8"):
         for store, tol in (("f32", 1e-12), ("f16", 2e-3)):
             g3 = npa.ESDF3D(vol, res, origin, store=store, layout=layout)
             dis, grd = g3.query(pts)
@@ -187,7 +187,7 @@ def test_cost_grad_trilinear_matches_oracle():
     dist = (ndimage.distance_transform_edt(1 - occ) * res).astype(np.float32)
     origin = (-1.0, -6.0, 0.0)
     o3 = onp.Grid3DESDF(dist, res, origin)
-    for layout in ("linear", "brick4"):
+    for layout in ("linear", "brick4", "cell8"):
         g3 = npa.ESDF3D(dist, res, origin, store="f32", layout=layout)
         for M, B in ((3, 4), (21, 4), (41, 2)):
             head, tail, wp, ts = _random_requests(rng, B, M, 3, (np.array([0.0, -5.0, 1.0]), np.array([10.5, 5.0, 8.0])))
