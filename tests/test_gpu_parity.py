@@ -420,3 +420,50 @@ def test_multi_scene_batch_uses_the_right_map():
     rm = bp.optimize(ma, x0, head, tail, scene_ids=ids)
     want = np.where((np.arange(16) % 2 == 0)[:, None], ra["x"], rb["x"])
     assert np.array_equal(rm["x"], want)
+
+
+def _cpu_run_3d(args):
+    """worker (spawned, never touches the GPU): one trajectory through the CPU oracle on the 3-D field"""
+    scene, n, b = args
+    import numpy as _np
+    from neo_planner_amd import synth as _synth
+    from oracle import minco_np as _onp
+    res = 30.0 / n
+    o3 = _onp.Grid3DESDF(_synth.esdf_3d(scene, n=n, res=res), res, _synth.DOMAIN_ORIGIN)
+    head, tail, wp, ts = _synth.replan_requests(scene, 64, 20, D=3)
+    pl = _onp.OraclePlanner(_onp.PlannerParams())
+    pl.read_planning_conditions(o3, head[b], tail[b], wp[b], ts[b])
+    try:
+        pl.plan_once()
+    except Exception:
+        pass
+    r = pl.last_result
+    return b, (r.nit, r.nfev) if r is not None else (-1, -1), float(_np.dot(pl.costs, pl.weights)), pl.int_wpts.copy()
+
+
+def test_3d_runs_follow_the_cpu_optimizer_in_fp64_mode():
+    """north-star shape (M = 21, D = 3, trilinear field) in parity mode: most runs take exactly the CPU's
+    evaluations and end at the CPU's control points; all of them end at comparable cost"""
+    import multiprocessing as mp
+    scene, n, B = 3, 100, 24
+    with mp.get_context("spawn").Pool(min(B, 24)) as pool:
+        cpu = sorted(pool.map(_cpu_run_3d, [(scene, n, b) for b in range(B)]))
+    res = 30.0 / n
+    g3 = npa.ESDF3D.from_occupancy(synth.occupancy_3d(scene, n=n, res=res), res, synth.DOMAIN_ORIGIN)
+    head, tail, wp, ts = synth.replan_requests(scene, 64, 20, D=3)
+    bp = npa.BatchPlanner(sample_dtype="f64")
+    out = bp.optimize(g3, bp.pack_x(wp[:B], ts[:B]), head[:B], tail[:B])
+    wq, _ = bp.unpack_x(out["x"], 21, 3)
+    w = np.array(bp.cfg.weights)
+    same = 0
+    rels = []
+    for b, (nit, nfev), cost, wpts in cpu:
+        if nit < 0:
+            continue
+        gpu_cost = float((out["costs_last"][b] * w).sum())
+        rels.append(abs(gpu_cost - cost) / abs(cost))
+        if int(out["nit"][b]) == nit and int(out["nfev"][b]) == nfev and rel_err(wq[b], wpts) < 1e-6:
+            same += 1                      # the run followed the CPU step for step
+            assert rels[-1] < 1e-6
+    assert same >= 0.4 * len(rels), (same, len(rels))
+    assert np.median(rels) < 1e-4 and max(rels) < 0.2, (np.median(rels), max(rels))
