@@ -339,6 +339,38 @@ class MinJerkPlanner:
     def get_acc_array(self):
         return self._states(10.0)[:, 2, :]
 
+    # single-time evaluators (traj_utils.py:85-179).  Not on the hot path (visualisation helpers): plain
+    # polynomial evaluation of the device-computed coefficients, with the reference's piece search.
+    def _at(self, t, order):
+        if isinstance(self.coeffs, list) and self.coeffs == []:
+            self.get_coeffs(self.int_wpts, self.ts)
+        total = sum(self.ts)
+        if t > total:
+            t = total
+        k = 0
+        while sum(self.ts[:k + 1]) < t:
+            k += 1
+        T = t - sum(self.ts[:k])
+        beta = [np.array([1, T, T**2, T**3, T**4, T**5]), np.array([0, 1, 2*T, 3*T**2, 4*T**3, 5*T**4]),
+                np.array([0, 0, 2, 6*T, 12*T**2, 20*T**3]), np.array([0, 0, 0, 6, 24*T, 60*T**2])][order]
+        return np.dot(np.asarray(self.coeffs)[6 * k:6 * k + 6, :].T, beta)[None, :]
+
+    def get_pos(self, t):
+        return self._at(t, 0)
+
+    def get_vel(self, t):
+        return self._at(t, 1)
+
+    def get_acc(self, t):
+        return self._at(t, 2)
+
+    def get_jerk(self, t):
+        return self._at(t, 3)
+
+    def get_jer_array(self):
+        self.get_coeffs(self.int_wpts, self.ts)
+        return np.concatenate([self.get_jerk(t) for t in np.arange(0, sum(self.ts), 0.1)], axis=0)
+
     def print_results(self):
         print("-----------------------Final intermediate waypoints-----------------------")
         print(np.asarray(self.int_wpts).T)

@@ -199,3 +199,22 @@ def test_concurrent_callers_on_one_context_are_serialised(scene):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+def test_single_time_evaluators(scene):
+    """traj_utils.py:85-179 get_pos / get_vel / get_acc / get_jerk at arbitrary times"""
+    _, m, o2 = scene
+    head = np.array([[1.0, 0.2], [0.3, 0.0]]); tail = np.array([[6.0, -0.4], [0.6, 0.1]])
+    pl = npa.MinJerkPlanner(npa.PlannerConfig())
+    ref = onp.OraclePlanner(onp.PlannerParams())
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        pl.plan(m, head, tail); ref.plan(o2, head, tail)
+    ref.get_coeffs(ref.int_wpts, ref.ts)
+    pl.get_coeffs(pl.int_wpts, pl.ts)
+    for t in (0.0, 0.37, float(pl.ts[0]), float(sum(pl.ts[:2])) + 0.01, float(sum(pl.ts)), float(sum(pl.ts)) + 3.0):
+        assert np.allclose(pl.get_pos(t), ref.get_pos(t), rtol=1e-9, atol=1e-12)
+        assert np.allclose(pl.get_vel(t), ref.get_vel(t), rtol=1e-9, atol=1e-12)
+        assert np.allclose(pl.get_acc(t), ref.get_acc(t), rtol=1e-8, atol=1e-10)
+        assert np.allclose(pl.get_jerk(t), ref.get_jerk(t), rtol=1e-8, atol=1e-9)
+    assert pl.get_jer_array().shape == (len(np.arange(0, sum(pl.ts), 0.1)), 2)
