@@ -162,7 +162,8 @@ int neo_cost_grad_batch_dev(neo_ctx *ctx, int scene_id, int B, int M, int D, con
  * (all_planner_demo.py:46-51).  coeffs[B][6M][D], ts[B][M]  ->
  *   costs2[B][2]      unweighted feasibility and collision cost            (:413, :422)
  *   grad_C[B][6M][D]  weighted partials w.r.t. the coefficients            (:450, :465)
- *   grad_T[B][M]      weighted partials w.r.t. the durations               (:451, :466) */
+ *   grad_T[B][M]      weighted partials w.r.t. the durations               (:451, :466)
+ * _dev: coeffs and grad_C must be 16-byte aligned (the kernel moves them as pairs of doubles). */
 int neo_sampled_terms_batch(neo_ctx *ctx, int scene_id, int B, int M, int D, const double *coeffs,
                             const double *ts, double *costs2, double *grad_C, double *grad_T);
 int neo_sampled_terms_batch_dev(neo_ctx *ctx, int scene_id, int B, int M, int D, const double *coeffs,

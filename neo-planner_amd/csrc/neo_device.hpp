@@ -160,15 +160,17 @@ struct Lookup2D {
   struct Raw {
     double4 r;
   };
+  // `on` = false (an idle sample slot): treated like a point outside the map, so that all idle lanes of a
+  // wavefront read one and the same record instead of 64 scattered ones
   template <int D>
-  __device__ __forceinline__ Addr prepare(const Real (&pos)[D]) const {
+  __device__ __forceinline__ Addr prepare(const Real (&pos)[D], bool on = true) const {
     // index arithmetic in fp64 with a true division, exactly like int((y - origin.y) / res)
     const double fy = ((double)pos[1] - m.oy) / m.res;
     const double fx = ((double)pos[0] - m.ox) / m.res;
     Addr a;
     a.idx = 0;
     a.inside = false;
-    if (!(fabs(fy) < 1.0e9) || !(fabs(fx) < 1.0e9)) return a;
+    if (!on || !(fabs(fy) < 1.0e9) || !(fabs(fx) < 1.0e9)) return a;
     const int row = (int)fy, col = (int)fx;  // C casts truncate toward zero, like int()
     if (row < 0 || row >= m.H || col < 0 || col >= m.W) return a;
     a.inside = true;
@@ -220,8 +222,11 @@ __device__ __forceinline__ void load_pair<float>(const float *p, float &a, float
 // The compiler splits a dword-aligned 8-byte *global* load into two dword loads; a raw buffer load
 // of 8 bytes at a dword-aligned offset is one instruction and returns the right data on gfx950
 // (tools/probe/unaligned_pair.hip).  `off` = byte offset into the field.
-__device__ __forceinline__ void buffer_load_pair_f32(__amdgpu_buffer_rsrc_t rsrc, unsigned int off, float &a, float &b) {
-  const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off, 0, 0);
+// `soff` is a wave-uniform byte offset (an SGPR operand of the instruction: the four x-pairs of a lookup share
+// one address register).
+__device__ __forceinline__ void buffer_load_pair_f32(__amdgpu_buffer_rsrc_t rsrc, unsigned int off, unsigned int soff,
+                                                     float &a, float &b) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off, (int)soff, 0);
   a = __uint_as_float(v[0]);
   b = __uint_as_float(v[1]);
 }
@@ -241,8 +246,18 @@ template <typename Real, typename E, int LAYOUT>
 struct Lookup3D {
   const Map3D &m;
   __amdgpu_buffer_rsrc_t rsrc;
+  // fp32 arithmetic: cell coordinate minus one half in ONE fma, um = pos * inv + off (all wave-uniform operands)
+  float inv, off[3], hi[3];
   __device__ __forceinline__ explicit Lookup3D(const Map3D &m_)
-      : m(m_), rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(m_.data), 0, (int)m_.bytes, 0x00020000)) {}
+      : m(m_), rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(m_.data), 0, (int)m_.bytes, 0x00020000)) {
+    inv = (float)(1.0 / m_.res);
+    off[0] = (float)(-m_.ox / m_.res - 0.5);
+    off[1] = (float)(-m_.oy / m_.res - 0.5);
+    off[2] = (float)(-m_.oz / m_.res - 0.5);
+    hi[0] = (float)m_.nx - 0.5f;
+    hi[1] = (float)m_.ny - 0.5f;
+    hi[2] = (float)m_.nz - 0.5f;
+  }
   struct Addr {
     int i0[3];
     Real fr[3];
@@ -258,20 +273,30 @@ struct Lookup3D {
     return brick * 64 + ((iz & 3) << 4) + ((iy & 3) << 2) + (ix & 3);
   }
 
+  // `on` = false (an idle sample slot): treated like a point outside the field -- corner (0,0,0) for every
+  // idle lane, i.e. one cache line per wavefront instead of 64 scattered gathers
   template <int D>
-  __device__ __forceinline__ Addr prepare(const Real (&pos)[D]) const {
+  __device__ __forceinline__ Addr prepare(const Real (&pos)[D], bool on = true) const {
     static_assert(D == 3, "the 3-D map needs D = 3");
     const int n[3] = {m.nx, m.ny, m.nz};
     const double org[3] = {m.ox, m.oy, m.oz};
     Addr a;
-    a.inside = true;
+    a.inside = on;
+    if constexpr (sizeof(Real) == 4) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float um = fmaf(pos[k], inv, off[k]);
+        if (!(um >= -0.5f && um < hi[k])) a.inside = false;
+        const int i = min(max((int)floorf(um), 0), n[k] - 2);
+        a.i0[k] = i;
+        a.fr[k] = __builtin_amdgcn_fmed3f(um - (float)i, 0.0f, 1.0f);
+      }
+      if (!a.inside) a.i0[0] = a.i0[1] = a.i0[2] = 0;
+      return a;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      Real u;
-      if constexpr (sizeof(Real) == 8)
-        u = (Real)(((double)pos[k] - org[k]) / m.res);  // as oracle Grid3DESDF._cell
-      else
-        u = (pos[k] - (Real)org[k]) * (Real)(1.0 / m.res);
+      Real u = (Real)(((double)pos[k] - org[k]) / m.res);  // as oracle Grid3DESDF._cell
       if (!(u >= Real(0) && u < (Real)n[k])) a.inside = false;
       u -= Real(0.5);
       const int i = min(max((int)floor(u), 0), n[k] - 2);
@@ -313,11 +338,11 @@ struct Lookup3D {
       for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
-          const unsigned int e = base + (dy ? sy : 0u) + (dz ? sz : 0u);
+          const unsigned int so = (dy ? sy : 0u) + (dz ? sz : 0u);
           if constexpr (sizeof(E) == 4)
-            buffer_load_pair_f32(rsrc, e * 4u, q.c[dz][dy][0], q.c[dz][dy][1]);
+            buffer_load_pair_f32(rsrc, base * 4u, so * 4u, q.c[dz][dy][0], q.c[dz][dy][1]);
           else
-            load_pair<E>(vox + e, q.c[dz][dy][0], q.c[dz][dy][1]);
+            load_pair<E>(vox + base + so, q.c[dz][dy][0], q.c[dz][dy][1]);
         }
     } else {
 #pragma unroll
@@ -621,25 +646,83 @@ __device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, d
   return 0;
 }
 
+// position and velocity of a piece at local time s: two Horner chains (the compiler pairs them into packed
+// fp32 fma's; the pre-scaled coefficients k*c_k are hoisted into registers), or, LEAN, Horner on p and p'
+// together -- 9 dependent fma per axis but no extra registers, which is what lets the stand-alone fp32
+// kernel fit 128 VGPRs.
+template <typename Real, int D, bool LEAN>
+__device__ __forceinline__ void piece_pos_vel(const Real (&c)[6][D], Real s, Real (&pos)[D], Real (&vel)[D]) {
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    if constexpr (LEAN && sizeof(Real) == 4) {
+      Real a = c[5][d], b = c[5][d];
+      a = fmaf(a, s, c[4][d]); b = fmaf(b, s, a);
+      a = fmaf(a, s, c[3][d]); b = fmaf(b, s, a);
+      a = fmaf(a, s, c[2][d]); b = fmaf(b, s, a);
+      a = fmaf(a, s, c[1][d]); b = fmaf(b, s, a);
+      a = fmaf(a, s, c[0][d]);
+      pos[d] = a;
+      vel[d] = b;
+    } else {
+      pos[d] = c[0][d] + s * (c[1][d] + s * (c[2][d] + s * (c[3][d] + s * (c[4][d] + s * c[5][d]))));
+      vel[d] = c[1][d] + s * (Real(2) * c[2][d] + s * (Real(3) * c[3][d] + s * (Real(4) * c[4][d] + s * (Real(5) * c[5][d]))));
+    }
+  }
+}
+
+// sum over the L lanes (residues r = 0..L-1, adjacent lanes) of each piece; valid in the lane with r = 0.
+// L <= 4 (M >= 16): wave_shl:1 DPP moves, summed left to right ((v_0 + v_1) + v_2) + v_3; otherwise a tree.
+template <typename Real>
+__device__ __forceinline__ Real fold_piece_lanes(Real v, int L, int r) {
+  if (L <= 4) {
+    Real acc = v, t = v;
+    for (int i = 1; i < L; ++i) {
+      if constexpr (sizeof(Real) == 4)
+        t = dpp_f<0x130>(t);
+      else
+        t = dpp_d<0x130>(t);
+      acc += t;
+    }
+    return acc;
+  }
+  for (int sft = 1; sft < L; sft <<= 1) {
+    const Real o = __shfl_down(v, sft, kWave);
+    if (r + sft < L) v += o;
+  }
+  return v;
+}
+
 // sampled feasibility + collision terms (:392-466), SAMPLE layout.
-// In (PIECE layout): cp = coefficients of the lane's piece, ns_piece = its sample count.
-// Out (PIECE layout): gC, gT = weighted partials of the two sampled terms; costs wave-uniform.
-// U = samples per lane whose gathers are put in flight together.
-template <typename Real, int D, class LookupT, int U>
-__device__ __forceinline__ void minco_sample(int M, int L, int ns_piece, const Real (&cp)[6][D],
+// SAMPLE_IO = false (fused kernels): in (PIECE layout) cp = coefficients of the lane's piece, ns_in = its sample
+//   count; out (PIECE layout) gC, gT = weighted partials of the two sampled terms.
+// SAMPLE_IO = true (stand-alone kernel): cp / ns_in are already those of the SAMPLE-layout lane's piece, and
+//   gC / gT are left in the first lane (r = 0) of each piece.
+// Costs are returned wave-uniform.  U = samples per lane whose gathers are put in flight together.
+template <typename Real, int D, class LookupT, int U, bool SAMPLE_IO = false>
+__device__ __forceinline__ void minco_sample(int M, int L, int ns_in, const Real (&cp)[6][D],
                                              const DevParams &prm, const LookupT &lk, Real (&gC)[6][D], Real &gT,
                                              double &cost_feas, double &cost_coll) {
   const int lane = lane_id();
-  const int piece = lane / L, r = lane - piece * L;
+  const int piece = (lane * ((65536 + L - 1) / L)) >> 16;  // lane / L for lane < 64
+  const int r = lane - piece * L;
   const bool act = piece < M;
-  // hand the piece data to its L sample lanes
   Real c[6][D];
+  int ns;
+  if constexpr (SAMPLE_IO) {
 #pragma unroll
-  for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < 6; ++k)
 #pragma unroll
-    for (int d = 0; d < D; ++d) c[k][d] = __shfl(cp[k][d], piece, kWave);
-  const int ns_sh = __shfl(ns_piece, piece, kWave);
-  const int ns = act ? ns_sh : 0;
+      for (int d = 0; d < D; ++d) c[k][d] = cp[k][d];
+    ns = act ? ns_in : 0;
+  } else {
+    // hand the piece data to its L sample lanes
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int d = 0; d < D; ++d) c[k][d] = __shfl(cp[k][d], piece, kWave);
+    const int ns_sh = __shfl(ns_in, piece, kWave);
+    ns = act ? ns_sh : 0;
+  }
   const int iters = (prm.dbg & 1) ? 0 : wave_max_nonneg((ns + L - 1) / L);
 
   const Real dt = (Real)prm.delta_t, vmax2 = (Real)(prm.v_max * prm.v_max), safe = (Real)prm.safe_dis;
@@ -655,25 +738,40 @@ __device__ __forceinline__ void minco_sample(int M, int L, int ns_piece, const R
   // U samples per lane are prepared together and their gathers issued back to back before any of
   // them is consumed
   for (int it0 = 0; it0 < iters; it0 += U) {
-    Real sv[U], pos[U][D], vel[U][D];
+    Real sv[U], vel[U][D];
     typename LookupT::Addr ad[U];
     typename LookupT::Raw rw[U];
     bool on[U];
+    // stand-alone kernel: lanes whose piece has run out of samples sit the round out (exec-masked)
+    if constexpr (SAMPLE_IO)
+      if (r + it0 * L >= ns) continue;
+    // LEAN: only the position is needed to issue the gathers; the velocity is evaluated while they fly
+    constexpr bool kVelLate = SAMPLE_IO && sizeof(Real) == 4;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int j = r + (it0 + u) * L;
       on[u] = j < ns;
       const Real s = (Real)((double)j * prm.delta_t);  // beta_full row j: t = j * delta_t (:251)
       sv[u] = s;
+      Real pos[D];
+      if constexpr (kVelLate) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        pos[u][d] = c[0][d] + s * (c[1][d] + s * (c[2][d] + s * (c[3][d] + s * (c[4][d] + s * c[5][d]))));
-        vel[u][d] = c[1][d] + s * (Real(2) * c[2][d] + s * (Real(3) * c[3][d] + s * (Real(4) * c[4][d] + s * (Real(5) * c[5][d]))));
+        for (int d = 0; d < D; ++d)
+          pos[d] = fmaf(fmaf(fmaf(fmaf(fmaf(c[5][d], s, c[4][d]), s, c[3][d]), s, c[2][d]), s, c[1][d]), s, c[0][d]);
+      } else {
+        piece_pos_vel<Real, D, SAMPLE_IO>(c, s, pos, vel[u]);
       }
-      ad[u] = lk.template prepare<D>(pos[u]);  // (an idle slot still yields a valid, ignored address)
+      ad[u] = lk.template prepare<D>(pos, on[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) rw[u] = lk.load(ad[u]);
+    if constexpr (kVelLate) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        Real pos[D];
+        piece_pos_vel<Real, D, SAMPLE_IO>(c, sv[u], pos, vel[u]);
+      }
+    }
     // violations are rare: first only the two penalties' arguments for the U samples, one test for the
     // whole group, and the per-sample accumulation code only if some lane of the wave needs it
     Real vv[U], vd[U];
@@ -737,13 +835,11 @@ __device__ __forceinline__ void minco_sample(int M, int L, int ns_piece, const R
       }
     }
   }
-  // fold the L lanes of each piece (fixed tree), then move lane piece*L -> lane piece
+  // fold the L lanes of each piece (fixed order); PIECE-layout callers get lane piece*L moved to lane piece
   auto fold = [&](Real v) -> Real {
-    for (int sft = 1; sft < L; sft <<= 1) {
-      const Real o = __shfl_down(v, sft, kWave);
-      if (r + sft < L) v += o;
-    }
-    return __shfl(v, lane * L, kWave);
+    const Real f = fold_piece_lanes<Real>(v, L, r);
+    if constexpr (SAMPLE_IO) return f;
+    return __shfl(f, lane * L, kWave);
   };
 #pragma unroll
   for (int k = 0; k < 6; ++k)
@@ -751,8 +847,9 @@ __device__ __forceinline__ void minco_sample(int M, int L, int ns_piece, const R
     for (int d = 0; d < D; ++d) gC[k][d] = fold(aC[k][d]);
   gT = fold(aT);
   const Real pf = fold(aF), pk = fold(aK);
-  cost_feas = wave_sum(lane < M ? (double)pf : 0.0);
-  cost_coll = wave_sum(lane < M ? (double)pk : 0.0);
+  const bool mine = SAMPLE_IO ? (act && r == 0) : (lane < M);
+  cost_feas = wave_sum(mine ? (double)pf : 0.0);
+  cost_coll = wave_sum(mine ? (double)pk : 0.0);
 }
 
 // backward pass (PIECE layout): gC = dW/dc incl. sampled part, gT = direct dW/dT incl. sampled part

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdint>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -50,6 +51,9 @@ struct DevBackend {
   int npad, m;
   double *coeff_out;  // optional [6M][D] (eval kernel)
   long long samples = 0;  // quadrature samples visited so far (lane-uniform), for the bench's byte count
+#ifdef NEO_STAMPS  // timing experiments (tools/gpu_straggler.py): 100 MHz wall-clock ticks per phase
+  long long tk[4] = {0, 0, 0, 0};  // forward, sample, backward, evaluations
+#endif
 
   __device__ DevBackend(const DevParams &p, const MapT &mp) : prm(p), map(mp) {}
 
@@ -139,9 +143,15 @@ struct DevBackend {
   // one evaluation of cost and gradient (get_cost + get_grad, :539-585)
   __device__ __forceinline__ int eval(const Vec &x, double &f, Vec &g, double *costs) {
     const int lane = lane_id();
+#ifdef NEO_STAMPS
+    const long long s0 = wall_clock64();
+#endif
     scatter_x(x);
     double energy, tsum;
     const int st = minco_forward<D>(t, prm, energy, tsum);
+#ifdef NEO_STAMPS
+    const long long s1 = wall_clock64();
+#endif
     if (st != 0) {
       f = 0.0;
 #pragma unroll
@@ -170,6 +180,9 @@ struct DevBackend {
         for (int d = 0; d < D; ++d) gC[k][d] = (double)gCr[k][d];
       gT = (double)gTr;
     }
+#ifdef NEO_STAMPS
+    const long long s2 = wall_clock64();
+#endif
     costs[0] = uniform(energy);
     costs[1] = uniform(tsum);
     costs[2] = uniform(cf);
@@ -188,6 +201,13 @@ struct DevBackend {
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NS; ++k) g.v[k] = (k * kWave + lane < t.n) ? xs[k * kWave + lane] : 0.0;
+#ifdef NEO_STAMPS
+    const long long s3 = wall_clock64();
+    tk[0] += s1 - s0;
+    tk[1] += s2 - s1;
+    tk[2] += s3 - s2;
+    tk[3] += 1;
+#endif
     return 0;
   }
 };
@@ -294,7 +314,19 @@ __global__ __launch_bounds__(kWave, NEO_OPT_WAVES) void optimize_kernel(int B, i
   for (int k = 0; k < NS; ++k) xv.v[k] = (k * kWave + lane < n) ? x[(size_t)b * n + k * kWave + lane] : 0.0;
   LbfgsOpts o{prm.ftol, prm.gtol, prm.maxls, prm.maxiter, prm.maxfun, NEO_LBFGS_M};
   LbfgsResult res;
+#ifdef NEO_STAMPS
+  const long long k0 = wall_clock64();
+#endif
   lbfgs_minimize(be, xv, o, res);
+#ifdef NEO_STAMPS
+  if (lane == 0 && nsamples) {  // the counter buffer is [B][8] in this build
+    long long *o8 = nsamples + (size_t)b * 8;
+    o8[1] = be.tk[3]; o8[2] = be.tk[0]; o8[3] = be.tk[1]; o8[4] = be.tk[2];
+    o8[5] = wall_clock64() - k0; o8[6] = k0; o8[7] = blockIdx.x;
+    o8[0] = be.samples;
+  }
+  nsamples = nullptr;
+#endif
 #pragma unroll
   for (int k = 0; k < NS; ++k)
     if (k * kWave + lane < n) x[(size_t)b * n + k * kWave + lane] = xv.v[k];
@@ -316,35 +348,53 @@ __global__ __launch_bounds__(kWave, NEO_OPT_WAVES) void optimize_kernel(int B, i
 
 // add_sampled_cost + add_sampled_grad_CT (expert_planner.py:392-466) as a kernel of its own: the ESDF
 // lookup kernel.  Input: polynomial coefficients and durations; output: the two sampled cost terms and
-// their partials w.r.t. coefficients and durations.  One wavefront per trajectory, SAMPLE layout.
+// their partials w.r.t. coefficients and durations.  One wavefront per trajectory; every lane reads the
+// coefficients of its piece straight into the SAMPLE layout and the first lane of each piece writes the
+// piece's partials.  fp32: <= 128 VGPRs, so four waves per SIMD -- the whole cfg2 batch is resident at once and
+// the gathers of different trajectories overlap (one sample per lane in flight is enough then).
+#ifndef NEO_SAMPLE_U
+#define NEO_SAMPLE_U 1
+#endif
 template <int D, typename Real, class MapT, class LookupT>
-__global__ __launch_bounds__(kWave, 3) void sample_kernel(int B, int M, DevParams prm, MapT map,
-                                                           const double *__restrict__ coeffs,
-                                                           const double *__restrict__ ts,
-                                                           double *__restrict__ costs2, double *__restrict__ grad_C,
-                                                           double *__restrict__ grad_T) {
+__global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? 4 : 2) void sample_kernel(int B, int M, DevParams prm, MapT map,
+                                                                                  const double *__restrict__ coeffs,
+                                                                                  const double *__restrict__ ts,
+                                                                                  double *__restrict__ costs2,
+                                                                                  double *__restrict__ grad_C,
+                                                                                  double *__restrict__ grad_T) {
   const int b = blockIdx.x;
   if (b >= B) return;
   const int lane = lane_id();
   int L = kWave / M;
   L = L < 1 ? 1 : L;
-  const bool act = lane < M;
-  const double T = act ? ts[(size_t)b * M + lane] : 1.0;
+  const int piece = (lane * ((65536 + L - 1) / L)) >> 16;
+  const int r = lane - piece * L;
+  const bool act = piece < M;
+  const double T = act ? ts[(size_t)b * M + piece] : 1.0;
   const int ns = act ? (int)(T / prm.delta_t) : 0;
   Real c[6][D], gC[6][D], gT;
+  {
+    // the 6*D doubles of a piece are contiguous and 16-byte aligned (6*D is even)
+    const double2 *src = reinterpret_cast<const double2 *>(coeffs + ((size_t)b * 6 * M + 6 * (act ? piece : 0)) * D);
 #pragma unroll
-  for (int k = 0; k < 6; ++k)
-#pragma unroll
-    for (int d = 0; d < D; ++d) c[k][d] = act ? (Real)coeffs[((size_t)b * 6 * M + 6 * lane + k) * D + d] : Real(0);
+    for (int q = 0; q < 3 * D; ++q) {
+      const double2 v = src[q];
+      const int e0 = 2 * q, e1 = 2 * q + 1;
+      c[e0 / D][e0 % D] = act ? (Real)v.x : Real(0);
+      c[e1 / D][e1 % D] = act ? (Real)v.y : Real(0);
+    }
+  }
   double cf, ck;
   LookupT lk(map);
-  minco_sample<Real, D, LookupT, 2>(M, L, ns, c, prm, lk, gC, gT, cf, ck);
-  if (act) {
+  minco_sample<Real, D, LookupT, NEO_SAMPLE_U, true>(M, L, ns, c, prm, lk, gC, gT, cf, ck);
+  if (act && r == 0) {
+    double2 *dst = reinterpret_cast<double2 *>(grad_C + ((size_t)b * 6 * M + 6 * piece) * D);
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
-#pragma unroll
-      for (int d = 0; d < D; ++d) grad_C[((size_t)b * 6 * M + 6 * lane + k) * D + d] = (double)gC[k][d];
-    grad_T[(size_t)b * M + lane] = (double)gT;
+    for (int q = 0; q < 3 * D; ++q) {
+      const int e0 = 2 * q, e1 = 2 * q + 1;
+      dst[q] = make_double2((double)gC[e0 / D][e0 % D], (double)gC[e1 / D][e1 % D]);
+    }
+    grad_T[(size_t)b * M + piece] = (double)gT;
   }
   if (lane == 0) {
     costs2[(size_t)b * 2 + 0] = cf;
@@ -1372,6 +1422,8 @@ int neo_sampled_terms_batch_dev(neo_ctx *c, int scene_id, int B, int M, int D, c
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
   if (!coeffs || !ts || !costs2 || !grad_C || !grad_T) return fail(c, NEO_ERR_INVALID, "null buffer");
+  if (((uintptr_t)coeffs | (uintptr_t)grad_C) & 15)
+    return fail(c, NEO_ERR_INVALID, "coeffs and grad_C must be 16-byte aligned");
   std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   auto it = c->maps.find(scene_id);

@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libneo_planner_hip.so")
+# NEO_PLANNER_LIB: another build of the same library (kernel experiments in tools/)
+LIB_PATH = os.environ.get("NEO_PLANNER_LIB") or os.path.join(PKG, "libneo_planner_hip.so")
 
 NEO_OK = 0
 NEO_F64, NEO_F32, NEO_F16 = 0, 1, 2

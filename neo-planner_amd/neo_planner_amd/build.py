@@ -26,8 +26,10 @@ def build(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libneo_planner_hip.so")
+    # NEO_BUILD_DEFS="-DNEO_STAMPS ..." : experiment builds only (tools/); the product is built without
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-I", INCLUDE] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+           "-I", INCLUDE] + os.environ.get("NEO_BUILD_DEFS", "").split() + \
+          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
