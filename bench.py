@@ -11,7 +11,10 @@ intermediate waypoints (M = 21 pieces, D = 3, n = 81 variables).  One step = one
 path over the batch: every trajectory is optimised from its initial guess to L-BFGS-B termination
 (neo_optimize_batch_dev, one kernel launch), inputs already in HBM.  With N > 1 every rank owns its
 own scene and batch (weak scaling, no data-path collective); the per-rank results are gathered with
-one RCCL all_gather inside the timed region.
+one RCCL all_gather inside the timed region.  Consecutive steps are issued on `--streams` (default 3) HIP
+streams with separate state and result buffers: the end of a launch is a handful of long runs on an
+otherwise idle chip, and the next batch fills it.  Every step is still one full batch optimised to
+termination; `--streams 1` gives the one-batch-at-a-time figure.
 
 Printed JSON (one line, rank 0): the driver contract plus
   roofline     dominant kernel = optimize_kernel; achieved = algorithmic bytes per launch
@@ -30,6 +33,9 @@ import time
 os.environ.setdefault("OMP_NUM_THREADS", "1")
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# HIP maps streams onto 4 hardware queues by default; the batches' streams plus RCCL's own then share queues
+# and serialise (measured: 359 k instead of 413 k traj/s with the gather on).  Must be set before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -70,6 +76,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-order", action="store_true", help="dispatch trajectories in index order")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="batches kept in flight per GPU (HIP streams): the tail of a launch -- a few long runs on an "
+                         "otherwise idle chip -- overlaps with the next batch")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="BASELINE.json configs[1..4]; cfg2 is the headline (default).  cfg3: 65536 trajectories, M=3, "
                          "warm-started by the initializer net; cfg4: --scenes scenes x 4096 per GPU; cfg5: 40 waypoints, "
@@ -130,6 +139,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         a.gpus = world
+    # NEO_BENCH_FORCE_DIST=1: run the process-group path (RCCL gather on the batches' streams) even with one rank
+    use_dist = world > 1 or bool(os.environ.get("NEO_BENCH_FORCE_DIST"))
     store = "f32"
     n_scenes = 1
     if a.config == "cfg3":
@@ -170,8 +181,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if a.dist_backend == "nccl":
             dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -182,7 +195,8 @@ def main():
     torch.cuda.set_stream(tstream)
     assert tstream.cuda_stream != 0
     ctx = npa.Context(local_rank, stream=tstream.cuda_stream)
-    bp = npa.BatchPlanner(ctx=ctx, sample_dtype=a.dtype)
+    # several batches in flight -> the throughput variant of the optimiser kernel (two wavefronts per SIMD)
+    bp = npa.BatchPlanner(ctx=ctx, sample_dtype=a.dtype, waves_per_simd=2 if a.streams > 1 else None)
     bp._sync()
     g3 = npa.ESDF3D.from_occupancy(torch.from_numpy(occ).to(dev), res, synth.DOMAIN_ORIGIN, store=store, layout=a.layout,
                                    ctx=ctx, want_dist=dist_host is not None)
@@ -218,12 +232,6 @@ def main():
     x0 = torch.from_numpy(bp.pack_x(wp, ts)).to(dev)
     d_head = torch.from_numpy(head).to(dev)
     d_tail = torch.from_numpy(tail).to(dev)
-    x = torch.empty_like(x0)
-    costs = torch.zeros(B, 4, dtype=torch.float64, device=dev)
-    last = torch.zeros_like(costs)
-    nit = torch.zeros(B, dtype=torch.int32, device=dev)
-    nfev = torch.zeros_like(nit)
-    status = torch.zeros_like(nit)
     nsamp = torch.zeros(B, dtype=torch.int64, device=dev)
     ctx.check(ctx.lib.neo_optimize_sample_counter(ctx.h, ctypes.c_void_p(nsamp.data_ptr())))
     order = None
@@ -231,51 +239,76 @@ def main():
         order = torch.from_numpy(bp.expected_effort_order(head, tail, ts)).to(dev)
         ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, ctypes.c_void_p(order.data_ptr()), B))
     from neo_planner_amd import sharding
-    gathered = torch.empty(world * B, n + 5, dtype=torch.float32, device=dev) if world > 1 else None
     w = torch.tensor(bp.cfg.weights, dtype=torch.float64, device=dev)
+    # `--streams` batches in flight: each has its own stream and its own state / result buffers; the scene,
+    # the requests and the dispatch order are shared (read-only)
+    n_lanes = max(1, a.streams)
+    lanes = []
+    for li in range(n_lanes):
+        st_ = tstream if li == 0 else torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st_):
+            lanes.append(dict(
+                st=st_, x0=x0 if (li == 0 or init is None) else x0.clone(), x=torch.empty_like(x0),
+                costs=torch.zeros(B, 4, dtype=torch.float64, device=dev), last=torch.zeros(B, 4, dtype=torch.float64, device=dev),
+                nit=torch.zeros(B, dtype=torch.int32, device=dev), nfev=torch.zeros(B, dtype=torch.int32, device=dev),
+                status=torch.zeros(B, dtype=torch.int32, device=dev),
+                gathered=torch.empty(world * B, n + 5, dtype=torch.float32, device=dev) if use_dist else None))
+    x, costs, last, nit, nfev, status = (lanes[0][k] for k in ("x", "costs", "last", "nit", "nfev", "status"))
 
-    def warm_start():
+    def warm_start(x0_):
         """network output -> x0: body-frame waypoints (a small correction on the straight line, the net
         being untrained) and durations clamped into (T_min, T_max), then tau = map_T2tau(ts)"""
         out = init.net.head(feat, d_motion).double()
         local = out[:, :6].reshape(B, 2, 3)
-        world = torch.einsum("bij,bwj->bwi", d_R, local) + d_p0[:, None, :]
-        wp_ = line + 0.05 * (world.transpose(1, 2) - d_p0[:, :, None])
+        world_ = torch.einsum("bij,bwj->bwi", d_R, local) + d_p0[:, None, :]
+        wp_ = line + 0.05 * (world_.transpose(1, 2) - d_p0[:, :, None])
         eps = 1e-3 * (T_hi - T_lo)
         ts_ = (2.5 + out[:, 6:]).clamp(T_lo + eps, T_hi - eps)
         tau_ = -torch.log((T_hi - T_lo) / (ts_ - T_lo) - 1.0)
-        x0[:, :D * (M - 1)] = wp_.reshape(B, -1)
-        x0[:, D * (M - 1):] = tau_
+        x0_[:, :D * (M - 1)] = wp_.reshape(B, -1)
+        x0_[:, D * (M - 1):] = tau_
 
-    def step():
-        if init is not None:
-            with torch.no_grad():
-                warm_start()
-        x.copy_(x0)
-        bp.optimize_dev(g3, x, d_head, d_tail, costs, last, nit, nfev, status, slots=slots)
-        if world > 1:
-            # results to every rank: final x, total cost, 4 cost terms (SURVEY.md 8.e1)
-            sharding.gather_results(sharding.pack_results(x, costs, w), world, out=gathered)
+    def step(k):
+        ln = lanes[k % n_lanes]
+        ctx.set_stream(ln["st"].cuda_stream)
+        with torch.cuda.stream(ln["st"]):
+            if init is not None:
+                with torch.no_grad():
+                    warm_start(ln["x0"])
+            ln["x"].copy_(ln["x0"])
+            bp.optimize_dev(g3, ln["x"], d_head, d_tail, ln["costs"], ln["last"], ln["nit"], ln["nfev"], ln["status"],
+                            slots=slots)
+            if use_dist:
+                # results to every rank: final x, total cost, 4 cost terms (SURVEY.md 8.e1).  The gather runs
+                # behind the batch on the process group's own stream; this batch's stream does not wait for it
+                # (the fence at the end of the timed region does), only the lane's next use of its buffers does.
+                if ln.get("work") is not None:
+                    ln["work"].wait()
+                ln["packed"] = sharding.pack_results(ln["x"], ln["costs"], w)
+                _, ln["work"] = sharding.gather_results(ln["packed"], world, out=ln["gathered"], force=use_dist,
+                                                        async_op=True)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist_.barrier()
         torch.cuda.synchronize()
 
     t_gpu0 = time.time()
-    for _ in range(a.warmup):
-        step()
+    fence()
+    for k in range(a.warmup):
+        step(k)
     fence()
     ctx.check(ctx.lib.neo_profile_reset(ctx.h))
     ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    for k in range(a.steps):
+        step(k)
     fence()
     elapsed = time.perf_counter() - t0
     ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
-    if world > 1:
+    ctx.set_stream(None)
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist_.all_reduce(tmax, op=dist_.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -344,10 +377,17 @@ def main():
                                    + ("; x0 from the initializer net (random weights) each step" if init is not None else ""),
                        "batch_per_gpu": B, "pieces": M, "dims": D, "esdf_voxels": a.grid ** 3,
                        "sampling_arithmetic": a.dtype, "solve_and_optimiser_arithmetic": "f64",
-                       "parallelism": f"scene-sharded x{world}"},
+                       "parallelism": f"scene-sharded x{world}",
+                       "batches_in_flight_per_gpu": n_lanes},
             "roofline": {"bound": "hbm", "kernel": "optimize_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kernel_ms, "launches": int(launches.value),
+                         # `achieved` follows the contract: bytes of one launch / its average duration (HIP events).
+                         # With several batches in flight the launches overlap and each one lasts longer than it
+                         # would alone; the chip-wide rate is all launches' bytes over the timed region:
+                         "concurrent_launches": n_lanes,
+                         "achieved_aggregate": bytes_launch * a.steps / elapsed / 1e9,
+                         "frac_aggregate": bytes_launch * a.steps / elapsed / 1e9 / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "evals_per_launch": int(nfev_h.sum()), "samples_per_launch": int(nsamp_h.sum())},
             "esdf_kernel": esdf,
@@ -382,8 +422,14 @@ def main():
                 bp64.optimize_dev(g3, x, d_head, d_tail, costs, last, nit, nfev, status)
                 torch.cuda.synchronize()
                 out["final_cost_delta_vs_cpu_f64_sampling"] = delta(last, nfev)
-        print(json.dumps(out))
-    if world > 1:
+        # RCCL prints a version banner through C stdio; push it out first so that the JSON is the last line
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist_.barrier()
         dist_.destroy_process_group()
 
 

@@ -96,8 +96,16 @@ typedef struct neo_params {
   int32_t maxfun;  /* 15000 */
   int32_t bugcompat_stale_T; /* 1 = reproduce expert_planner.py:528-533 */
   int32_t sample_dtype;      /* NEO_F64 | NEO_F32: arithmetic of the sampled cost terms */
-  int32_t reserved;
+  int32_t flags;             /* NEO_FLAG_* below; 0 = defaults */
 } neo_params;
+
+/* neo_params.flags.  The optimiser kernel exists in two register allocations with bit-identical results:
+ * one wavefront per SIMD (shortest evaluation; default below 8192 trajectories per call) and two per SIMD
+ * (slower evaluations, higher throughput once the trajectories queue for the SIMDs: large calls, or several
+ * calls in flight on several streams; 3-D fields with fp32 sampling and n <= 128 variables only). */
+#define NEO_FLAG_ONE_WAVE_PER_SIMD 32
+#define NEO_FLAG_TWO_WAVES_PER_SIMD 64
+/* bits 1..16 switch phases off for timing experiments (tools/): leave them 0 */
 
 /* ---- lifetime ------------------------------------------------------------- */
 int neo_abi_version(void);
@@ -110,6 +118,11 @@ const char *neo_last_error(neo_ctx *ctx);
 int neo_params_default(neo_params *p);
 int neo_params_set(neo_ctx *ctx, const neo_params *p);
 int neo_ctx_synchronize(neo_ctx *ctx);
+/* stream of the calls that follow (NULL = back to the stream the context was created with).  The `_dev`
+ * entry points are asynchronous and only read the context's maps, so a caller may keep several batches in
+ * flight on several streams of one context; ordering between the streams (and with map updates, which run on
+ * the stream current at the time) is the caller's business. */
+int neo_ctx_set_stream(neo_ctx *ctx, void *stream);
 
 /* ---- maps (map_server/esdf.py) ------------------------------------------- */
 /* replaces ESDF.esdf_map / esdf_grad_x / esdf_grad_y (esdf.py:29-33) as looked up by

@@ -36,7 +36,7 @@ struct DevParams {
   double coll_tol;
   double ftol, gtol;
   int maxls, maxiter, maxfun, stale_T;
-  int dbg;  // timing experiments only (neo_params.reserved): 1 skip sample loop, 2 skip joint sweeps, 4 no history
+  int dbg;  // timing experiments only (neo_params.flags): 1 skip sample loop, 2 skip joint sweeps, 4 no history
 };
 
 // 2-D reference map: one 32-byte record per cell {dist, grad_x, grad_y, 0}

@@ -25,9 +25,6 @@
 #ifndef NEO_FUSED_U
 #define NEO_FUSED_U (sizeof(Real) == 4 ? 4 : 2)
 #endif
-#ifndef NEO_OPT_WAVES
-#define NEO_OPT_WAVES 1
-#endif
 #include "neo_device.hpp"
 #include "neo_lbfgs.hpp"
 
@@ -272,8 +269,13 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
   }
 }
 
-template <int D, int NS, typename Real, class MapT, class LookupT>
-__global__ __launch_bounds__(kWave, NEO_OPT_WAVES) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
+// WAVES = wavefronts per SIMD the register allocation aims at.  1: the whole file (256 VGPRs + AGPRs) for one
+// trajectory -- the shortest evaluation, for batches that leave SIMDs to spare.  2: half the file, some state
+// spilled to scratch -- each evaluation is slower, but two trajectories share a SIMD's issue slots, which wins
+// once the batch queues for the 1024 SIMDs anyway (cfg2 with several batches in flight: +10 %).  Same
+// source, same arithmetic, bit-identical results.
+template <int D, int NS, typename Real, class MapT, class LookupT, int WAVES>
+__global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
                                                           const int *__restrict__ scene_slot,
                                                           double *__restrict__ x,
                                                           const double *__restrict__ head,
@@ -749,6 +751,7 @@ struct neo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t home_stream = nullptr;  // the stream of neo_ctx_create (neo_ctx_set_stream(NULL) returns to it)
   neo_params params{};
   DevParams dev{};
   std::map<int, MapEntry> maps;
@@ -803,7 +806,7 @@ void fill_dev_params(neo_ctx *c) {
   d.maxiter = p.maxiter;
   d.maxfun = p.maxfun;
   d.stale_T = p.bugcompat_stale_T;
-  d.dbg = p.reserved;
+  d.dbg = p.flags;
 }
 
 struct ProfScope {
@@ -940,6 +943,8 @@ int dispatch_eval(neo_ctx *c, const MapEntry &e, int D, const EvalArgs &a) {
 #undef NEO_3D
 }
 
+constexpr int kTwoWavesFromBatch = 8192;  // 8 trajectories per SIMD of an MI355X: clearly queueing
+
 struct OptArgs {
   int B, M;
   const void *table;
@@ -950,19 +955,21 @@ struct OptArgs {
   int *nit, *nfev, *status;
 };
 
-template <int D, typename Real, class MapT, class LookupT>
+template <int D, typename Real, class MapT, class LookupT, int WAVES = 1>
 int launch_opt(neo_ctx *c, const OptArgs &a) {
   const dim3 grid(a.B), blk(kWave);
   const size_t dyn = (size_t)2 * NEO_LBFGS_M * (D * (a.M - 1) + a.M) * sizeof(double);  // L-BFGS pairs in LDS
 #define NEO_OPT(NS)                                                                                           \
-  hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT>), grid, blk, dyn, c->stream, a.B, a.M, c->dev, \
+  hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES>), grid, blk, dyn, c->stream, a.B, a.M, c->dev, \
                      static_cast<const MapT *>(a.table), a.slots, a.x, a.head, a.tail, c->hist, a.costs4,      \
                      a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter,                                \
                      (c->order_B == a.B ? c->dispatch_order : nullptr))
   switch (slots_for(a.M, D)) {
     case 1: NEO_OPT(1); break;
     case 2: NEO_OPT(2); break;
-    default: NEO_OPT(4); break;
+    default:
+      if constexpr (WAVES == 1) NEO_OPT(4);  // (dispatch_opt never asks for two waves beyond n = 128)
+      break;
   }
 #undef NEO_OPT
   return NEO_OK;
@@ -976,16 +983,27 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
     return f32 ? launch_opt<3, float, Map2D, Lookup2D<float>>(c, a) : launch_opt<3, double, Map2D, Lookup2D<double>>(c, a);
   }
   if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
+  // two trajectories per SIMD for calls that queue for the SIMDs anyway (3-D fields, fp32 sampling, the
+  // linear and cell-packed layouts, n <= 128: beyond that the spills cost more than the sharing gains)
+  const int fl = c->params.flags;
+  const bool two = f32 && layout != 1 && slots_for(a.M, D) <= 2 &&
+                   ((a.B >= kTwoWavesFromBatch && !(fl & NEO_FLAG_ONE_WAVE_PER_SIMD)) || (fl & NEO_FLAG_TWO_WAVES_PER_SIMD));
 #define NEO_3D(LAY)                                                                       \
   if (elem == NEO_F32)                                                                    \
     return f32 ? launch_opt<3, float, Map3D, Lookup3D<float, float, LAY>>(c, a)           \
                : launch_opt<3, double, Map3D, Lookup3D<double, float, LAY>>(c, a);        \
   return f32 ? launch_opt<3, float, Map3D, Lookup3D<float, __half, LAY>>(c, a)            \
              : launch_opt<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, a);
+#define NEO_3D2(LAY)                                                                      \
+  if (elem == NEO_F32) return launch_opt<3, float, Map3D, Lookup3D<float, float, LAY>, 2>(c, a); \
+  return launch_opt<3, float, Map3D, Lookup3D<float, __half, LAY>, 2>(c, a);
+  if (two && layout == 0) { NEO_3D2(0) }
+  if (two && layout == 2) { NEO_3D2(2) }
   if (layout == 0) { NEO_3D(0) }
   if (layout == 2) { NEO_3D(2) }
   NEO_3D(1)
 #undef NEO_3D
+#undef NEO_3D2
 }
 
 struct SampleArgs {
@@ -1092,9 +1110,17 @@ int neo_ctx_create(int device_id, void *stream, neo_ctx **out) {
     }
     c->own_stream = true;
   }
+  c->home_stream = c->stream;
   neo_params_default(&c->params);
   fill_dev_params(c);
   *out = c;
+  return NEO_OK;
+}
+
+int neo_ctx_set_stream(neo_ctx *c, void *stream) {
+  if (!c) return NEO_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> g(c->mu);
+  c->stream = stream ? static_cast<hipStream_t>(stream) : c->home_stream;
   return NEO_OK;
 }
 
@@ -1102,6 +1128,7 @@ int neo_ctx_destroy(neo_ctx *c) {
   if (!c) return NEO_ERR_INVALID;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  if (c->stream != c->home_stream) hipStreamSynchronize(c->home_stream);
   drain_profile(c);
   for (auto &kv : c->maps)
     if (kv.second.data) hipFree(kv.second.data);
@@ -1110,7 +1137,7 @@ int neo_ctx_destroy(neo_ctx *c) {
   if (c->table2d) hipFree(c->table2d);
   if (c->table3d) hipFree(c->table3d);
   if (c->scratch) hipFree(c->scratch);
-  if (c->own_stream) hipStreamDestroy(c->stream);
+  if (c->own_stream) hipStreamDestroy(c->home_stream);
   delete c;
   return NEO_OK;
 }

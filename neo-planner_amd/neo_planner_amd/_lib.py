@@ -15,6 +15,7 @@ NEO_TRAJ_CONVERGED_GRAD, NEO_TRAJ_CONVERGED_F, NEO_TRAJ_ABNORMAL = 0, 1, 2
 NEO_TRAJ_MAXITER, NEO_TRAJ_NUMERIC_RANGE, NEO_TRAJ_NONFINITE = 3, 4, 5
 NEO_TRAJ_FLAG_COLLISION = 0x100
 NEO_KERNEL_EVAL, NEO_KERNEL_OPTIMIZE, NEO_KERNEL_ESDF_BUILD, NEO_KERNEL_ESDF_SAMPLE = 0, 1, 2, 3
+NEO_FLAG_ONE_WAVE_PER_SIMD, NEO_FLAG_TWO_WAVES_PER_SIMD = 32, 64
 
 # every symbol include/neo_planner.h declares (tests check the library exports them all)
 EXPORTS = [
@@ -25,7 +26,7 @@ EXPORTS = [
     "neo_optimize_workspace_bytes", "neo_eval_traj_batch", "neo_profile_enable", "neo_profile_read",
     "neo_profile_reset", "neo_optimize_sample_counter", "neo_optimize_dispatch_order",
     "neo_sampled_terms_batch", "neo_sampled_terms_batch_dev", "neo_esdf_build_3d",
-    "neo_optimize_dispatch_order_host",
+    "neo_optimize_dispatch_order_host", "neo_ctx_set_stream",
 ]
 
 
@@ -35,7 +36,7 @@ class NeoParams(ctypes.Structure):
                 ("collision_cost_tol", ctypes.c_double), ("ftol", ctypes.c_double), ("gtol", ctypes.c_double),
                 ("maxls", ctypes.c_int32), ("maxiter", ctypes.c_int32), ("maxfun", ctypes.c_int32),
                 ("bugcompat_stale_T", ctypes.c_int32), ("sample_dtype", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("flags", ctypes.c_int32)]
 
 
 _lib = None
@@ -63,6 +64,7 @@ def load():
     L.neo_params_default.argtypes = [ctypes.POINTER(NeoParams)]
     L.neo_params_set.argtypes = [c_p, ctypes.POINTER(NeoParams)]
     L.neo_ctx_synchronize.argtypes = [c_p]
+    L.neo_ctx_set_stream.argtypes = [c_p, c_p]
     L.neo_esdf_upload_2d.argtypes = [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_d]
     L.neo_esdf_build_2d.argtypes = [c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_d, c_p, c_p, c_p]
     L.neo_esdf_upload_3d.argtypes = [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_d, c_p, c_i, c_i]
@@ -139,6 +141,10 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.neo_ctx_synchronize(self.h))
+
+    def set_stream(self, stream=None):
+        """HIP stream handle for the calls that follow (None: the stream the context was created with)"""
+        self.check(self.lib.neo_ctx_set_stream(self.h, ctypes.c_void_p(stream) if stream else None))
 
     def close(self):
         if self.h:

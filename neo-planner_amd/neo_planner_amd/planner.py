@@ -45,12 +45,12 @@ class PlannerConfig:
             setattr(self, k, v)
 
 
-def _push_params(ctx, p, sample_dtype, stale_T=True):
+def _push_params(ctx, p, sample_dtype, stale_T=True, flags=0):
     ctx.set_params(v_max=float(p.v_max), T_min=float(p.T_min), T_max=float(p.T_max), safe_dis=float(p.safe_dis),
                    delta_t=float(p.delta_t), weights=[float(w) for w in p.weights],
                    collision_cost_tol=float(p.collision_cost_tol), ftol=1e-4, gtol=1e-4, maxls=20,
                    maxiter=15000, maxfun=15000, bugcompat_stale_T=int(bool(stale_T)),
-                   sample_dtype={"f64": _lib.NEO_F64, "f32": _lib.NEO_F32}[sample_dtype])
+                   sample_dtype={"f64": _lib.NEO_F64, "f32": _lib.NEO_F32}[sample_dtype], flags=int(flags))
 
 
 def _map_scene(ctx, map, cache):
@@ -384,11 +384,14 @@ class BatchPlanner:
     """B independent replans per call (host arrays in, host arrays out).  For device-resident
     buffers use `optimize_dev` with torch tensors."""
 
-    def __init__(self, config=None, ctx=None, sample_dtype="f64", stale_T=True):
+    def __init__(self, config=None, ctx=None, sample_dtype="f64", stale_T=True, waves_per_simd=None):
+        """waves_per_simd: None (the library decides by batch size), 1 (shortest evaluations) or 2 (highest
+        throughput when several batches are in flight) -- include/neo_planner.h NEO_FLAG_*; same results"""
         self.cfg = config if config is not None else PlannerConfig()
         self._ctx = ctx
         self.sample_dtype = sample_dtype
         self.stale_T = stale_T
+        self.flags = {None: 0, 1: _lib.NEO_FLAG_ONE_WAVE_PER_SIMD, 2: _lib.NEO_FLAG_TWO_WAVES_PER_SIMD}[waves_per_simd]
 
     @property
     def ctx(self):
@@ -397,7 +400,7 @@ class BatchPlanner:
         return self._ctx
 
     def _sync(self):
-        _push_params(self.ctx, self.cfg, self.sample_dtype, self.stale_T)
+        _push_params(self.ctx, self.cfg, self.sample_dtype, self.stale_T, self.flags)
 
     def pack_x(self, int_wpts, ts):
         """int_wpts (B, D, M-1), ts (B, M) -> x (B, n) with tau = map_T2tau(ts) (:468-475)"""

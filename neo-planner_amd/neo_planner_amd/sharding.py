@@ -27,14 +27,17 @@ def pack_results(x, costs, weights):
     return out
 
 
-def gather_results(local, world, out=None):
-    """all ranks end up with the rows of every rank, rank-major.  Equal B_local on every rank."""
-    if world == 1:
-        return local
+def gather_results(local, world, out=None, force=False, async_op=False):
+    """all ranks end up with the rows of every rank, rank-major.  Equal B_local on every rank.
+    `force`: run the collective even in a one-rank group (exercises the process-group path).
+    `async_op`: do not make the caller's stream wait for the collective; returns (out, work) and the caller
+    calls work.wait() (or synchronises the device) before it reads `out` or frees `local`."""
+    if world == 1 and not force:
+        return (local, None) if async_op else local
     if out is None:
         out = torch.empty(world * local.shape[0], local.shape[1], dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous())
-    return out
+    work = dist.all_gather_into_tensor(out, local.contiguous(), async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def scene_major_order(gathered, n_scenes, world, rows_per_scene):

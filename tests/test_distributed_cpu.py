@@ -37,6 +37,10 @@ def _worker(rank, world, port, n_scenes, rows, n, q):
     mine = sharding.owned_scenes(n_scenes, rank, world)
     local = torch.cat([sharding.pack_results(*_fake_results(s, rows, n), w) for s in mine])
     allr = sharding.gather_results(local, world)
+    # the asynchronous form bench.py uses (several batches in flight): same rows once the work is waited for
+    allr2, work = sharding.gather_results(local, world, async_op=True)
+    work.wait()
+    assert torch.equal(allr, allr2)
     ordered = sharding.scene_major_order(allr, n_scenes, world, rows)
     dist.barrier()
     q.put((rank, mine, ordered.numpy()))
@@ -76,3 +80,4 @@ def test_pack_results_layout():
     assert torch.allclose(r[:, 3], torch.tensor([40006.0, 10.5]))
     assert torch.equal(r[:, 4:], costs.float())
     assert sharding.gather_results(r, 1) is r
+    assert sharding.gather_results(r, 1, async_op=True) == (r, None) or sharding.gather_results(r, 1, async_op=True)[0] is r

@@ -218,3 +218,55 @@ def test_single_time_evaluators(scene):
         assert np.allclose(pl.get_acc(t), ref.get_acc(t), rtol=1e-8, atol=1e-10)
         assert np.allclose(pl.get_jerk(t), ref.get_jerk(t), rtol=1e-8, atol=1e-9)
     assert pl.get_jer_array().shape == (len(np.arange(0, sum(pl.ts), 0.1)), 2)
+
+
+def test_two_batches_in_flight_on_two_streams(scene):
+    """neo_ctx_set_stream: the same batch issued on two streams of one context (both in flight) gives the
+    results of the one-at-a-time run bit for bit"""
+    import ctypes
+    import torch
+    _, m, _ = scene
+    ctx = m.ctx
+    B, M = 256, 5
+    head, tail, wp, ts = synth.replan_requests(5, B, M - 1, D=2, length_range=(6.0, 12.0), jitter=0.3)
+    bp = npa.BatchPlanner(ctx=ctx)
+    ref = bp.optimize(m, bp.pack_x(wp, ts), head, tail, order=False)
+    dev = torch.device("cuda", 0)
+    x0 = torch.from_numpy(bp.pack_x(wp, ts)).to(dev)
+    h, tl = torch.from_numpy(head).to(dev), torch.from_numpy(tail).to(dev)
+    torch.cuda.synchronize()
+    outs = []
+    try:
+        for _ in range(2):
+            st = torch.cuda.Stream(device=dev)
+            ctx.set_stream(st.cuda_stream)
+            with torch.cuda.stream(st):
+                o = dict(x=x0.clone(), costs=torch.zeros(B, 4, dtype=torch.float64, device=dev),
+                         last=torch.zeros(B, 4, dtype=torch.float64, device=dev),
+                         nit=torch.zeros(B, dtype=torch.int32, device=dev), nfev=torch.zeros(B, dtype=torch.int32, device=dev),
+                         status=torch.zeros(B, dtype=torch.int32, device=dev), st=st)
+                bp.optimize_dev(m, o["x"], h, tl, o["costs"], o["last"], o["nit"], o["nfev"], o["status"])
+            outs.append(o)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_stream(None)
+    for o in outs:
+        assert np.array_equal(o["x"].cpu().numpy(), ref["x"])
+        assert np.array_equal(o["nfev"].cpu().numpy(), ref["nfev"])
+        assert np.array_equal(o["costs"].cpu().numpy(), ref["costs"])
+
+
+def test_one_and_two_waves_per_simd_agree_bit_for_bit():
+    """NEO_FLAG_ONE_WAVE_PER_SIMD / NEO_FLAG_TWO_WAVES_PER_SIMD select two register allocations of the same
+    optimiser kernel: every output must be identical"""
+    dist = synth.esdf_3d(2, n=100, res=0.3)
+    g3 = npa.ESDF3D(dist, 0.3, synth.DOMAIN_ORIGIN, store="f32")
+    for M, B in ((5, 300), (21, 200)):
+        head, tail, wp, ts = synth.replan_requests(2, B, M - 1, D=3)
+        out = []
+        for waves in (1, 2):
+            bp = npa.BatchPlanner(sample_dtype="f32", waves_per_simd=waves)
+            out.append(bp.optimize(g3, bp.pack_x(wp, ts), head, tail))
+        for k in ("x", "costs", "costs_last", "nit", "nfev", "status"):
+            assert np.array_equal(out[0][k], out[1][k]), (M, k)
+        assert out[0]["nfev"].mean() > 10

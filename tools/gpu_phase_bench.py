@@ -26,7 +26,7 @@ for dtype in ("f32", "f64"):
     g = torch.zeros(B, n, dtype=torch.float64, device=dev); stt = torch.zeros(B, dtype=torch.int32, device=dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     for dbg, name in ((0, "full"), (1, "no sample loop"), (2, "no joint sweeps"), (3, "neither")):
-        bp._sync(); ctx.set_params(reserved=dbg)
+        bp._sync(); ctx.set_params(flags=dbg)
         def run():
             ctx.check(ctx.lib.neo_cost_grad_batch_dev(ctx.h, g3.scene_id, B, M, D, p(x), p(h), p(tl), p(cost), p(c4), p(g), None, p(stt)))
         for _ in range(3): run()
@@ -35,10 +35,10 @@ for dtype in ("f32", "f64"):
         for _ in range(R): run()
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / R
         print(f"{dtype} eval_kernel {name:18s}: {dt*1e6:8.1f} us per launch of {B} evaluations  ({dt/B*1e9:.1f} ns/eval)")
-    ctx.set_params(reserved=0)
+    ctx.set_params(flags=0)
 
 print("--- latency / scaling of eval_kernel and optimize_kernel with batch size (f32)")
-bp = npa.BatchPlanner(ctx=ctx, sample_dtype="f32"); bp._sync(); ctx.set_params(reserved=0)
+bp = npa.BatchPlanner(ctx=ctx, sample_dtype="f32"); bp._sync(); ctx.set_params(flags=0)
 for Bs in (1, 64, 256, 1024, 2048, 4096):
     def run():
         ctx.check(ctx.lib.neo_cost_grad_batch_dev(ctx.h, g3.scene_id, Bs, M, D, p(x), p(h), p(tl), p(cost), p(c4), p(g), None, p(stt)))
@@ -65,7 +65,7 @@ for Bs in (1, 64, 1024, 4096):
 
 print("--- single-wave latency split (B=1, f32)")
 for dbg, name in ((0, "full"), (1, "no sample loop"), (2, "no joint sweeps"), (8, "no factor sweep"), (16, "no scans"), (3, "neither")):
-    bp._sync(); ctx.set_params(reserved=dbg)
+    bp._sync(); ctx.set_params(flags=dbg)
     def run():
         ctx.check(ctx.lib.neo_cost_grad_batch_dev(ctx.h, g3.scene_id, 1, M, D, p(x0), p(h), p(tl), p(cost), p(c4), p(g), None, p(stt)))
     for _ in range(3): run()
@@ -74,4 +74,4 @@ for dbg, name in ((0, "full"), (1, "no sample loop"), (2, "no joint sweeps"), (8
     for _ in range(R): run()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / R
     print(f"B=1 eval_kernel {name:18s}: {dt*1e6:8.1f} us")
-ctx.set_params(reserved=0)
+ctx.set_params(flags=0)

@@ -120,9 +120,9 @@ def main():
                                      pp(d_co), pp(d_ts), pp(c2), pp(gC), pp(gT), 50)
                     print(f"        ({what}: {us:7.2f} us)")
         print(f"   production sample_kernel again {production():6.2f} us")
-        ctx.set_params(reserved=1)
+        ctx.set_params(flags=1)
         print(f"        (no sample loop: {production():6.2f} us)")
-        ctx.set_params(reserved=0)
+        ctx.set_params(flags=0)
 
 
 if __name__ == "__main__":
