@@ -277,6 +277,7 @@ struct Lookup3D {
   // idle lane, i.e. one cache line per wavefront instead of 64 scattered gathers
   template <int D>
   __device__ __forceinline__ Addr prepare(const Real (&pos)[D], bool on = true) const {
+#pragma clang fp contract(on)  // fuse a*b+c only as written: the same arithmetic whatever the unrolling around it
     static_assert(D == 3, "the 3-D map needs D = 3");
     const int n[3] = {m.nx, m.ny, m.nz};
     const double org[3] = {m.ox, m.oy, m.oz};
@@ -357,6 +358,7 @@ struct Lookup3D {
   }
   template <int D>
   __device__ __forceinline__ Real finish(const Addr &a, const Raw &q, Real (&g)[D]) const {
+#pragma clang fp contract(on)  // fuse a*b+c only as written: the same arithmetic whatever the unrolling around it
 #pragma unroll
     for (int d = 0; d < D; ++d) g[d] = Real(0);
     if (!a.inside) return Real(10000);
@@ -646,15 +648,17 @@ __device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, d
   return 0;
 }
 
-// position and velocity of a piece at local time s: two Horner chains (the compiler pairs them into packed
-// fp32 fma's; the pre-scaled coefficients k*c_k are hoisted into registers), or, LEAN, Horner on p and p'
-// together -- 9 dependent fma per axis but no extra registers, which is what lets the stand-alone fp32
-// kernel fit 128 VGPRs.
-template <typename Real, int D, bool LEAN>
+// position and velocity of a piece at local time s.  fp64 follows the reference's monomial sums.  fp32 runs
+// Horner on p and p' together: 9 dependent fma per axis, but no pre-scaled copies k*c_k of the coefficients in
+// registers -- that is what lets the stand-alone kernel fit 128 VGPRs and the two-waves optimiser variant spill a
+// third as much (2 % slower than two independent chains where registers are plentiful).  Every fp32 kernel uses
+// this one form, so the sampled terms of eval / optimize / sample kernels agree bit for bit.
+template <typename Real, int D>
 __device__ __forceinline__ void piece_pos_vel(const Real (&c)[6][D], Real s, Real (&pos)[D], Real (&vel)[D]) {
+#pragma clang fp contract(on)  // fuse a*b+c only as written: the same arithmetic whatever the unrolling around it
 #pragma unroll
   for (int d = 0; d < D; ++d) {
-    if constexpr (LEAN && sizeof(Real) == 4) {
+    if constexpr (sizeof(Real) == 4) {
       Real a = c[5][d], b = c[5][d];
       a = fmaf(a, s, c[4][d]); b = fmaf(b, s, a);
       a = fmaf(a, s, c[3][d]); b = fmaf(b, s, a);
@@ -702,6 +706,7 @@ template <typename Real, int D, class LookupT, int U, bool SAMPLE_IO = false>
 __device__ __forceinline__ void minco_sample(int M, int L, int ns_in, const Real (&cp)[6][D],
                                              const DevParams &prm, const LookupT &lk, Real (&gC)[6][D], Real &gT,
                                              double &cost_feas, double &cost_coll) {
+#pragma clang fp contract(on)  // fuse a*b+c only as written: the same arithmetic whatever the unrolling around it
   const int lane = lane_id();
   const int piece = (lane * ((65536 + L - 1) / L)) >> 16;  // lane / L for lane < 64
   const int r = lane - piece * L;
@@ -745,7 +750,7 @@ __device__ __forceinline__ void minco_sample(int M, int L, int ns_in, const Real
     // stand-alone kernel: lanes whose piece has run out of samples sit the round out (exec-masked)
     if constexpr (SAMPLE_IO)
       if (r + it0 * L >= ns) continue;
-    // LEAN: only the position is needed to issue the gathers; the velocity is evaluated while they fly
+    // only the position is needed to issue the gathers; the velocity is evaluated while they fly
     constexpr bool kVelLate = SAMPLE_IO && sizeof(Real) == 4;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -759,7 +764,7 @@ __device__ __forceinline__ void minco_sample(int M, int L, int ns_in, const Real
         for (int d = 0; d < D; ++d)
           pos[d] = fmaf(fmaf(fmaf(fmaf(fmaf(c[5][d], s, c[4][d]), s, c[3][d]), s, c[2][d]), s, c[1][d]), s, c[0][d]);
       } else {
-        piece_pos_vel<Real, D, SAMPLE_IO>(c, s, pos, vel[u]);
+        piece_pos_vel<Real, D>(c, s, pos, vel[u]);
       }
       ad[u] = lk.template prepare<D>(pos, on[u]);
     }
@@ -769,7 +774,7 @@ __device__ __forceinline__ void minco_sample(int M, int L, int ns_in, const Real
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         Real pos[D];
-        piece_pos_vel<Real, D, SAMPLE_IO>(c, sv[u], pos, vel[u]);
+        piece_pos_vel<Real, D>(c, sv[u], pos, vel[u]);
       }
     }
     // violations are rare: first only the two penalties' arguments for the U samples, one test for the

@@ -25,13 +25,17 @@
 #ifndef NEO_FUSED_U
 #define NEO_FUSED_U (sizeof(Real) == 4 ? 4 : 2)
 #endif
+#ifndef NEO_W2_U
+#define NEO_W2_U 2
+#endif
 #include "neo_device.hpp"
 #include "neo_lbfgs.hpp"
 
 namespace neo {
 
 // ------------------------------------------------------------------ device backend of the optimiser
-template <int D, int NS, typename Real, class MapT, class LookupT>
+// SU: samples per lane in flight in the sample loop (minco_sample)
+template <int D, int NS, typename Real, class MapT, class LookupT, int SU = NEO_FUSED_U>
 struct DevBackend {
   // FLAT layout with NS slots: n <= 64 * NS
   struct Vec {
@@ -170,7 +174,7 @@ struct DevBackend {
 #pragma unroll
         for (int d = 0; d < D; ++d) cr[k][d] = (Real)t.c[k][d];
       LookupT lk(map);
-      minco_sample<Real, D, LookupT, NEO_FUSED_U>(t.M, t.L, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
+      minco_sample<Real, D, LookupT, SU>(t.M, t.L, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
 #pragma unroll
       for (int k = 0; k < 6; ++k)
 #pragma unroll
@@ -295,7 +299,9 @@ __global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, De
   // workgroups are dispatched in index order: `order` lets the caller start the runs it expects to
   // be long first (list scheduling: a long run that starts last sets the duration of the launch)
   const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
-  using BE = DevBackend<D, NS, Real, MapT, LookupT>;
+  // the two-waves variant has half the registers: two samples per lane in flight instead of four (with the lean
+  // Horner form, cfg2 with three batches in flight: 414 k -> 541 k traj/s; scratch 640 -> 336 B per lane)
+  using BE = DevBackend<D, NS, Real, MapT, LookupT, (WAVES == 2 ? NEO_W2_U : NEO_FUSED_U)>;
   const MapT map = maps[scene_slot ? scene_slot[b] : 0];
   BE be(prm, map);
   be.xs = xs;
@@ -922,6 +928,11 @@ int launch_eval(neo_ctx *c, const MapT &map, const EvalArgs &a) {
 }
 
 int dispatch_eval(neo_ctx *c, const MapEntry &e, int D, const EvalArgs &a) {
+#ifdef NEO_SLIM_BUILD  // kernel experiments (tools/probe): only the cfg2 instantiation compiles, in 20 s
+  if (e.kind != 0 && D == 3 && e.elem == NEO_F32 && e.m3.layout == 0 && c->params.sample_dtype == NEO_F32)
+    return launch_eval<3, float, Map3D, Lookup3D<float, float, 0>>(c, e.m3, a);
+  return fail(c, NEO_ERR_INVALID, "slim build: cfg2 kernels only");
+#else
   const bool f32 = c->params.sample_dtype == NEO_F32;
   if (e.kind == 0) {
     if (D == 2)
@@ -941,6 +952,7 @@ int dispatch_eval(neo_ctx *c, const MapEntry &e, int D, const EvalArgs &a) {
   if (e.m3.layout == 2) { NEO_3D(2) }
   NEO_3D(1)
 #undef NEO_3D
+#endif
 }
 
 constexpr int kTwoWavesFromBatch = 8192;  // 8 trajectories per SIMD of an MI355X: clearly queueing
@@ -976,6 +988,14 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
 }
 
 int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArgs &a) {
+#ifdef NEO_SLIM_BUILD  // kernel experiments (tools/probe): only the cfg2 instantiation compiles, in 20 s
+  if (kind != 0 && D == 3 && elem == NEO_F32 && layout == 0 && c->params.sample_dtype == NEO_F32) {
+    const bool two2 = c->params.flags & NEO_FLAG_TWO_WAVES_PER_SIMD;
+    return two2 ? launch_opt<3, float, Map3D, Lookup3D<float, float, 0>, 2>(c, a)
+                : launch_opt<3, float, Map3D, Lookup3D<float, float, 0>>(c, a);
+  }
+  return fail(c, NEO_ERR_INVALID, "slim build: cfg2 kernels only");
+#else
   const bool f32 = c->params.sample_dtype == NEO_F32;
   if (kind == 0) {
     if (D == 2)
@@ -1004,6 +1024,7 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
   NEO_3D(1)
 #undef NEO_3D
 #undef NEO_3D2
+#endif
 }
 
 struct SampleArgs {
@@ -1020,6 +1041,11 @@ int launch_sample(neo_ctx *c, const MapT &map, const SampleArgs &a) {
 }
 
 int dispatch_sample(neo_ctx *c, const MapEntry &e, int D, const SampleArgs &a) {
+#ifdef NEO_SLIM_BUILD  // kernel experiments (tools/probe): only the cfg2 instantiation compiles, in 20 s
+  if (e.kind != 0 && D == 3 && e.elem == NEO_F32 && e.m3.layout == 0 && c->params.sample_dtype == NEO_F32)
+    return launch_sample<3, float, Map3D, Lookup3D<float, float, 0>>(c, e.m3, a);
+  return fail(c, NEO_ERR_INVALID, "slim build: cfg2 kernels only");
+#else
   const bool f32 = c->params.sample_dtype == NEO_F32;
   if (e.kind == 0) {
     if (D == 2)
@@ -1039,6 +1065,7 @@ int dispatch_sample(neo_ctx *c, const MapEntry &e, int D, const SampleArgs &a) {
   if (e.m3.layout == 2) { NEO_3D(2) }
   NEO_3D(1)
 #undef NEO_3D
+#endif
 }
 
 size_t hist_bytes_for(int, int, int) {
