@@ -100,7 +100,7 @@ typedef struct neo_params {
 } neo_params;
 
 /* neo_params.flags.  The optimiser kernel exists in two register allocations with bit-identical results:
- * one wavefront per SIMD (shortest evaluation; default below 8192 trajectories per call) and two per SIMD
+ * one wavefront per SIMD (shortest evaluation; default below 4096 trajectories per call) and two per SIMD
  * (slower evaluations, higher throughput once the trajectories queue for the SIMDs: large calls, or several
  * calls in flight on several streams; 3-D fields with fp32 sampling and n <= 128 variables only). */
 #define NEO_FLAG_ONE_WAVE_PER_SIMD 32

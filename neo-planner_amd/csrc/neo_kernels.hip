@@ -955,7 +955,8 @@ int dispatch_eval(neo_ctx *c, const MapEntry &e, int D, const EvalArgs &a) {
 #endif
 }
 
-constexpr int kTwoWavesFromBatch = 8192;  // 8 trajectories per SIMD of an MI355X: clearly queueing
+constexpr int kTwoWavesFromBatch = 4096;  // 4 trajectories per SIMD of an MI355X (measured: 2048 -> one wave is
+                                          // faster, 9.1 vs 10.1 ms; 4096 -> two are, 11.0 vs 13.6 ms)
 
 struct OptArgs {
   int B, M;
