@@ -94,3 +94,13 @@ def test_synthetic_forest_is_deterministic_and_clear():
             assert not (abs(cx - bx) < (sx + bsx) / 2 + 1.8 and abs(cy - by) < (sy + bsy) / 2 + 1.8)
     occ = synth.occupancy_2d(4)
     assert occ.shape == (300, 300) and set(np.unique(occ)) <= {0, 100}
+
+
+def test_flag_constants_match_the_header():
+    """NEO_FLAG_* in include/neo_planner.h and in the ctypes binding"""
+    import re
+    hdr = open(os.path.join(REPO, "include", "neo_planner.h")).read()
+    defs = dict(re.findall(r"#define\s+(NEO_FLAG_\w+)\s+(\d+)", hdr))
+    assert int(defs["NEO_FLAG_ONE_WAVE_PER_SIMD"]) == _lib.NEO_FLAG_ONE_WAVE_PER_SIMD
+    assert int(defs["NEO_FLAG_TWO_WAVES_PER_SIMD"]) == _lib.NEO_FLAG_TWO_WAVES_PER_SIMD
+    assert [f for f, _ in _lib.NeoParams._fields_][-1] == "flags"
