@@ -284,7 +284,6 @@ __global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, De
                                                           double *__restrict__ x,
                                                           const double *__restrict__ head,
                                                           const double *__restrict__ tail,
-                                                          double *__restrict__ hist_ws,
                                                           double *__restrict__ costs4,
                                                           double *__restrict__ costs4_last,
                                                           int *__restrict__ nit, int *__restrict__ nfev,
@@ -315,7 +314,6 @@ __global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, De
   be.npad = NS * kWave;
   extern __shared__ double dyn_lds[];  // 2 * maxcor * n doubles (launch parameter)
   be.hist = dyn_lds;
-  (void)hist_ws;
   const int lane = lane_id();
   typename BE::Vec xv;
 #pragma unroll
@@ -763,9 +761,6 @@ struct neo_ctx {
   std::map<int, MapEntry> maps;
   std::string err;
   std::recursive_mutex mu;  // recursive: the host-pointer entry points hold it across their *_dev call
-  // optimiser workspace
-  double *hist = nullptr;
-  size_t hist_bytes = 0;
   // device-side table of maps (rebuilt when a map changes)
   void *table2d = nullptr, *table3d = nullptr;
   int n2d = 0, n3d = 0;
@@ -974,7 +969,7 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
   const size_t dyn = (size_t)2 * NEO_LBFGS_M * (D * (a.M - 1) + a.M) * sizeof(double);  // L-BFGS pairs in LDS
 #define NEO_OPT(NS)                                                                                           \
   hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES>), grid, blk, dyn, c->stream, a.B, a.M, c->dev, \
-                     static_cast<const MapT *>(a.table), a.slots, a.x, a.head, a.tail, c->hist, a.costs4,      \
+                     static_cast<const MapT *>(a.table), a.slots, a.x, a.head, a.tail, a.costs4,      \
                      a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter,                                \
                      (c->order_B == a.B ? c->dispatch_order : nullptr))
   switch (slots_for(a.M, D)) {
@@ -1069,9 +1064,6 @@ int dispatch_sample(neo_ctx *c, const MapEntry &e, int D, const SampleArgs &a) {
 #endif
 }
 
-size_t hist_bytes_for(int, int, int) {
-  return 0;  // the L-BFGS pairs live in LDS (2 * maxcor * n doubles per trajectory), not in HBM
-}
 
 void drain_profile(neo_ctx *c) {
   for (int k = 0; k < NEO_KERNEL_COUNT; ++k) {
@@ -1160,7 +1152,6 @@ int neo_ctx_destroy(neo_ctx *c) {
   drain_profile(c);
   for (auto &kv : c->maps)
     if (kv.second.data) hipFree(kv.second.data);
-  if (c->hist) hipFree(c->hist);
   if (c->order_buf) hipFree(c->order_buf);
   if (c->table2d) hipFree(c->table2d);
   if (c->table3d) hipFree(c->table3d);
@@ -1525,7 +1516,8 @@ int neo_sampled_terms_batch(neo_ctx *c, int scene_id, int B, int M, int D, const
   return NEO_OK;
 }
 
-size_t neo_optimize_workspace_bytes(int B, int M, int D) { return hist_bytes_for(B, M, D); }
+// the L-BFGS pairs (2 * maxcor * n doubles per trajectory) live in LDS: no HBM workspace
+size_t neo_optimize_workspace_bytes(int, int, int) { return 0; }
 
 int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, int B, int M, int D, double *x,
                            const double *head, const double *tail, double *costs4, double *costs4_last, int32_t *nit,
@@ -1559,16 +1551,6 @@ int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, i
     layout = it->second.m3.layout;
     const char *base = static_cast<const char *>(kind == 0 ? c->table2d : c->table3d);
     table = base + (size_t)it->second.slot * (kind == 0 ? sizeof(Map2D) : sizeof(Map3D));
-  }
-  const size_t need = hist_bytes_for(B, M, D);
-  if (need > c->hist_bytes) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->hist) hipFree(c->hist);
-  if (c->order_buf) hipFree(c->order_buf);
-    c->hist = nullptr;
-    c->hist_bytes = 0;
-    HIPCHK(c, hipMalloc((void **)&c->hist, need));
-    c->hist_bytes = need;
   }
   ProfScope ps(c, NEO_KERNEL_OPTIMIZE);
   const OptArgs oa{B, M, table, slots, x, head, tail, costs4, costs4_last, nit, nfev, status};
