@@ -675,20 +675,46 @@ __device__ __forceinline__ void piece_pos_vel(const Real (&c)[6][D], Real s, Rea
   }
 }
 
+// lanes per piece in the SAMPLE layout: floor(64 / M), rounded down to a power of two from 8 up -- the piece's
+// lanes then form an aligned group inside a 16-lane DPP row (or whole rows) and fold with DPP shifts instead of
+// LDS shuffles (M = 3: 16 lanes per piece instead of 21, still two rounds of samples, 550 fewer instructions)
+__host__ __device__ __forceinline__ int sample_lanes_per_piece(int M) {
+  int L = kWave / M;
+  if (L < 1) L = 1;
+  if (L >= 8) L = L >= 64 ? 64 : (L >= 32 ? 32 : (L >= 16 ? 16 : 8));
+  return L;
+}
+
+template <typename Real, int CTRL>
+__device__ __forceinline__ Real dpp_real(Real v) {
+  if constexpr (sizeof(Real) == 4)
+    return dpp_f<CTRL>(v);
+  else
+    return dpp_d<CTRL>(v);
+}
+
 // sum over the L lanes (residues r = 0..L-1, adjacent lanes) of each piece; valid in the lane with r = 0.
-// L <= 4 (M >= 16): wave_shl:1 DPP moves, summed left to right ((v_0 + v_1) + v_2) + v_3; otherwise a tree.
+// L <= 4 (M >= 16): wave_shl:1 DPP moves, summed left to right ((v_0 + v_1) + v_2) + v_3.
+// L = 8, 16, 32, 64: halving tree with row_shl DPP moves (lane i <- lane i + s inside its row of 16), rows joined
+// through LDS shuffles.  Other L: a shuffle tree.  Fixed order in every case.
 template <typename Real>
 __device__ __forceinline__ Real fold_piece_lanes(Real v, int L, int r) {
   if (L <= 4) {
     Real acc = v, t = v;
     for (int i = 1; i < L; ++i) {
-      if constexpr (sizeof(Real) == 4)
-        t = dpp_f<0x130>(t);
-      else
-        t = dpp_d<0x130>(t);
+      t = dpp_real<Real, 0x130>(t);
       acc += t;
     }
     return acc;
+  }
+  if ((L & (L - 1)) == 0) {
+    if (L >= 16) v += dpp_real<Real, 0x108>(v);  // row_shl:8
+    v += dpp_real<Real, 0x104>(v);               // row_shl:4
+    v += dpp_real<Real, 0x102>(v);
+    v += dpp_real<Real, 0x101>(v);
+    if (L >= 32) v += __shfl_down(v, 16, kWave);
+    if (L >= 64) v += __shfl_down(v, 32, kWave);
+    return v;
   }
   for (int sft = 1; sft < L; sft <<= 1) {
     const Real o = __shfl_down(v, sft, kWave);

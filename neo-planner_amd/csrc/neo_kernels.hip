@@ -218,8 +218,7 @@ __device__ __forceinline__ void load_boundary(Traj<D> &t, const double *head, co
   t.M = M;
   t.nq = D * (M - 1);
   t.n = t.nq + M;
-  int L = kWave / M;
-  t.L = L < 1 ? 1 : L;
+  t.L = sample_lanes_per_piece(M);
   t.head = head;
   t.tail = tail;
 }
@@ -371,8 +370,7 @@ __global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? 4 : 2) void sample_kerne
   const int b = blockIdx.x;
   if (b >= B) return;
   const int lane = lane_id();
-  int L = kWave / M;
-  L = L < 1 ? 1 : L;
+  const int L = sample_lanes_per_piece(M);
   const int piece = (lane * ((65536 + L - 1) / L)) >> 16;
   const int r = lane - piece * L;
   const bool act = piece < M;

@@ -10,8 +10,8 @@ import neo_planner_amd as npa
 from neo_planner_amd import synth
 grid = 300; res = 30.0 / grid
 dist = synth.esdf_3d(0, n=grid, res=res)
-B, M, D = 4096, 21, 3
-head, tail, wp, ts = synth.replan_requests(0, B, M - 1, D=D)
+B, M, D = int(os.environ.get("NEO_B", "4096")), int(os.environ.get("NEO_M", "21")), 3
+head, tail, wp, ts = synth.replan_requests(0, B, M - 1, D=D, length_range=((4.0, 6.0) if M == 3 else (10.0, 28.0)))
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
 ctx = npa.Context(0, stream=st.cuda_stream)
