@@ -392,7 +392,7 @@ struct Traj {
   // wave-uniform
   int M, n, nq, L;
   // PIECE layout (lane p < M)
-  double T, tau;
+  double T, tau;                  // tau: the decision variable on entry to minco_forward, exp(-tau) after it
   double i1, i2, i3, i4;          // T^-1 .. T^-4
   double P0[D], P1[D];            // positions at the start / end joint
   double V0[D], A0[D], V1[D], A1[D];
@@ -580,7 +580,9 @@ __device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, d
   {
     const double tau = act ? t.tau : 0.0;
     if (-tau > 709.782712893384) bad = 1;
-    t.T = (prm.T_max - prm.T_min) / (1.0 + exp(-tau)) + prm.T_min;
+    const double ex = exp(-tau);
+    t.T = (prm.T_max - prm.T_min) / (1.0 + ex) + prm.T_min;
+    t.tau = ex;  // get_grad_T2tau needs exp(-tau) again (:490): keep it instead of tau
   }
   if (__any(bad)) return 4;
   t.i1 = 1.0 / t.T;
@@ -1021,7 +1023,7 @@ __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams 
     }
   }
   // get_grad_T2tau (:485-492)
-  const double ex = exp(-t.tau);
+  const double ex = t.tau;  // exp(-tau), left there by minco_forward
   // `(1 + math.exp(-tau))**2` (:490) is a Python-float power too: OverflowError beyond sqrt(DBL_MAX)
   if (lane < M && (1.0 + ex) > 1.3407807929942596e154) pow_overflow = 1;
   gtau = gTt * (prm.T_max - prm.T_min) * ex / ((1.0 + ex) * (1.0 + ex));
