@@ -28,6 +28,9 @@
 #ifndef NEO_W2_U
 #define NEO_W2_U 2
 #endif
+#ifndef NEO_W2_MAX_SLOTS
+#define NEO_W2_MAX_SLOTS 2  // two waves per SIMD only up to n = 128 variables (M = 41: +5 % on an fp32 field, -2 % at cfg5)
+#endif
 #include "neo_device.hpp"
 #include "neo_lbfgs.hpp"
 
@@ -974,7 +977,7 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
     case 1: NEO_OPT(1); break;
     case 2: NEO_OPT(2); break;
     default:
-      if constexpr (WAVES == 1) NEO_OPT(4);  // (dispatch_opt never asks for two waves beyond n = 128)
+      if constexpr (WAVES == 1 || NEO_W2_MAX_SLOTS >= 4) NEO_OPT(4);  // (two waves only up to NEO_W2_MAX_SLOTS)
       break;
   }
 #undef NEO_OPT
@@ -984,7 +987,7 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
 int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArgs &a) {
 #ifdef NEO_SLIM_BUILD  // kernel experiments (tools/probe): only the cfg2 instantiation compiles, in 20 s
   if (kind != 0 && D == 3 && elem == NEO_F32 && layout == 0 && c->params.sample_dtype == NEO_F32) {
-    const bool two2 = c->params.flags & NEO_FLAG_TWO_WAVES_PER_SIMD;
+    const bool two2 = (c->params.flags & NEO_FLAG_TWO_WAVES_PER_SIMD) && slots_for(a.M, D) <= NEO_W2_MAX_SLOTS;
     return two2 ? launch_opt<3, float, Map3D, Lookup3D<float, float, 0>, 2>(c, a)
                 : launch_opt<3, float, Map3D, Lookup3D<float, float, 0>>(c, a);
   }
@@ -1000,7 +1003,7 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
   // two trajectories per SIMD for calls that queue for the SIMDs anyway (3-D fields, fp32 sampling, the
   // linear and cell-packed layouts, n <= 128: beyond that the spills cost more than the sharing gains)
   const int fl = c->params.flags;
-  const bool two = f32 && layout != 1 && slots_for(a.M, D) <= 2 &&
+  const bool two = f32 && layout != 1 && slots_for(a.M, D) <= NEO_W2_MAX_SLOTS &&
                    ((a.B >= kTwoWavesFromBatch && !(fl & NEO_FLAG_ONE_WAVE_PER_SIMD)) || (fl & NEO_FLAG_TWO_WAVES_PER_SIMD));
 #define NEO_3D(LAY)                                                                       \
   if (elem == NEO_F32)                                                                    \
