@@ -1,0 +1,215 @@
+// neo_lbfgs_sm.hpp -- the L-BFGS-B run of neo_lbfgs.hpp (lbfgs_minimize) as a resumable state machine, in the
+// reverse-communication style of the original setulb: the caller evaluates the objective, the machine does
+// everything between two evaluations.
+//
+//     LbfgsMachine<Backend> m(be, opts);
+//     m.begin();                                   // be's x holds the start point
+//     while (m.need_eval()) {
+//       est = be.eval(m.x, m.f, m.g, m.costs());   // one cost + gradient evaluation
+//       m.advance(est);
+//     }
+//     m.result(res);
+//
+// Same arithmetic, same order, same decisions as lbfgs_minimize -- tests/test_lbfgs_host.py runs both on the
+// SciPy traces and asks for identical bits.  What it is for: several trajectories sharing one wavefront (lane
+// groups) stay in lock step on the expensive part, the evaluation, whatever each of them does in between:
+// every round is "evaluate, then advance" for all of them.
+#pragma once
+#include "neo_lbfgs.hpp"
+
+namespace neo {
+
+template <class Backend>
+struct LbfgsMachine {
+  using Vec = typename Backend::Vec;
+  enum : int { PH_FIRST = 0, PH_LS = 1, PH_DONE = 2 };
+  enum : int { DO_START_ITER = 0, DO_LS_CONT = 1, DO_SUCCESS = 2, DO_FAILED = 3, DO_RETURN = 4 };
+
+  Backend &be;
+  LbfgsOpts o;
+  Vec x, g, t, r, d, tmp;
+  double f = 0.0, fold = 0.0, stp = 0.0, gd = 0.0, gdold = 0.0, theta = 1.0, stp_evaluated = -1.0;
+  int nfev = 0, nit = 0, iter = 0, col = 0, head = 0, task = LS_START, ifun = 0;
+  int phase = PH_FIRST, status = -1;
+
+  NEO_HD LbfgsMachine(Backend &b, const LbfgsOpts &opts) : be(b), o(opts) {}
+
+  NEO_HD double *costs() { return be.cost_store(); }
+  NEO_HD double *cur() { return be.cost_store() + 4; }
+  NEO_HD double *old() { return be.cost_store() + 8; }
+  NEO_HD bool need_eval() const { return phase != PH_DONE; }
+
+  NEO_HD void begin() {
+    phase = PH_FIRST;
+    status = -1;
+    nfev = nit = iter = col = head = 0;
+    theta = 1.0;
+  }
+
+  NEO_HD void finish(int st) {
+    status = st;
+    phase = PH_DONE;
+  }
+
+  NEO_HD void result(LbfgsResult &res) {
+    res.f = f;
+    res.nit = nit;
+    res.nfev = nfev;
+    res.status = status;
+    for (int k = 0; k < 4; ++k) {
+      res.costs[k] = cur()[k];
+      res.costs_last[k] = costs()[k];
+    }
+  }
+
+  // after be.eval(x, f, g, costs()) returned `est`
+  NEO_HD void advance(int est) {
+    const double epsmch = 2.220446049250313e-16;
+    const double big = 1.0e10;
+    int next;
+    if (phase == PH_FIRST) {
+      nfev++;
+      for (int k = 0; k < 4; ++k) cur()[k] = costs()[k];
+      if (est != 0) return finish(est);
+      if (!(f - f == 0.0)) return finish(TERM_NONFINITE);
+      if (be.amax(g) <= o.gtol) return finish(TERM_CONVERGED_GRAD);
+      phase = PH_LS;
+      next = DO_START_ITER;
+    } else {
+      // an evaluation inside the line search
+      nfev++;
+      if (est != 0) {
+        for (int k = 0; k < 4; ++k) cur()[k] = costs()[k];
+        return finish(est);
+      }
+      if (!(f - f == 0.0)) {
+        for (int k = 0; k < 4; ++k) cur()[k] = costs()[k];
+        return finish(TERM_NONFINITE);
+      }
+      gd = be.dot(g, d);
+      task = LS_FG;
+      next = DO_LS_CONT;
+    }
+
+    while (next != DO_RETURN) {
+      if (next == DO_START_ITER) {
+        // ---- search direction
+        if (col == 0) {
+          be.neg(d, g);
+        } else {
+          be.copy(d, g);  // d plays q of the two-loop recursion
+          for (int k = col - 1; k >= 0; --k) {
+            const int slot = (head + k) % o.m;
+            be.hist_get_s(slot, tmp);
+            const double a = be.sget(slot) * be.dot(tmp, d);  // rho * s'q
+            be.sput(o.m + slot, a);
+            be.hist_get_y(slot, tmp);
+            be.axpy(-a, tmp, d);
+          }
+          be.scale(d, 1.0 / theta);
+          for (int k = 0; k < col; ++k) {
+            const int slot = (head + k) % o.m;
+            be.hist_get_y(slot, tmp);
+            const double b = be.sget(slot) * be.dot(tmp, d);
+            be.hist_get_s(slot, tmp);
+            be.axpy(be.sget(o.m + slot) - b, tmp, d);
+          }
+          be.scale(d, -1.0);
+        }
+        // ---- line search set-up (lnsrlb)
+        be.copy(t, x);
+        be.copy(r, g);
+        fold = f;
+        for (int k = 0; k < 4; ++k) old()[k] = cur()[k];
+        const double dnorm = sqrt(be.dot(d, d));
+        stp = (iter == 0) ? fmin(1.0 / dnorm, big) : 1.0;
+        gd = be.dot(g, d);
+        gdold = gd;
+        if (gd >= 0.0) {
+          next = DO_FAILED;  // "ascent direction in projection": info = -4
+        } else {
+          LineSearch &L = be.ls();
+          L.ftol = 1.0e-3;
+          L.gtol = 0.9;
+          L.xtol = 0.1;
+          L.stpmin = 0.0;
+          L.stpmax = big;
+          task = LS_START;
+          ifun = 0;
+          stp_evaluated = -1.0;
+          next = DO_LS_CONT;
+        }
+      } else if (next == DO_LS_CONT) {
+        next = DO_RETURN;
+        for (;;) {
+          task = dcsrch(be.ls(), f, gd, stp, task);
+          if (task == LS_CONVERGENCE || task == LS_WARNING) {
+            next = DO_SUCCESS;
+            break;
+          }
+          // LS_FG (an LS_ERROR is treated like FG by lnsrlb's csave test)
+          ifun++;
+          if (ifun - 1 >= o.maxls) {
+            next = DO_FAILED;
+            break;
+          }
+          if (stp == stp_evaluated) {
+            // the point just evaluated again: served from SciPy's cache there, not evaluated here
+            task = LS_FG;
+            continue;
+          }
+          stp_evaluated = stp;
+          be.lincomb(x, t, stp, d);
+          break;  // next == DO_RETURN: the caller evaluates x
+        }
+      } else if (next == DO_FAILED) {
+        be.copy(x, t);
+        be.copy(g, r);
+        f = fold;
+        for (int k = 0; k < 4; ++k) cur()[k] = old()[k];
+        if (col == 0) return finish(TERM_ABNORMAL);
+        col = 0;
+        head = 0;
+        theta = 1.0;
+        next = DO_START_ITER;  // RESTART_FROM_LNSRCH: same iteration, steepest descent, stp = 1
+      } else {  // DO_SUCCESS: NEW_X
+        iter++;
+        nit++;
+        for (int k = 0; k < 4; ++k) cur()[k] = costs()[k];
+        if (be.amax(g) <= o.gtol) return finish(TERM_CONVERGED_GRAD);
+        {
+          const double ddum = fmax(fmax(fabs(fold), fabs(f)), 1.0);
+          if ((fold - f) <= o.ftol * ddum) return finish(TERM_CONVERGED_F);
+        }
+        if (nit >= o.maxiter || nfev > o.maxfun) return finish(TERM_MAXITER);
+        // ---- update the limited-memory pairs (mainlb + matupd)
+        be.lincomb(r, g, -1.0, r);  // r = g - g_old = y
+        double dr, ddum;
+        if (stp == 1.0) {
+          dr = gd - gdold;
+          ddum = -gdold;
+        } else {
+          dr = (gd - gdold) * stp;
+          be.scale(d, stp);  // d = s
+          ddum = -gdold * stp;
+        }
+        next = DO_START_ITER;
+        if (dr <= epsmch * ddum) continue;  // skip the update, keep the old memory
+        const double rr = be.dot(r, r);
+        int slot;
+        if (col < o.m) {
+          slot = (head + col) % o.m;
+          col++;
+        } else {
+          slot = head;
+          head = (head + 1) % o.m;
+        }
+        be.hist_put(slot, d, r);
+        be.sput(slot, 1.0 / dr);
+        theta = rr / dr;
+      }
+    }
+  }
+};
+
+}  // namespace neo

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "neo_lbfgs.hpp"
+#include "neo_lbfgs_sm.hpp"
 
 extern "C" {
 typedef int (*eval_cb)(const double *x, int n, double *f, double *g, double *costs, void *user);
@@ -78,6 +79,31 @@ int lbfgs_host_minimize(int n, double *x, double ftol, double gtol, int maxls, i
   neo::LbfgsResult res;
   neo::lbfgs_minimize(be, xv, o, res);
   memcpy(x, xv.data(), n * sizeof(double));
+  *f_out = res.f;
+  *nit = res.nit;
+  *nfev = res.nfev;
+  *status = res.status;
+  memcpy(costs, res.costs, sizeof(res.costs));
+  memcpy(costs_last, res.costs_last, sizeof(res.costs_last));
+  return 0;
+}
+
+// the same run through the resumable state machine (csrc/neo_lbfgs_sm.hpp): must give identical bits
+int lbfgs_host_minimize_sm(int n, double *x, double ftol, double gtol, int maxls, int maxiter,
+                           int maxfun, int m, eval_cb cb, void *user, double *f_out, int *nit,
+                           int *nfev, int *status, double *costs, double *costs_last) {
+  HostBackend be(n, m, cb, user);
+  neo::LbfgsOpts o{ftol, gtol, maxls, maxiter, maxfun, m};
+  neo::LbfgsMachine<HostBackend> mach(be, o);
+  mach.x.assign(x, x + n);
+  mach.begin();
+  while (mach.need_eval()) {
+    const int est = be.eval(mach.x, mach.f, mach.g, mach.costs());
+    mach.advance(est);
+  }
+  neo::LbfgsResult res;
+  mach.result(res);
+  memcpy(x, mach.x.data(), n * sizeof(double));
   *f_out = res.f;
   *nit = res.nit;
   *nfev = res.nfev;

@@ -41,7 +41,8 @@ EVAL_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes
                            ctypes.POINTER(ctypes.c_double), ctypes.c_void_p)
 
 
-def host_minimize(lib, x0, fun_grad_costs, ftol=1e-4, gtol=1e-4, maxls=20, maxiter=15000, maxfun=15000, m=10):
+def host_minimize(lib, x0, fun_grad_costs, ftol=1e-4, gtol=1e-4, maxls=20, maxiter=15000, maxfun=15000, m=10,
+                  entry="lbfgs_host_minimize"):
     n = len(x0)
     x = np.array(x0, dtype=np.float64)
     evals = []
@@ -62,7 +63,7 @@ def host_minimize(lib, x0, fun_grad_costs, ftol=1e-4, gtol=1e-4, maxls=20, maxit
     nit = ctypes.c_int(); nfev = ctypes.c_int(); status = ctypes.c_int()
     costs = np.zeros(4); costs_last = np.zeros(4)
     dp = ctypes.POINTER(ctypes.c_double)
-    lib.lbfgs_host_minimize(ctypes.c_int(n), x.ctypes.data_as(dp), ctypes.c_double(ftol), ctypes.c_double(gtol),
+    getattr(lib, entry)(ctypes.c_int(n), x.ctypes.data_as(dp), ctypes.c_double(ftol), ctypes.c_double(gtol),
                             maxls, maxiter, maxfun, m, EVAL_CB(cb), None, ctypes.byref(f_out),
                             ctypes.byref(nit), ctypes.byref(nfev), ctypes.byref(status),
                             costs.ctypes.data_as(dp), costs_last.ctypes.data_as(dp))
@@ -171,3 +172,24 @@ def test_lbfgs_follows_scipy_traces(lib):
             n_identical += bool(identical)
     assert n_runs >= 30
     assert n_identical >= 0.9 * n_runs, (n_identical, n_runs)
+
+
+def test_state_machine_form_is_the_same_run(lib):
+    """csrc/neo_lbfgs_sm.hpp (the resumable form the lane-group kernels use) against csrc/neo_lbfgs.hpp on every
+    recorded objective: same trial points, same counts, same result, bit for bit"""
+    n_runs = 0
+    for path in golden("g3_trace_*.npz"):
+        d = load(path)
+        for r in range(int(d["n_runs"])):
+            x0 = d[f"r{r}_x0"]
+            M = (len(x0) + 2) // 3
+            _, fgc = _oracle_objective(d, x0[:2 * (M - 1)].reshape(2, M - 1), np.zeros(M))
+            a = host_minimize(lib, x0, fgc)
+            b = host_minimize(lib, x0, fgc, entry="lbfgs_host_minimize_sm")
+            assert (a["nit"], a["nfev"], a["status"]) == (b["nit"], b["nfev"], b["status"]), (path, r)
+            assert np.array_equal(a["x"], b["x"]) and a["f"] == b["f"]
+            assert np.array_equal(a["costs"], b["costs"]) and np.array_equal(a["costs_last"], b["costs_last"])
+            assert len(a["evals"]) == len(b["evals"])
+            assert all(np.array_equal(p[0], q[0]) for p, q in zip(a["evals"], b["evals"]))
+            n_runs += 1
+    assert n_runs >= 30
