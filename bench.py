@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-order", action="store_true", help="dispatch trajectories in index order")
+    ap.add_argument("--lane-groups", action="store_true",
+                    help="small problems (cfg3): four trajectories per wavefront (NEO_FLAG_LANE_GROUPS)")
     ap.add_argument("--streams", type=int, default=3,
                     help="batches kept in flight per GPU (HIP streams): the tail of a launch -- a few long runs on an "
                          "otherwise idle chip -- overlaps with the next batch")
@@ -145,6 +147,7 @@ def main():
     n_scenes = 1
     if a.config == "cfg3":
         a.batch, a.waypoints, a.no_cpu = 65536, 2, True
+        a.lane_groups = True            # M = 3: four trajectories per wavefront
     elif a.config == "cfg4":
         n_scenes, a.no_cpu = a.scenes, True
         a.batch = 4096 * n_scenes
@@ -196,7 +199,8 @@ def main():
     assert tstream.cuda_stream != 0
     ctx = npa.Context(local_rank, stream=tstream.cuda_stream)
     # several batches in flight -> the throughput variant of the optimiser kernel (two wavefronts per SIMD)
-    bp = npa.BatchPlanner(ctx=ctx, sample_dtype=a.dtype, waves_per_simd=2 if a.streams > 1 else None)
+    bp = npa.BatchPlanner(ctx=ctx, sample_dtype=a.dtype, waves_per_simd=2 if a.streams > 1 else None,
+                          lane_groups=a.lane_groups)
     bp._sync()
     g3 = npa.ESDF3D.from_occupancy(torch.from_numpy(occ).to(dev), res, synth.DOMAIN_ORIGIN, store=store, layout=a.layout,
                                    ctx=ctx, want_dist=dist_host is not None)
@@ -378,7 +382,7 @@ def main():
                        "batch_per_gpu": B, "pieces": M, "dims": D, "esdf_voxels": a.grid ** 3,
                        "sampling_arithmetic": a.dtype, "solve_and_optimiser_arithmetic": "f64",
                        "parallelism": f"scene-sharded x{world}",
-                       "batches_in_flight_per_gpu": n_lanes},
+                       "batches_in_flight_per_gpu": n_lanes, "lane_groups": bool(a.lane_groups)},
             "roofline": {"bound": "hbm", "kernel": "optimize_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kernel_ms, "launches": int(launches.value),

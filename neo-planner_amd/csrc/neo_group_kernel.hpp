@@ -1,0 +1,225 @@
+// neo_group_kernel.hpp -- several trajectories per wavefront for small problems (included by neo_kernels.hip).
+//
+// A lane group of W = 16 lanes owns one trajectory (n <= 16 variables, M <= 16 pieces: the reference's M = 3),
+// four groups share a wavefront.  Every round all groups evaluate cost and gradient together (the expensive,
+// identical instruction stream), then each group advances its own L-BFGS-B run -- the resumable form of
+// neo_lbfgs_sm.hpp -- to its next trial point; what the groups do in between may differ, the hardware masks it.
+// A group whose run has ended takes the next trajectory off the launch's ticket counter, so no group idles while
+// work is left.  Opt-in (NEO_FLAG_LANE_GROUPS): the sample loop strides a piece's samples over W / M lanes
+// instead of 64 / M, so sums are associated differently than in optimize_kernel and results agree with it to
+// fp32 rounding, not bit for bit.
+#pragma once
+#include "neo_group.hpp"
+#include "neo_lbfgs_sm.hpp"
+
+namespace neo {
+
+template <int D, int W, typename Real, class MapT, class LookupT, int SU>
+struct GroupBackend {
+  struct Vec {
+    double v[1];  // FLAT layout inside the group: element e <-> lane e, n <= W
+  };
+  Traj<D> t;
+  const DevParams &prm;
+  const MapT &map;
+  double *xs;       // LDS [W] of this group: FLAT <-> PIECE staging
+  double *sc;       // LDS [2m]
+  LineSearch *lsp;  // LDS
+  double *cst;      // LDS [12]
+  double *hist;     // LDS [2][m][n]
+  int m;
+
+  __device__ GroupBackend(const DevParams &p, const MapT &mp) : prm(p), map(mp) {}
+
+  __device__ __forceinline__ double dot(const Vec &a, const Vec &b) const { return grp::grp_sum<W>(a.v[0] * b.v[0]); }
+  __device__ __forceinline__ double amax(const Vec &a) const { return grp::grp_max_nonneg<W>(fabs(a.v[0])); }
+  __device__ __forceinline__ void copy(Vec &d, const Vec &s) const { d.v[0] = s.v[0]; }
+  __device__ __forceinline__ void neg(Vec &d, const Vec &s) const { d.v[0] = -s.v[0]; }
+  __device__ __forceinline__ void axpy(double a, const Vec &x, Vec &y) const { y.v[0] += a * x.v[0]; }
+  __device__ __forceinline__ void lincomb(Vec &o, const Vec &a, double s, const Vec &b) const { o.v[0] = a.v[0] + s * b.v[0]; }
+  __device__ __forceinline__ void scale(Vec &v, double s) const { v.v[0] *= s; }
+  __device__ __forceinline__ void hist_put(int slot, const Vec &s, const Vec &y) {
+    const int gl = grp::glane<W>();
+    if (gl < t.n) {
+      hist[slot * t.n + gl] = s.v[0];
+      hist[(m + slot) * t.n + gl] = y.v[0];
+    }
+    __syncthreads();
+  }
+  __device__ __forceinline__ void hist_get(int row, Vec &v) const {
+    const int gl = grp::glane<W>();
+    v.v[0] = gl < t.n ? hist[row * t.n + gl] : 0.0;
+  }
+  __device__ __forceinline__ void hist_get_s(int slot, Vec &v) const { hist_get(slot, v); }
+  __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
+  __device__ __forceinline__ void sput(int i, double v) {
+    sc[i] = v;
+    __syncthreads();
+  }
+  __device__ __forceinline__ double sget(int i) const { return sc[i]; }
+  __device__ __forceinline__ LineSearch &ls() { return *lsp; }
+  __device__ __forceinline__ double *cost_store() { return cst; }
+
+  // one evaluation (get_cost + get_grad, :539-585); costs into registers, nsamp = samples visited
+  __device__ __forceinline__ int eval(const Vec &x, double &f, Vec &g, double (&costs)[4], int &nsamp) {
+    const int lane = grp::glane<W>();
+    const int M = t.M;
+    __syncthreads();
+    if (lane < t.n) xs[lane] = x.v[0];
+    __syncthreads();
+    const bool act = lane < M;
+    t.tau = act ? xs[t.nq + lane] : 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      t.P0[d] = (lane == 0 || !act) ? t.head[d] : xs[d * (M - 1) + (lane > 0 ? lane - 1 : 0)];
+      t.P1[d] = (lane >= M - 1) ? t.tail[d] : xs[d * (M - 1) + lane];
+    }
+    double energy = 0.0, tsum = 0.0;
+    const int st = grp::minco_forward<W, D>(t, prm, energy, tsum);
+    // (a group whose forward pass fails -- exp overflow -- still walks through the rest on the state its last
+    //  good evaluation left in `t`: the wavefront-wide loop bounds need finite values, and its own results are
+    //  zeroed below exactly as DevBackend::eval returns them)
+    nsamp = grp::grp_sum<W>(act ? t.ns : 0);
+    double gC[6][D], gT = 0.0, cf, ck;
+    {
+      Real cr[6][D], gCr[6][D], gTr;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int d = 0; d < D; ++d) cr[k][d] = (Real)t.c[k][d];
+      LookupT lk(map);
+      grp::minco_sample<W, Real, D, LookupT, SU>(M, t.L, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int d = 0; d < D; ++d) gC[k][d] = (double)gCr[k][d];
+      gT = (double)gTr;
+    }
+    costs[0] = energy;
+    costs[1] = tsum;
+    costs[2] = cf;
+    costs[3] = ck;
+    f = costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3];
+    double gq[D], gtau;
+    const int bst = grp::minco_backward<W, D>(t, prm, gC, gT, gq, gtau);
+    __syncthreads();
+    if (lane >= 1 && lane < M) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) xs[d * (M - 1) + lane - 1] = gq[d];
+    }
+    if (lane < M) xs[t.nq + lane] = gtau;
+    __syncthreads();
+    g.v[0] = lane < t.n ? xs[lane] : 0.0;
+    if (st != 0) {
+      f = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) costs[k] = 0.0;
+      return st;
+    }
+    return bst;
+  }
+};
+
+// grid = any number of wavefronts (the host sizes it to the chip); groups pull trajectories off *ticket
+#ifndef NEO_GRP_OCC
+#define NEO_GRP_OCC 2
+#endif
+#ifndef NEO_GRP_U
+#define NEO_GRP_U 2
+#endif
+template <int D, typename Real, class MapT, class LookupT, int W>
+__global__ __launch_bounds__(kWave, NEO_GRP_OCC) void optimize_group_kernel(int B, int M, DevParams prm, const MapT *maps,
+                                                                   double *__restrict__ x,
+                                                                   const double *__restrict__ head,
+                                                                   const double *__restrict__ tail,
+                                                                   double *__restrict__ costs4,
+                                                                   double *__restrict__ costs4_last,
+                                                                   int *__restrict__ nit, int *__restrict__ nfev,
+                                                                   int *__restrict__ status,
+                                                                   long long *__restrict__ nsamples,
+                                                                   const int *__restrict__ order,
+                                                                   int *__restrict__ ticket) {
+  constexpr int G = kWave / W;
+  __shared__ double xs[G][W];
+  __shared__ double sc[G][2 * NEO_LBFGS_M];
+  __shared__ LineSearch lsm[G];
+  __shared__ double cst[G][12];
+  extern __shared__ double dyn_lds[];  // G * 2 * maxcor * n doubles
+  using BE = GroupBackend<D, W, Real, MapT, LookupT, NEO_GRP_U>;
+  const MapT map = maps[0];
+  BE be(prm, map);
+  be.t = Traj<D>{};
+  const int gl = grp::glane<W>();
+  const int g = lane_id() / W;
+  const int nq = D * (M - 1), n = nq + M;
+  be.xs = xs[g];
+  be.sc = sc[g];
+  be.lsp = &lsm[g];
+  be.cst = cst[g];
+  be.m = NEO_LBFGS_M;
+  be.hist = dyn_lds + (size_t)g * 2 * NEO_LBFGS_M * n;
+  be.t.M = M;
+  be.t.nq = nq;
+  be.t.n = n;
+  be.t.L = grp::sample_lanes_per_piece<W>(M);
+
+  LbfgsOpts o{prm.ftol, prm.gtol, prm.maxls, prm.maxiter, prm.maxfun, NEO_LBFGS_M};
+  LbfgsMachine<BE> mach(be, o);
+  int b = 0;              // the group's trajectory
+  bool busy = false;      // it has one
+  long long samples = 0;
+
+  // take the next trajectory: lane 0 of the group draws a ticket, the group loads the start point
+  auto take = [&]() {
+    int tk = 0;
+    if (gl == 0) tk = atomicAdd(ticket, 1);
+    tk = __shfl(tk, grp::gbase<W>(), kWave);
+    busy = tk < B;
+    b = busy ? (order ? order[tk] : tk) : 0;
+    be.t.head = head + (size_t)b * 3 * D;
+    be.t.tail = tail + (size_t)b * 3 * D;
+    mach.x.v[0] = gl < n ? x[(size_t)b * n + gl] : 0.0;
+    mach.begin();
+    samples = 0;
+  };
+  auto put = [&]() {
+    if (gl < n) x[(size_t)b * n + gl] = mach.x.v[0];
+    if (gl == 0) {
+      LbfgsResult res;
+      mach.result(res);
+      int st = res.status;
+      if (res.costs_last[3] * prm.w[3] > prm.coll_tol) st |= NEO_TRAJ_FLAG_COLLISION;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        costs4[(size_t)b * 4 + k] = res.costs[k];
+        if (costs4_last) costs4_last[(size_t)b * 4 + k] = res.costs_last[k];
+      }
+      nit[b] = res.nit;
+      nfev[b] = res.nfev;
+      status[b] = st;
+      if (nsamples) nsamples[b] = samples;
+    }
+  };
+
+  take();
+  while (__any(busy)) {
+    double fnew, c4[4];
+    typename BE::Vec gnew;
+    int ns;
+    const int est = be.eval(mach.x, fnew, gnew, c4, ns);  // every lane of the wavefront, busy group or not
+    if (busy) {
+      mach.f = fnew;
+      mach.g = gnew;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) be.cst[k] = c4[k];
+      samples += ns;
+      mach.advance(est);
+      if (!mach.need_eval()) {
+        put();
+        take();
+      }
+    }
+  }
+}
+
+}  // namespace neo

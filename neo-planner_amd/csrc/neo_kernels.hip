@@ -33,6 +33,7 @@
 #endif
 #include "neo_device.hpp"
 #include "neo_lbfgs.hpp"
+#include "neo_group_kernel.hpp"
 
 namespace neo {
 
@@ -762,6 +763,8 @@ struct neo_ctx {
   std::map<int, MapEntry> maps;
   std::string err;
   std::recursive_mutex mu;  // recursive: the host-pointer entry points hold it across their *_dev call
+  int *tickets = nullptr;  // ring of work counters for optimize_group_kernel launches (one per launch in flight)
+  unsigned ticket_next = 0;
   // device-side table of maps (rebuilt when a map changes)
   void *table2d = nullptr, *table3d = nullptr;
   int n2d = 0, n3d = 0;
@@ -984,9 +987,31 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
   return NEO_OK;
 }
 
+constexpr int kTicketRing = 64;
+
+template <typename Real, class LookupT>
+int launch_group(neo_ctx *c, const OptArgs &a) {
+  constexpr int D = 3, W = 16, G = kWave / W;
+  if (!c->tickets) {
+    HIPCHK(c, hipMalloc((void **)&c->tickets, kTicketRing * sizeof(int)));
+  }
+  int *ticket = c->tickets + (c->ticket_next++ % kTicketRing);
+  HIPCHK(c, hipMemsetAsync(ticket, 0, sizeof(int), c->stream));
+  const int n = D * (a.M - 1) + a.M;
+  const size_t dyn = (size_t)G * 2 * NEO_LBFGS_M * n * sizeof(double);
+  const int waves = std::min((a.B + G - 1) / G, 4096);  // persistent groups: they draw trajectories off the ticket
+  hipLaunchKernelGGL((optimize_group_kernel<D, Real, Map3D, LookupT, W>), dim3(waves), dim3(kWave), dyn, c->stream, a.B,
+                     a.M, c->dev, static_cast<const Map3D *>(a.table), a.x, a.head, a.tail, a.costs4, a.costs4_last,
+                     a.nit, a.nfev, a.status, c->sample_counter, (c->order_B == a.B ? c->dispatch_order : nullptr),
+                     ticket);
+  return NEO_OK;
+}
+
 int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArgs &a) {
 #ifdef NEO_SLIM_BUILD  // kernel experiments (tools/probe): only the cfg2 instantiation compiles, in 20 s
   if (kind != 0 && D == 3 && elem == NEO_F32 && layout == 0 && c->params.sample_dtype == NEO_F32) {
+    if ((c->params.flags & NEO_FLAG_LANE_GROUPS) && !a.slots && a.M <= 16 && D * (a.M - 1) + a.M <= 16)
+      return launch_group<float, Lookup3D<float, float, 0>>(c, a);
     const bool two2 = (c->params.flags & NEO_FLAG_TWO_WAVES_PER_SIMD) && slots_for(a.M, D) <= NEO_W2_MAX_SLOTS;
     return two2 ? launch_opt<3, float, Map3D, Lookup3D<float, float, 0>, 2>(c, a)
                 : launch_opt<3, float, Map3D, Lookup3D<float, float, 0>>(c, a);
@@ -1003,6 +1028,10 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
   // two trajectories per SIMD for calls that queue for the SIMDs anyway (3-D fields, fp32 sampling, the
   // linear and cell-packed layouts, n <= 128: beyond that the spills cost more than the sharing gains)
   const int fl = c->params.flags;
+  if ((fl & NEO_FLAG_LANE_GROUPS) && f32 && layout == 0 && !a.slots && a.M <= 16 && D * (a.M - 1) + a.M <= 16) {
+    if (elem == NEO_F32) return launch_group<float, Lookup3D<float, float, 0>>(c, a);
+    return launch_group<float, Lookup3D<float, __half, 0>>(c, a);
+  }
   const bool two = f32 && layout != 1 && slots_for(a.M, D) <= NEO_W2_MAX_SLOTS &&
                    ((a.B >= kTwoWavesFromBatch && !(fl & NEO_FLAG_ONE_WAVE_PER_SIMD)) || (fl & NEO_FLAG_TWO_WAVES_PER_SIMD));
 #define NEO_3D(LAY)                                                                       \
@@ -1154,6 +1183,7 @@ int neo_ctx_destroy(neo_ctx *c) {
   for (auto &kv : c->maps)
     if (kv.second.data) hipFree(kv.second.data);
   if (c->order_buf) hipFree(c->order_buf);
+  if (c->tickets) hipFree(c->tickets);
   if (c->table2d) hipFree(c->table2d);
   if (c->table3d) hipFree(c->table3d);
   if (c->scratch) hipFree(c->scratch);

@@ -1,6 +1,7 @@
 """ctypes binding of include/neo_planner.h.  Loading fails loudly: there is no CPU fallback."""
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -15,7 +16,7 @@ NEO_TRAJ_CONVERGED_GRAD, NEO_TRAJ_CONVERGED_F, NEO_TRAJ_ABNORMAL = 0, 1, 2
 NEO_TRAJ_MAXITER, NEO_TRAJ_NUMERIC_RANGE, NEO_TRAJ_NONFINITE = 3, 4, 5
 NEO_TRAJ_FLAG_COLLISION = 0x100
 NEO_KERNEL_EVAL, NEO_KERNEL_OPTIMIZE, NEO_KERNEL_ESDF_BUILD, NEO_KERNEL_ESDF_SAMPLE = 0, 1, 2, 3
-NEO_FLAG_ONE_WAVE_PER_SIMD, NEO_FLAG_TWO_WAVES_PER_SIMD = 32, 64
+NEO_FLAG_ONE_WAVE_PER_SIMD, NEO_FLAG_TWO_WAVES_PER_SIMD, NEO_FLAG_LANE_GROUPS = 32, 64, 128
 
 # every symbol include/neo_planner.h declares (tests check the library exports them all)
 EXPORTS = [
@@ -54,6 +55,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise NeoError(f"{LIB_PATH} is missing: build it with `python -m neo_planner_amd.build` "
                        "(hipcc, gfx950).  There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own HIP runtime under the same soname as /opt/rocm's.  Whichever is loaded
+    # first serves the whole process; torch does not find its GPUs on the system one ("No HIP GPUs are
+    # available"), while this library runs on either.  So: torch first, if it is installed at all.
+    if "torch" not in sys.modules and not os.environ.get("NEO_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = ctypes.CDLL(LIB_PATH)
     c_p, c_i, c_d = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
     L.neo_abi_version.restype = c_i

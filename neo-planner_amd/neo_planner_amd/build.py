@@ -8,7 +8,8 @@ CSRC = os.path.join(os.path.dirname(PKG), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(PKG)), "include")
 LIB = os.path.join(PKG, "libneo_planner_hip.so")
 SOURCES = ["neo_kernels.hip"]
-DEPS = ["neo_kernels.hip", "neo_device.hpp", "neo_lbfgs.hpp", "neo_linesearch.hpp"]
+DEPS = ["neo_kernels.hip", "neo_device.hpp", "neo_lbfgs.hpp", "neo_linesearch.hpp", "neo_lbfgs_sm.hpp", "neo_group.hpp",
+        "neo_group_kernel.hpp"]
 
 
 def _stale():

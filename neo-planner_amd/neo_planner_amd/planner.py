@@ -384,7 +384,7 @@ class BatchPlanner:
     """B independent replans per call (host arrays in, host arrays out).  For device-resident
     buffers use `optimize_dev` with torch tensors."""
 
-    def __init__(self, config=None, ctx=None, sample_dtype="f64", stale_T=True, waves_per_simd=None):
+    def __init__(self, config=None, ctx=None, sample_dtype="f64", stale_T=True, waves_per_simd=None, lane_groups=False):
         """waves_per_simd: None (the library decides by batch size), 1 (shortest evaluations) or 2 (highest
         throughput when several batches are in flight) -- include/neo_planner.h NEO_FLAG_*; same results"""
         self.cfg = config if config is not None else PlannerConfig()
@@ -392,6 +392,8 @@ class BatchPlanner:
         self.sample_dtype = sample_dtype
         self.stale_T = stale_T
         self.flags = {None: 0, 1: _lib.NEO_FLAG_ONE_WAVE_PER_SIMD, 2: _lib.NEO_FLAG_TWO_WAVES_PER_SIMD}[waves_per_simd]
+        if lane_groups:     # small problems: four trajectories per wavefront (NEO_FLAG_LANE_GROUPS; fp32-rounding-level
+            self.flags |= _lib.NEO_FLAG_LANE_GROUPS   # differences to the default kernel)
 
     @property
     def ctx(self):
