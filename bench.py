@@ -77,7 +77,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-order", action="store_true", help="dispatch trajectories in index order")
     ap.add_argument("--lane-groups", action="store_true",
-                    help="small problems (cfg3): four trajectories per wavefront (NEO_FLAG_LANE_GROUPS)")
+                    help="small problems (cfg3): eight trajectories per wavefront (NEO_FLAG_LANE_GROUPS)")
     ap.add_argument("--streams", type=int, default=3,
                     help="batches kept in flight per GPU (HIP streams): the tail of a launch -- a few long runs on an "
                          "otherwise idle chip -- overlaps with the next batch")
@@ -147,7 +147,7 @@ def main():
     n_scenes = 1
     if a.config == "cfg3":
         a.batch, a.waypoints, a.no_cpu = 65536, 2, True
-        a.lane_groups = True            # M = 3: four trajectories per wavefront
+        a.lane_groups = True            # M = 3: eight trajectories per wavefront
     elif a.config == "cfg4":
         n_scenes, a.no_cpu = a.scenes, True
         a.batch = 4096 * n_scenes
@@ -201,6 +201,7 @@ def main():
     # several batches in flight -> the throughput variant of the optimiser kernel (two wavefronts per SIMD)
     bp = npa.BatchPlanner(ctx=ctx, sample_dtype=a.dtype, waves_per_simd=2 if a.streams > 1 else None,
                           lane_groups=a.lane_groups)
+    bp.flags |= int(os.environ.get("NEO_BENCH_FLAGS_OR", "0"))     # kernel experiments
     bp._sync()
     g3 = npa.ESDF3D.from_occupancy(torch.from_numpy(occ).to(dev), res, synth.DOMAIN_ORIGIN, store=store, layout=a.layout,
                                    ctx=ctx, want_dist=dist_host is not None)

@@ -1,7 +1,7 @@
 // neo_group_kernel.hpp -- several trajectories per wavefront for small problems (included by neo_kernels.hip).
 //
-// A lane group of W = 16 lanes owns one trajectory (n <= 16 variables, M <= 16 pieces: the reference's M = 3),
-// four groups share a wavefront.  Every round all groups evaluate cost and gradient together (the expensive,
+// A lane group of W = 8 or 16 lanes owns one trajectory (n <= 16 variables, M <= W pieces: the reference's M = 3),
+// eight or four groups share a wavefront.  Every round all groups evaluate cost and gradient together (the expensive,
 // identical instruction stream), then each group advances its own L-BFGS-B run -- the resumable form of
 // neo_lbfgs_sm.hpp -- to its next trial point; what the groups do in between may differ, the hardware masks it.
 // A group whose run has ended takes the next trajectory off the launch's ticket counter, so no group idles while
@@ -14,15 +14,15 @@
 
 namespace neo {
 
-template <int D, int W, typename Real, class MapT, class LookupT, int SU>
+template <int D, int W, int NS, typename Real, class MapT, class LookupT, int SU>
 struct GroupBackend {
   struct Vec {
-    double v[1];  // FLAT layout inside the group: element e <-> lane e, n <= W
+    double v[NS];  // FLAT layout inside the group: element e <-> (lane e % W, slot e / W), n <= W * NS
   };
   Traj<D> t;
   const DevParams &prm;
   const MapT &map;
-  double *xs;       // LDS [W] of this group: FLAT <-> PIECE staging
+  double *xs;       // LDS [W * NS] of this group: FLAT <-> PIECE staging
   double *sc;       // LDS [2m]
   LineSearch *lsp;  // LDS
   double *cst;      // LDS [12]
@@ -31,24 +31,52 @@ struct GroupBackend {
 
   __device__ GroupBackend(const DevParams &p, const MapT &mp) : prm(p), map(mp) {}
 
-  __device__ __forceinline__ double dot(const Vec &a, const Vec &b) const { return grp::grp_sum<W>(a.v[0] * b.v[0]); }
-  __device__ __forceinline__ double amax(const Vec &a) const { return grp::grp_max_nonneg<W>(fabs(a.v[0])); }
-  __device__ __forceinline__ void copy(Vec &d, const Vec &s) const { d.v[0] = s.v[0]; }
-  __device__ __forceinline__ void neg(Vec &d, const Vec &s) const { d.v[0] = -s.v[0]; }
-  __device__ __forceinline__ void axpy(double a, const Vec &x, Vec &y) const { y.v[0] += a * x.v[0]; }
-  __device__ __forceinline__ void lincomb(Vec &o, const Vec &a, double s, const Vec &b) const { o.v[0] = a.v[0] + s * b.v[0]; }
-  __device__ __forceinline__ void scale(Vec &v, double s) const { v.v[0] *= s; }
+  __device__ __forceinline__ double dot(const Vec &a, const Vec &b) const {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s += a.v[k] * b.v[k];
+    return grp::grp_sum<W>(s);
+  }
+  __device__ __forceinline__ double amax(const Vec &a) const {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s = fmax(s, fabs(a.v[k]));
+    return grp::grp_max_nonneg<W>(s);
+  }
+  __device__ __forceinline__ void copy(Vec &d, const Vec &s) const {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) d.v[k] = s.v[k];
+  }
+  __device__ __forceinline__ void neg(Vec &d, const Vec &s) const {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) d.v[k] = -s.v[k];
+  }
+  __device__ __forceinline__ void axpy(double a, const Vec &x, Vec &y) const {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) y.v[k] += a * x.v[k];
+  }
+  __device__ __forceinline__ void lincomb(Vec &o, const Vec &a, double s, const Vec &b) const {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) o.v[k] = a.v[k] + s * b.v[k];
+  }
+  __device__ __forceinline__ void scale(Vec &v, double s) const {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) v.v[k] *= s;
+  }
   __device__ __forceinline__ void hist_put(int slot, const Vec &s, const Vec &y) {
     const int gl = grp::glane<W>();
-    if (gl < t.n) {
-      hist[slot * t.n + gl] = s.v[0];
-      hist[(m + slot) * t.n + gl] = y.v[0];
-    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      if (k * W + gl < t.n) {
+        hist[slot * t.n + k * W + gl] = s.v[k];
+        hist[(m + slot) * t.n + k * W + gl] = y.v[k];
+      }
     __syncthreads();
   }
   __device__ __forceinline__ void hist_get(int row, Vec &v) const {
     const int gl = grp::glane<W>();
-    v.v[0] = gl < t.n ? hist[row * t.n + gl] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) v.v[k] = (k * W + gl < t.n) ? hist[row * t.n + k * W + gl] : 0.0;
   }
   __device__ __forceinline__ void hist_get_s(int slot, Vec &v) const { hist_get(slot, v); }
   __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
@@ -65,7 +93,9 @@ struct GroupBackend {
     const int lane = grp::glane<W>();
     const int M = t.M;
     __syncthreads();
-    if (lane < t.n) xs[lane] = x.v[0];
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      if (k * W + lane < t.n) xs[k * W + lane] = x.v[k];
     __syncthreads();
     const bool act = lane < M;
     t.tau = act ? xs[t.nq + lane] : 0.0;
@@ -109,7 +139,8 @@ struct GroupBackend {
     }
     if (lane < M) xs[t.nq + lane] = gtau;
     __syncthreads();
-    g.v[0] = lane < t.n ? xs[lane] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) g.v[k] = (k * W + lane < t.n) ? xs[k * W + lane] : 0.0;
     if (st != 0) {
       f = 0.0;
 #pragma unroll
@@ -127,7 +158,7 @@ struct GroupBackend {
 #ifndef NEO_GRP_U
 #define NEO_GRP_U 2
 #endif
-template <int D, typename Real, class MapT, class LookupT, int W>
+template <int D, typename Real, class MapT, class LookupT, int W, int NS>
 __global__ __launch_bounds__(kWave, NEO_GRP_OCC) void optimize_group_kernel(int B, int M, DevParams prm, const MapT *maps,
                                                                    double *__restrict__ x,
                                                                    const double *__restrict__ head,
@@ -140,12 +171,12 @@ __global__ __launch_bounds__(kWave, NEO_GRP_OCC) void optimize_group_kernel(int 
                                                                    const int *__restrict__ order,
                                                                    int *__restrict__ ticket) {
   constexpr int G = kWave / W;
-  __shared__ double xs[G][W];
+  __shared__ double xs[G][W * NS];
   __shared__ double sc[G][2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm[G];
   __shared__ double cst[G][12];
   extern __shared__ double dyn_lds[];  // G * 2 * maxcor * n doubles
-  using BE = GroupBackend<D, W, Real, MapT, LookupT, NEO_GRP_U>;
+  using BE = GroupBackend<D, W, NS, Real, MapT, LookupT, NEO_GRP_U>;
   const MapT map = maps[0];
   BE be(prm, map);
   be.t = Traj<D>{};
@@ -178,12 +209,15 @@ __global__ __launch_bounds__(kWave, NEO_GRP_OCC) void optimize_group_kernel(int 
     b = busy ? (order ? order[tk] : tk) : 0;
     be.t.head = head + (size_t)b * 3 * D;
     be.t.tail = tail + (size_t)b * 3 * D;
-    mach.x.v[0] = gl < n ? x[(size_t)b * n + gl] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) mach.x.v[k] = (k * W + gl < n) ? x[(size_t)b * n + k * W + gl] : 0.0;
     mach.begin();
     samples = 0;
   };
   auto put = [&]() {
-    if (gl < n) x[(size_t)b * n + gl] = mach.x.v[0];
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      if (k * W + gl < n) x[(size_t)b * n + k * W + gl] = mach.x.v[k];
     if (gl == 0) {
       LbfgsResult res;
       mach.result(res);

@@ -392,7 +392,7 @@ class BatchPlanner:
         self.sample_dtype = sample_dtype
         self.stale_T = stale_T
         self.flags = {None: 0, 1: _lib.NEO_FLAG_ONE_WAVE_PER_SIMD, 2: _lib.NEO_FLAG_TWO_WAVES_PER_SIMD}[waves_per_simd]
-        if lane_groups:     # small problems: four trajectories per wavefront (NEO_FLAG_LANE_GROUPS; fp32-rounding-level
+        if lane_groups:     # small problems: eight trajectories per wavefront (NEO_FLAG_LANE_GROUPS; fp32-rounding-level
             self.flags |= _lib.NEO_FLAG_LANE_GROUPS   # differences to the default kernel)
 
     @property

@@ -273,7 +273,7 @@ def test_one_and_two_waves_per_simd_agree_bit_for_bit():
 
 
 def test_lane_group_kernel_small_problems():
-    """NEO_FLAG_LANE_GROUPS: four trajectories per wavefront (M = 3, n = 9).  Same algorithm, fp32 sums associated
+    """NEO_FLAG_LANE_GROUPS: eight trajectories per wavefront (M = 3, n = 9).  Same algorithm, fp32 sums associated
     differently: runs either follow the default kernel's path (then the results agree to fp32 rounding) or part
     from it the way any two fp32 evaluations of this objective do; the batch as a whole ends at the same costs.
     Results do not depend on which group of which wavefront picks a trajectory up."""
