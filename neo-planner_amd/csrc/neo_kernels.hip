@@ -1011,6 +1011,8 @@ int launch_group_w(neo_ctx *c, const OptArgs &a) {
 // comparison), else four
 template <typename Real, class LookupT>
 int launch_group(neo_ctx *c, const OptArgs &a) {
+  const int n = 3 * (a.M - 1) + a.M;
+  if (n > 16) return launch_group_w<Real, LookupT, 16, 2>(c, a);  // n <= 32 (M <= 8): four per wavefront, two slots
   if (a.M <= 8 && !(c->params.flags & 256)) return launch_group_w<Real, LookupT, 8, 2>(c, a);
   return launch_group_w<Real, LookupT, 16, 1>(c, a);
 }
@@ -1018,7 +1020,7 @@ int launch_group(neo_ctx *c, const OptArgs &a) {
 int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArgs &a) {
 #ifdef NEO_SLIM_BUILD  // kernel experiments (tools/probe): only the cfg2 instantiation compiles, in 20 s
   if (kind != 0 && D == 3 && elem == NEO_F32 && layout == 0 && c->params.sample_dtype == NEO_F32) {
-    if ((c->params.flags & NEO_FLAG_LANE_GROUPS) && !a.slots && a.M <= 16 && D * (a.M - 1) + a.M <= 16)
+    if ((c->params.flags & NEO_FLAG_LANE_GROUPS) && !a.slots && a.M <= 16 && D * (a.M - 1) + a.M <= 32)
       return launch_group<float, Lookup3D<float, float, 0>>(c, a);
     const bool two2 = (c->params.flags & NEO_FLAG_TWO_WAVES_PER_SIMD) && slots_for(a.M, D) <= NEO_W2_MAX_SLOTS;
     return two2 ? launch_opt<3, float, Map3D, Lookup3D<float, float, 0>, 2>(c, a)
@@ -1036,7 +1038,7 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
   // two trajectories per SIMD for calls that queue for the SIMDs anyway (3-D fields, fp32 sampling, the
   // linear and cell-packed layouts, n <= 128: beyond that the spills cost more than the sharing gains)
   const int fl = c->params.flags;
-  if ((fl & NEO_FLAG_LANE_GROUPS) && f32 && layout == 0 && !a.slots && a.M <= 16 && D * (a.M - 1) + a.M <= 16) {
+  if ((fl & NEO_FLAG_LANE_GROUPS) && f32 && layout == 0 && !a.slots && a.M <= 16 && D * (a.M - 1) + a.M <= 32) {
     if (elem == NEO_F32) return launch_group<float, Lookup3D<float, float, 0>>(c, a);
     return launch_group<float, Lookup3D<float, __half, 0>>(c, a);
   }

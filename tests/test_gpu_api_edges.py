@@ -279,7 +279,7 @@ def test_lane_group_kernel_small_problems():
     Results do not depend on which group of which wavefront picks a trajectory up."""
     dist = synth.esdf_3d(2, n=100, res=0.3)
     g3 = npa.ESDF3D(dist, 0.3, synth.DOMAIN_ORIGIN, store="f32")
-    for M, B in ((3, 1001), (4, 130), (2, 64), (3, 1)):
+    for M, B in ((3, 1001), (4, 130), (2, 64), (3, 1), (6, 200), (8, 65)):
         head, tail, wp, ts = synth.replan_requests(4, B, M - 1, D=3, length_range=(4.0, 6.0))
         ref = npa.BatchPlanner(sample_dtype="f32")
         x0 = ref.pack_x(wp, ts)
