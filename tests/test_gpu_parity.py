@@ -472,3 +472,47 @@ def test_3d_runs_follow_the_cpu_optimizer_in_fp64_mode():
     # other local minima: comparable cost, no tighter statement holds for them
     assert np.median(rels) < 1e-4 and np.percentile(rels, 80) < 0.02 and max(rels) < 0.5, \
         (np.median(rels), np.percentile(rels, 80), max(rels))
+
+
+def _cpu_run_3d_small(args):
+    """worker: one M = 3 trajectory through the CPU oracle on the 3-D field"""
+    scene, n, b, B = args
+    import numpy as _np
+    from neo_planner_amd import synth as _synth
+    from oracle import minco_np as _onp
+    res = 30.0 / n
+    o3 = _onp.Grid3DESDF(_synth.esdf_3d(scene, n=n, res=res), res, _synth.DOMAIN_ORIGIN)
+    head, tail, wp, ts = _synth.replan_requests(scene, B, 2, D=3, length_range=(4.0, 6.0))
+    pl = _onp.OraclePlanner(_onp.PlannerParams())
+    pl.read_planning_conditions(o3, head[b], tail[b], wp[b], ts[b])
+    try:
+        pl.plan_once()
+    except Exception:
+        pass
+    r = pl.last_result
+    return b, (r.nit, r.nfev) if r is not None else (-1, -1), float(_np.dot(pl.costs, pl.weights))
+
+
+def test_lane_group_kernel_against_the_cpu_optimizer():
+    """the eight-trajectories-per-wavefront kernel (M = 3, fp32 sampling) against SciPy L-BFGS-B on the oracle
+    objective, same inputs: the bar of the fp32 mode (final cost, §3 of DESIGN.md)"""
+    import multiprocessing as mp
+    scene, n, B = 5, 100, 32
+    with mp.get_context("spawn").Pool(8) as pool:
+        cpu = sorted(pool.map(_cpu_run_3d_small, [(scene, n, b, B) for b in range(B)]))
+    res = 30.0 / n
+    g3 = npa.ESDF3D(synth.esdf_3d(scene, n=n, res=res), res, synth.DOMAIN_ORIGIN, store="f32")
+    head, tail, wp, ts = synth.replan_requests(scene, B, 2, D=3, length_range=(4.0, 6.0))
+    bp = npa.BatchPlanner(sample_dtype="f32", lane_groups=True)
+    out = bp.optimize(g3, bp.pack_x(wp, ts), head, tail)
+    w = np.array(bp.cfg.weights)
+    rels, same = [], 0
+    for b, (nit, nfev), cost in cpu:
+        if nit < 0 or out["status"][b] > 2:
+            continue
+        gpu_cost = float((out["costs_last"][b] * w).sum())
+        rels.append(abs(gpu_cost - cost) / abs(cost))
+        same += int(out["nit"][b]) == nit and int(out["nfev"][b]) == nfev
+    assert len(rels) >= 0.8 * B
+    assert np.median(rels) < 1e-4 and np.percentile(rels, 80) < 2e-2, (np.median(rels), np.percentile(rels, 80))
+    assert same >= 0.2 * len(rels), (same, len(rels))
