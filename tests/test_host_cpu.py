@@ -104,3 +104,13 @@ def test_flag_constants_match_the_header():
     assert int(defs["NEO_FLAG_ONE_WAVE_PER_SIMD"]) == _lib.NEO_FLAG_ONE_WAVE_PER_SIMD
     assert int(defs["NEO_FLAG_TWO_WAVES_PER_SIMD"]) == _lib.NEO_FLAG_TWO_WAVES_PER_SIMD
     assert [f for f, _ in _lib.NeoParams._fields_][-1] == "flags"
+
+
+def test_generated_group_header_is_in_sync():
+    """csrc/neo_group.hpp is generated from csrc/neo_device.hpp (tools/gen_group_header.py): the committed copy
+    must be what the generator produces from the committed source"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_group_header", os.path.join(REPO, "tools", "gen_group_header.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert gen.generate() == open(gen.DST).read()
