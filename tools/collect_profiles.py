@@ -25,7 +25,7 @@ PMC_GROUPS = [
     ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES"],
     ["TCC_HIT_sum", "TCC_MISS_sum", "TCP_TCC_READ_REQ_sum"],
 ]
-KERNELS = ["optimize_kernel", "sample_kernel", "eval_kernel", "edt3_x", "edt3_y", "edt3_z", "pack3d"]
+KERNELS = ["optimize_group_kernel", "optimize_kernel", "sample_kernel", "eval_kernel", "edt3_x", "edt3_y", "edt3_z", "pack3d"]
 
 
 def run(cmd, log, timeout):
