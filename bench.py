@@ -424,9 +424,14 @@ def main():
                 bp64 = npa.BatchPlanner(ctx=ctx, sample_dtype="f64")
                 bp64._sync()
                 x.copy_(x0)
+                torch.cuda.synchronize()
+                t64 = time.perf_counter()
                 bp64.optimize_dev(g3, x, d_head, d_tail, costs, last, nit, nfev, status)
                 torch.cuda.synchronize()
+                t64 = time.perf_counter() - t64
                 out["final_cost_delta_vs_cpu_f64_sampling"] = delta(last, nfev)
+                out["final_cost_delta_vs_cpu_f64_sampling"]["ms_one_batch"] = 1e3 * t64
+                out["final_cost_delta_vs_cpu_f64_sampling"]["traj_per_s_one_batch_at_a_time"] = B / t64
         # RCCL prints a version banner through C stdio; push it out first so that the JSON is the last line
         try:
             ctypes.CDLL(None).fflush(None)
