@@ -309,3 +309,44 @@ def test_lane_group_kernel_small_problems():
     a = ref.optimize(g3, x0, head, tail)
     b = npa.BatchPlanner(sample_dtype="f32", lane_groups=True).optimize(g3, x0, head, tail)
     assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["nfev"], b["nfev"])
+
+
+def test_lane_groups_with_dispatch_order_and_batches_in_flight():
+    """the ticket counters of concurrent lane-group launches are separate, and a dispatch order only changes who
+    starts first: results identical to the plain one-at-a-time run"""
+    import ctypes
+    import torch
+    dist = synth.esdf_3d(2, n=100, res=0.3)
+    dev = torch.device("cuda", 0)
+    ctx = npa.Context(0)
+    g3 = npa.ESDF3D(dist, 0.3, synth.DOMAIN_ORIGIN, store="f32", ctx=ctx)
+    B, M = 3000, 3
+    head, tail, wp, ts = synth.replan_requests(9, B, M - 1, D=3, length_range=(4.0, 6.0))
+    bp = npa.BatchPlanner(ctx=ctx, sample_dtype="f32", lane_groups=True)
+    ref = bp.optimize(g3, bp.pack_x(wp, ts), head, tail, order=False)
+    x0 = torch.from_numpy(bp.pack_x(wp, ts)).to(dev)
+    h, tl = torch.from_numpy(head).to(dev), torch.from_numpy(tail).to(dev)
+    order = torch.from_numpy(np.random.default_rng(0).permutation(B).astype(np.int32)).to(dev)
+    ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, ctypes.c_void_p(order.data_ptr()), B))
+    torch.cuda.synchronize()
+    outs = []
+    try:
+        for _ in range(3):
+            st = torch.cuda.Stream(device=dev)
+            ctx.set_stream(st.cuda_stream)
+            with torch.cuda.stream(st):
+                o = dict(x=x0.clone(), costs=torch.zeros(B, 4, dtype=torch.float64, device=dev),
+                         last=torch.zeros(B, 4, dtype=torch.float64, device=dev),
+                         nit=torch.zeros(B, dtype=torch.int32, device=dev), nfev=torch.zeros(B, dtype=torch.int32, device=dev),
+                         status=torch.zeros(B, dtype=torch.int32, device=dev), st=st)
+                bp.optimize_dev(g3, o["x"], h, tl, o["costs"], o["last"], o["nit"], o["nfev"], o["status"])
+            outs.append(o)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_stream(None)
+        ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, None, 0))
+    for o in outs:
+        assert np.array_equal(o["x"].cpu().numpy(), ref["x"])
+        assert np.array_equal(o["nfev"].cpu().numpy(), ref["nfev"])
+        assert np.array_equal(o["costs"].cpu().numpy(), ref["costs"])
+        assert np.array_equal(o["status"].cpu().numpy() & 0xff, ref["status"])
