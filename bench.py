@@ -112,7 +112,7 @@ def _cpu_worker(args):
             pass
         cost = float(np.dot(pl.costs, pl.weights)) if hasattr(pl, "costs") else float("nan")
         nfev = pl.last_result.nfev if pl.last_result is not None else 0
-        done.append((int(b), cost, int(nfev)))
+        done.append((int(b), cost, int(nfev), np.asarray(pl.int_wpts, dtype=np.float64).reshape(-1).copy()))
     return done
 
 
@@ -410,15 +410,26 @@ def main():
             ref = np.array([r[1] for r in cpu_done])
             good = np.isfinite(ref)
 
-            def delta(last_t, nfev_t):
+            cpu_wp = np.stack([r[3] for r in cpu_done])
+
+            def delta(last_t, nfev_t, x_t=None):
                 lc = (last_t * w).sum(dim=1).cpu().numpy()[idx][good]
                 rel = np.abs(lc - ref[good]) / np.maximum(np.abs(ref[good]), 1e-12)
                 same = nfev_t.cpu().numpy()[idx][good] == np.array([r[2] for r in cpu_done])[good]
-                return {"n": int(good.sum()), "median_rel": float(np.median(rel)),
+                extra = {}
+                if x_t is not None:
+                    # final control points: max |x_gpu - x_cpu| / max |x_cpu| per trajectory
+                    gw = x_t[:, :D * (M - 1)].cpu().numpy()[idx][good]
+                    cw = cpu_wp[good]
+                    dx = np.abs(gw - cw).max(axis=1) / np.maximum(np.abs(cw).max(axis=1), 1e-12)
+                    extra = {"control_points_rel_median": float(np.median(dx)),
+                             "control_points_rel_max_on_runs_with_cpu_nfev": float(dx[same].max()) if same.any() else None,
+                             "control_points_frac_within_1e-4": float((dx <= 1e-4).mean())}
+                return {**extra, "n": int(good.sum()), "median_rel": float(np.median(rel)),
                         "frac_within_1e-4": float((rel <= 1e-4).mean()), "frac_within_1e-2": float((rel <= 1e-2).mean()),
                         "frac_same_nfev_as_cpu": float(same.mean()),
                         "gpu_median_cost": float(np.median(lc)), "cpu_median_cost": float(np.median(ref[good]))}
-            out["final_cost_delta_vs_cpu"] = delta(last, nfev)
+            out["final_cost_delta_vs_cpu"] = delta(last, nfev, x)
             if a.dtype != "f64":
                 # the same batch once more with fp64 sampling (parity mode), outside the timed region
                 bp64 = npa.BatchPlanner(ctx=ctx, sample_dtype="f64")
@@ -429,7 +440,7 @@ def main():
                 bp64.optimize_dev(g3, x, d_head, d_tail, costs, last, nit, nfev, status)
                 torch.cuda.synchronize()
                 t64 = time.perf_counter() - t64
-                out["final_cost_delta_vs_cpu_f64_sampling"] = delta(last, nfev)
+                out["final_cost_delta_vs_cpu_f64_sampling"] = delta(last, nfev, x)
                 out["final_cost_delta_vs_cpu_f64_sampling"]["ms_one_batch"] = 1e3 * t64
                 out["final_cost_delta_vs_cpu_f64_sampling"]["traj_per_s_one_batch_at_a_time"] = B / t64
         # RCCL prints a version banner through C stdio; push it out first so that the JSON is the last line
