@@ -497,6 +497,36 @@ __global__ void edt_rows_kernel(const int *__restrict__ g, int W, int H, double 
   }
 }
 
+// Small maps (the reference's 300 x 300): the same two passes by exhaustive minimisation, one thread per cell --
+// W*H*(W+H) integer operations (54 M at 300 x 300) instead of a sequential sweep per line.  Exact integer
+// squared distances, hence the same doubles as the sweeps above (and as SciPy).
+__global__ void edt2_columns_bf_kernel(const int8_t *__restrict__ occ, int W, int H, int *__restrict__ g) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  int d = kEdtInf;
+  for (int q = 0; q < H; ++q) {
+    const int dq = q > y ? q - y : y - q;
+    if (occ[(size_t)q * W + x] == 100 && dq < d) d = dq;
+  }
+  g[(size_t)y * W + x] = d;
+}
+__global__ void edt2_rows_bf_kernel(const int *__restrict__ g, int W, int H, double res, double *__restrict__ dist) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const int *f = g + (size_t)y * W;
+  long long best = -1;
+  for (int p = 0; p < W; ++p) {
+    const int fp = f[p];
+    if (fp >= kEdtInf) continue;
+    const long long dq = x - p;
+    const long long sq = dq * dq + (long long)fp * fp;
+    if (best < 0 || sq < best) best = sq;
+  }
+  // no occupied cell in the whole map: SciPy's virtual background cell at (row -1, column 0), see edt_rows_kernel
+  if (best < 0) best = (long long)(y + 1) * (y + 1) + (long long)x * x;
+  dist[(size_t)y * W + x] = sqrt((double)best) * res;
+}
+
 // ---- 3-D exact EDT (north-star scenes): three separable passes over integer squared distances.
 // pass X: binary occupancy -> squared distance to the nearest occupied voxel along x (two sweeps);
 // pass Y, pass Z: 1-D squared-distance transform of a sampled function (lower envelope of parabolas,
@@ -1272,8 +1302,19 @@ int neo_esdf_build_2d(neo_ctx *c, int scene_id, const int8_t *occ, int W, int H,
   if (!c || !occ || W < 1 || H < 1 || !(res > 0.0)) return NEO_ERR_INVALID;
   std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
-  drop_locked(c, scene_id);
   const size_t ncell = (size_t)W * H;
+  // a map update of the same size keeps its record buffer (no hipFree / hipMalloc per update)
+  void *reuse = nullptr;
+  {
+    auto it = c->maps.find(scene_id);
+    if (it != c->maps.end() && it->second.kind == 0 && it->second.data &&
+        (size_t)it->second.m2.W * it->second.m2.H == ncell) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      reuse = it->second.data;
+      it->second.data = nullptr;
+    }
+  }
+  drop_locked(c, scene_id);
   const size_t need = ncell * (sizeof(int8_t) + 2 * sizeof(int) + 3 * sizeof(double)) +
                       (size_t)H * (W + 1) * sizeof(double) + 4096;
   int rc = ensure_scratch(c, need);
@@ -1289,13 +1330,22 @@ int neo_esdf_build_2d(neo_ctx *c, int scene_id, const int8_t *occ, int W, int H,
   MapEntry e;
   e.kind = 0;
   e.elem = NEO_F64;
-  HIPCHK(c, hipMalloc(&e.data, ncell * sizeof(double4)));
+  if (reuse)
+    e.data = reuse;
+  else
+    HIPCHK(c, hipMalloc(&e.data, ncell * sizeof(double4)));
   HIPCHK(c, hipMemcpyAsync(d_occ, occ, ncell, hipMemcpyHostToDevice, c->stream));
   {
     ProfScope ps(c, NEO_KERNEL_ESDF_BUILD);
-    hipLaunchKernelGGL(edt_columns_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, d_occ, W, H, d_g);
-    hipLaunchKernelGGL(edt_rows_kernel, dim3((H + 63) / 64), dim3(64), 0, c->stream, d_g, W, H, res, d_v, d_z,
-                       d_dist);
+    if (W <= 512 && H <= 512) {
+      const dim3 grid((W + 63) / 64, H);
+      hipLaunchKernelGGL(edt2_columns_bf_kernel, grid, dim3(64), 0, c->stream, d_occ, W, H, d_g);
+      hipLaunchKernelGGL(edt2_rows_bf_kernel, grid, dim3(64), 0, c->stream, d_g, W, H, res, d_dist);
+    } else {
+      hipLaunchKernelGGL(edt_columns_kernel, dim3((W + 63) / 64), dim3(64), 0, c->stream, d_occ, W, H, d_g);
+      hipLaunchKernelGGL(edt_rows_kernel, dim3((H + 63) / 64), dim3(64), 0, c->stream, d_g, W, H, res, d_v, d_z,
+                         d_dist);
+    }
     hipLaunchKernelGGL(gradient_pack_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream,
                        d_dist, W, H, static_cast<double4 *>(e.data), d_gx, d_gy);
   }
