@@ -56,6 +56,7 @@ enum {
   NEO_TRAJ_MAXITER = 3,          /* iteration / evaluation cap                                                */
   NEO_TRAJ_NUMERIC_RANGE = 4,    /* exp(-tau) overflow: the reference raises OverflowError (:481)            */
   NEO_TRAJ_NONFINITE = 5,        /* NaN/Inf objective                                                         */
+  NEO_TRAJ_BAD_SCENE = 6,        /* its map-table slot is outside the table (neo_optimize_batch_dev): left untouched */
 };
 /* OR-ed into the code above when weighted collision cost > collision_cost_tol
  * (expert_planner.py:235-237 raises ValueError("collision cost too large")). */
@@ -124,8 +125,10 @@ int neo_params_set(neo_ctx *ctx, const neo_params *p);
 int neo_ctx_synchronize(neo_ctx *ctx);
 /* stream of the calls that follow (NULL = back to the stream the context was created with).  The `_dev`
  * entry points are asynchronous and only read the context's maps, so a caller may keep several batches in
- * flight on several streams of one context; ordering between the streams (and with map updates, which run on
- * the stream current at the time) is the caller's business. */
+ * flight on several streams of one context; ordering between the batches' streams is the caller's business.
+ * Map updates (neo_esdf_upload_*, neo_esdf_build_*, neo_esdf_drop) wait for ALL work in flight on the device
+ * before they rewrite or free a scene's buffer, so a batch launched before the update reads the old map and one
+ * launched after it the new map; map-table slots (neo_scene_slot) must be re-read after any update. */
 int neo_ctx_set_stream(neo_ctx *ctx, void *stream);
 
 /* ---- maps (map_server/esdf.py) ------------------------------------------- */
@@ -189,9 +192,13 @@ int neo_sampled_terms_batch_dev(neo_ctx *ctx, int scene_id, int B, int M, int D,
 /* ---- optimiser (expert_planner.py:205-237: plan_once) ----------------------
  * Runs L-BFGS-B(maxcor 10, no bounds) from x to termination for every trajectory,
  * entirely on the device.  scene_ids[B] selects the map per trajectory (NULL = all
- * use `scene_id`); all maps of one call must be of the same kind and element type.
+ * use `scene_id`); all maps of one call must be of the same kind (2-D / 3-D), element type
+ * and layout: NEO_ERR_INVALID otherwise.
  * The *_dev variant takes a DEVICE array of map-table slots (neo_scene_slot) in
- * place of scene ids, and `scene_id` then only names the kind of map.
+ * place of scene ids, and `scene_id` then only names the kind of map; since the slots cannot
+ * be inspected from the host, every map of that kind held by the context must then share
+ * `scene_id`'s element type and layout (NEO_ERR_INVALID otherwise), and a slot outside the
+ * table ends that trajectory with NEO_TRAJ_BAD_SCENE.
  *   x[B][n]         in: x0, out: final x (res.x)
  *   costs4[B][4]    unweighted costs at the final x
  *   costs4_last[B][4] unweighted costs at the LAST EVALUATED x -- what the reference

@@ -1,414 +1,15 @@
-// neo_kernels.hip -- kernels and C ABI of libneo_planner_hip.so (gfx950 only).
+// neo_abi.hip -- C ABI of libneo_planner_hip.so (include/neo_planner.h) and the small kernels around the hot path:
 //
-//   eval_kernel      get_cost + get_grad for a batch            (expert_planner.py:539-585)
-//   optimize_kernel  plan_once: the whole L-BFGS-B run on-chip  (expert_planner.py:205-237)
 //   query_kernel     ESDF point lookups                         (map_server/esdf.py:53-82)
 //   edt / gradient   ESDF.occupancy_map_cb                      (map_server/esdf.py:11-33)
 //   traj_state_kernel get_full_state_cmd                        (traj_utils.py:85-195)
 //
-// One 64-lane workgroup (= one wavefront) per trajectory: the optimiser never leaves the chip,
-// finished trajectories free their slot for the next ones, no host round trips.
-#include <hip/hip_runtime.h>
-#include <hip/hip_fp16.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdint>
-#include <cstring>
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../include/neo_planner.h"
-#ifndef NEO_FUSED_U
-#define NEO_FUSED_U (sizeof(Real) == 4 ? 4 : 2)
-#endif
-#ifndef NEO_W2_U
-#define NEO_W2_U 2
-#endif
-#ifndef NEO_W2_MAX_SLOTS
-#define NEO_W2_MAX_SLOTS 2  // two waves per SIMD only up to n = 128 variables (M = 41: +5 % on an fp32 field, -2 % at cfg5)
-#endif
-#include "neo_device.hpp"
-#include "neo_lbfgs.hpp"
-#include "neo_group_kernel.hpp"
+// The fused kernels (eval / optimize / sample) are templates in neo_kernels.hpp, instantiated per family in the
+// neo_disp_*.hip translation units.
+#include "neo_host.hpp"
+#include "neo_kernels.hpp"
 
 namespace neo {
-
-// ------------------------------------------------------------------ device backend of the optimiser
-// SU: samples per lane in flight in the sample loop (minco_sample)
-template <int D, int NS, typename Real, class MapT, class LookupT, int SU = NEO_FUSED_U>
-struct DevBackend {
-  // FLAT layout with NS slots: n <= 64 * NS
-  struct Vec {
-    double v[NS];
-  };
-  Traj<D> t;
-  const DevParams &prm;
-  const MapT &map;
-  double *xs;    // LDS [256]: FLAT <-> PIECE staging
-  double *sc;    // LDS [2m]: rho / alpha of the two-loop recursion
-  LineSearch *lsp;  // LDS: line-search state (wave-uniform)
-  double *cst;      // LDS [12]: cost terms of the last evaluation / current x / previous x
-  double *hist;  // LDS [2][m][n]: the stored (s, y) pairs of this trajectory
-  int npad, m;
-  double *coeff_out;  // optional [6M][D] (eval kernel)
-  long long samples = 0;  // quadrature samples visited so far (lane-uniform), for the bench's byte count
-#ifdef NEO_STAMPS  // timing experiments (tools/gpu_straggler.py): 100 MHz wall-clock ticks per phase
-  long long tk[4] = {0, 0, 0, 0};  // forward, sample, backward, evaluations
-#endif
-
-  __device__ DevBackend(const DevParams &p, const MapT &mp) : prm(p), map(mp) {}
-
-  __device__ __forceinline__ double dot(const Vec &a, const Vec &b) const {
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) s += a.v[k] * b.v[k];
-    return wave_sum(s);
-  }
-  __device__ __forceinline__ double amax(const Vec &a) const {
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) s = fmax(s, fabs(a.v[k]));
-    return wave_max_nonneg(s);
-  }
-  __device__ __forceinline__ void copy(Vec &d, const Vec &s) const {
-#pragma unroll
-    for (int k = 0; k < NS; ++k) d.v[k] = s.v[k];
-  }
-  __device__ __forceinline__ void neg(Vec &d, const Vec &s) const {
-#pragma unroll
-    for (int k = 0; k < NS; ++k) d.v[k] = -s.v[k];
-  }
-  __device__ __forceinline__ void axpy(double a, const Vec &x, Vec &y) const {
-#pragma unroll
-    for (int k = 0; k < NS; ++k) y.v[k] += a * x.v[k];
-  }
-  __device__ __forceinline__ void lincomb(Vec &o, const Vec &a, double s, const Vec &b) const {
-#pragma unroll
-    for (int k = 0; k < NS; ++k) o.v[k] = a.v[k] + s * b.v[k];
-  }
-  __device__ __forceinline__ void scale(Vec &v, double s) const {
-#pragma unroll
-    for (int k = 0; k < NS; ++k) v.v[k] *= s;
-  }
-  __device__ __forceinline__ void hist_put(int slot, const Vec &s, const Vec &y) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int k = 0; k < NS; ++k)
-      if (k * kWave + lane < t.n) {
-        hist[slot * t.n + k * kWave + lane] = s.v[k];
-        hist[(m + slot) * t.n + k * kWave + lane] = y.v[k];
-      }
-    __syncthreads();
-  }
-  __device__ __forceinline__ void hist_get(int row, Vec &v) const {
-    const int lane = lane_id();
-#pragma unroll
-    for (int k = 0; k < NS; ++k) v.v[k] = (k * kWave + lane < t.n) ? hist[row * t.n + k * kWave + lane] : 0.0;
-  }
-  __device__ __forceinline__ void hist_get_s(int slot, Vec &v) const { hist_get(slot, v); }
-  __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
-  __device__ __forceinline__ void sput(int i, double v) {
-    sc[i] = v;
-    __syncthreads();
-  }
-  __device__ __forceinline__ double sget(int i) const { return sc[i]; }
-#ifndef NEO_LS_IN_REGS  // measured: LDS is faster (registers spill: 14.0 vs 15.5 ms at cfg2)
-  __device__ __forceinline__ LineSearch &ls() { return *lsp; }
-  __device__ __forceinline__ double *cost_store() { return cst; }
-#else
-  // registers: with one wave per SIMD the file is not the binding constraint, LDS round trips are
-  LineSearch ls_reg;
-  double cst_reg[12];
-  __device__ __forceinline__ LineSearch &ls() { return ls_reg; }
-  __device__ __forceinline__ double *cost_store() { return cst_reg; }
-#endif
-
-  // FLAT x -> PIECE inputs
-  __device__ __forceinline__ void scatter_x(const Vec &x) {
-    const int lane = lane_id();
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NS; ++k)
-      if (k * kWave + lane < t.n) xs[k * kWave + lane] = x.v[k];
-    __syncthreads();
-    const int M = t.M;
-    const bool act = lane < M;
-    t.tau = act ? xs[t.nq + lane] : 0.0;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      t.P0[d] = (lane == 0 || !act) ? t.head[d] : xs[d * (M - 1) + (lane > 0 ? lane - 1 : 0)];
-      t.P1[d] = (lane >= M - 1) ? t.tail[d] : xs[d * (M - 1) + lane];
-    }
-  }
-
-  // one evaluation of cost and gradient (get_cost + get_grad, :539-585)
-  __device__ __forceinline__ int eval(const Vec &x, double &f, Vec &g, double *costs) {
-    const int lane = lane_id();
-#ifdef NEO_STAMPS
-    const long long s0 = wall_clock64();
-#endif
-    scatter_x(x);
-    double energy, tsum;
-    const int st = minco_forward<D>(t, prm, energy, tsum);
-#ifdef NEO_STAMPS
-    const long long s1 = wall_clock64();
-#endif
-    if (st != 0) {
-      f = 0.0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) costs[k] = 0.0;
-      return st;
-    }
-    samples += (long long)wave_sum(lane < t.M ? t.ns : 0);
-    if (coeff_out != nullptr && lane < t.M) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k)
-#pragma unroll
-        for (int d = 0; d < D; ++d) coeff_out[(size_t)(6 * lane + k) * D + d] = t.c[k][d];
-    }
-    double gC[6][D], gT = 0.0, cf, ck;
-    {
-      Real cr[6][D], gCr[6][D], gTr;
-#pragma unroll
-      for (int k = 0; k < 6; ++k)
-#pragma unroll
-        for (int d = 0; d < D; ++d) cr[k][d] = (Real)t.c[k][d];
-      LookupT lk(map);
-      minco_sample<Real, D, LookupT, SU>(t.M, t.L, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
-#pragma unroll
-      for (int k = 0; k < 6; ++k)
-#pragma unroll
-        for (int d = 0; d < D; ++d) gC[k][d] = (double)gCr[k][d];
-      gT = (double)gTr;
-    }
-#ifdef NEO_STAMPS
-    const long long s2 = wall_clock64();
-#endif
-    costs[0] = uniform(energy);
-    costs[1] = uniform(tsum);
-    costs[2] = uniform(cf);
-    costs[3] = uniform(ck);
-    f = costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3];
-    double gq[D], gtau;
-    const int bst = minco_backward<D>(t, prm, gC, gT, gq, gtau);
-    if (bst != 0) return bst;
-    // PIECE -> FLAT
-    __syncthreads();
-    if (lane >= 1 && lane < t.M) {
-#pragma unroll
-      for (int d = 0; d < D; ++d) xs[d * (t.M - 1) + lane - 1] = gq[d];
-    }
-    if (lane < t.M) xs[t.nq + lane] = gtau;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NS; ++k) g.v[k] = (k * kWave + lane < t.n) ? xs[k * kWave + lane] : 0.0;
-#ifdef NEO_STAMPS
-    const long long s3 = wall_clock64();
-    tk[0] += s1 - s0;
-    tk[1] += s2 - s1;
-    tk[2] += s3 - s2;
-    tk[3] += 1;
-#endif
-    return 0;
-  }
-};
-
-template <int D>
-__device__ __forceinline__ void load_boundary(Traj<D> &t, const double *head, const double *tail, int M) {
-  t.M = M;
-  t.nq = D * (M - 1);
-  t.n = t.nq + M;
-  t.L = sample_lanes_per_piece(M);
-  t.head = head;
-  t.tail = tail;
-}
-
-struct MapTable {
-  const void *maps;  // array of MapT indexed by scene slot
-};
-
-// ------------------------------------------------------------------ kernels
-template <int D, int NS, typename Real, class MapT, class LookupT>
-__global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm, MapT map,
-                                                      const double *__restrict__ x,
-                                                      const double *__restrict__ head,
-                                                      const double *__restrict__ tail,
-                                                      double *__restrict__ cost, double *__restrict__ costs4,
-                                                      double *__restrict__ grad, double *__restrict__ coeffs,
-                                                      int *__restrict__ status) {
-  __shared__ double xs[NS * kWave];
-  __shared__ double sc[2 * NEO_LBFGS_M];
-  __shared__ LineSearch lsm;
-  __shared__ double cst[12];
-  const int b = blockIdx.x;
-  if (b >= B) return;
-  using BE = DevBackend<D, NS, Real, MapT, LookupT>;
-  BE be(prm, map);
-  be.xs = xs;
-  be.sc = sc;
-  be.lsp = &lsm;
-  be.cst = cst;
-  be.hist = nullptr;
-  be.m = NEO_LBFGS_M;
-  load_boundary<D>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
-  const int n = be.t.n;
-  be.npad = NS * kWave;
-  be.coeff_out = coeffs ? coeffs + (size_t)b * 6 * M * D : nullptr;
-  const int lane = lane_id();
-  typename BE::Vec xv, gv;
-#pragma unroll
-  for (int k = 0; k < NS; ++k) xv.v[k] = (k * kWave + lane < n) ? x[(size_t)b * n + k * kWave + lane] : 0.0;
-  double f;
-  double *costs = cst;
-  const int st = be.eval(xv, f, gv, costs);
-#pragma unroll
-  for (int k = 0; k < NS; ++k)
-    if (k * kWave + lane < n) grad[(size_t)b * n + k * kWave + lane] = gv.v[k];
-  if (lane == 0) {
-    cost[b] = f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) costs4[(size_t)b * 4 + k] = costs[k];
-    if (status) status[b] = st;
-  }
-}
-
-// WAVES = wavefronts per SIMD the register allocation aims at.  1: the whole file (256 VGPRs + AGPRs) for one
-// trajectory -- the shortest evaluation, for batches that leave SIMDs to spare.  2: half the file, some state
-// spilled to scratch -- each evaluation is slower, but two trajectories share a SIMD's issue slots, which wins
-// once the batch queues for the 1024 SIMDs anyway (cfg2 with several batches in flight: +10 %).  Same
-// source, same arithmetic, bit-identical results.
-template <int D, int NS, typename Real, class MapT, class LookupT, int WAVES>
-__global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
-                                                          const int *__restrict__ scene_slot,
-                                                          double *__restrict__ x,
-                                                          const double *__restrict__ head,
-                                                          const double *__restrict__ tail,
-                                                          double *__restrict__ costs4,
-                                                          double *__restrict__ costs4_last,
-                                                          int *__restrict__ nit, int *__restrict__ nfev,
-                                                          int *__restrict__ status,
-                                                          long long *__restrict__ nsamples,
-                                                          const int *__restrict__ order) {
-  __shared__ double xs[NS * kWave];
-  __shared__ double sc[2 * NEO_LBFGS_M];
-  __shared__ LineSearch lsm;
-  __shared__ double cst[12];
-  if ((int)blockIdx.x >= B) return;
-  // workgroups are dispatched in index order: `order` lets the caller start the runs it expects to
-  // be long first (list scheduling: a long run that starts last sets the duration of the launch)
-  const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
-  // the two-waves variant has half the registers: two samples per lane in flight instead of four (with the lean
-  // Horner form, cfg2 with three batches in flight: 414 k -> 541 k traj/s; scratch 640 -> 336 B per lane)
-  using BE = DevBackend<D, NS, Real, MapT, LookupT, (WAVES == 2 ? NEO_W2_U : NEO_FUSED_U)>;
-  const MapT map = maps[scene_slot ? scene_slot[b] : 0];
-  BE be(prm, map);
-  be.xs = xs;
-  be.sc = sc;
-  be.lsp = &lsm;
-  be.cst = cst;
-  be.m = NEO_LBFGS_M;
-  be.coeff_out = nullptr;
-  load_boundary<D>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
-  const int n = be.t.n;
-  be.npad = NS * kWave;
-  extern __shared__ double dyn_lds[];  // 2 * maxcor * n doubles (launch parameter)
-  be.hist = dyn_lds;
-  const int lane = lane_id();
-  typename BE::Vec xv;
-#pragma unroll
-  for (int k = 0; k < NS; ++k) xv.v[k] = (k * kWave + lane < n) ? x[(size_t)b * n + k * kWave + lane] : 0.0;
-  LbfgsOpts o{prm.ftol, prm.gtol, prm.maxls, prm.maxiter, prm.maxfun, NEO_LBFGS_M};
-  LbfgsResult res;
-#ifdef NEO_STAMPS
-  const long long k0 = wall_clock64();
-#endif
-  lbfgs_minimize(be, xv, o, res);
-#ifdef NEO_STAMPS
-  if (lane == 0 && nsamples) {  // the counter buffer is [B][8] in this build
-    long long *o8 = nsamples + (size_t)b * 8;
-    o8[1] = be.tk[3]; o8[2] = be.tk[0]; o8[3] = be.tk[1]; o8[4] = be.tk[2];
-    o8[5] = wall_clock64() - k0; o8[6] = k0; o8[7] = blockIdx.x;
-    o8[0] = be.samples;
-  }
-  nsamples = nullptr;
-#endif
-#pragma unroll
-  for (int k = 0; k < NS; ++k)
-    if (k * kWave + lane < n) x[(size_t)b * n + k * kWave + lane] = xv.v[k];
-  if (lane == 0) {
-    int st = res.status;
-    // weighted collision cost of the last evaluated x against the tolerance (:233-237)
-    if (res.costs_last[3] * prm.w[3] > prm.coll_tol) st |= NEO_TRAJ_FLAG_COLLISION;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      costs4[(size_t)b * 4 + k] = res.costs[k];
-      if (costs4_last) costs4_last[(size_t)b * 4 + k] = res.costs_last[k];
-    }
-    nit[b] = res.nit;
-    nfev[b] = res.nfev;
-    status[b] = st;
-    if (nsamples) nsamples[b] = be.samples;
-  }
-}
-
-// add_sampled_cost + add_sampled_grad_CT (expert_planner.py:392-466) as a kernel of its own: the ESDF
-// lookup kernel.  Input: polynomial coefficients and durations; output: the two sampled cost terms and
-// their partials w.r.t. coefficients and durations.  One wavefront per trajectory; every lane reads the
-// coefficients of its piece straight into the SAMPLE layout and the first lane of each piece writes the
-// piece's partials.  fp32: <= 128 VGPRs, so four waves per SIMD -- the whole cfg2 batch is resident at once and
-// the gathers of different trajectories overlap (one sample per lane in flight is enough then).
-#ifndef NEO_SAMPLE_U
-#define NEO_SAMPLE_U 1
-#endif
-template <int D, typename Real, class MapT, class LookupT>
-__global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? 4 : 2) void sample_kernel(int B, int M, DevParams prm, MapT map,
-                                                                                  const double *__restrict__ coeffs,
-                                                                                  const double *__restrict__ ts,
-                                                                                  double *__restrict__ costs2,
-                                                                                  double *__restrict__ grad_C,
-                                                                                  double *__restrict__ grad_T) {
-  const int b = blockIdx.x;
-  if (b >= B) return;
-  const int lane = lane_id();
-  const int L = sample_lanes_per_piece(M);
-  const int piece = (lane * ((65536 + L - 1) / L)) >> 16;
-  const int r = lane - piece * L;
-  const bool act = piece < M;
-  const double T = act ? ts[(size_t)b * M + piece] : 1.0;
-  const int ns = act ? (int)(T / prm.delta_t) : 0;
-  Real c[6][D], gC[6][D], gT;
-  {
-    // the 6*D doubles of a piece are contiguous and 16-byte aligned (6*D is even)
-    const double2 *src = reinterpret_cast<const double2 *>(coeffs + ((size_t)b * 6 * M + 6 * (act ? piece : 0)) * D);
-#pragma unroll
-    for (int q = 0; q < 3 * D; ++q) {
-      const double2 v = src[q];
-      const int e0 = 2 * q, e1 = 2 * q + 1;
-      c[e0 / D][e0 % D] = act ? (Real)v.x : Real(0);
-      c[e1 / D][e1 % D] = act ? (Real)v.y : Real(0);
-    }
-  }
-  double cf, ck;
-  LookupT lk(map);
-  minco_sample<Real, D, LookupT, NEO_SAMPLE_U, true>(M, L, ns, c, prm, lk, gC, gT, cf, ck);
-  if (act && r == 0) {
-    double2 *dst = reinterpret_cast<double2 *>(grad_C + ((size_t)b * 6 * M + 6 * piece) * D);
-#pragma unroll
-    for (int q = 0; q < 3 * D; ++q) {
-      const int e0 = 2 * q, e1 = 2 * q + 1;
-      dst[q] = make_double2((double)gC[e0 / D][e0 % D], (double)gC[e1 / D][e1 % D]);
-    }
-    grad_T[(size_t)b * M + piece] = (double)gT;
-  }
-  if (lane == 0) {
-    costs2[(size_t)b * 2 + 0] = cf;
-    costs2[(size_t)b * 2 + 1] = ck;
-  }
-}
 
 template <typename Real, class MapT, class LookupT, int DM>
 __global__ void query_kernel(int n, MapT map, const double *__restrict__ pts, double *__restrict__ dist,
@@ -766,65 +367,6 @@ using namespace neo;
 
 namespace {
 
-struct MapEntry {
-  int kind = -1;  // 0 = 2-D reference map, 1 = 3-D field
-  int elem = NEO_F64;
-  void *data = nullptr;  // device
-  Map2D m2{};
-  Map3D m3{};
-  int slot = -1;  // index into the device-side map table
-};
-
-struct ProfileSlot {
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-  int64_t launches = 0;
-  double ms = 0.0;
-};
-
-}  // namespace
-
-struct neo_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  hipStream_t home_stream = nullptr;  // the stream of neo_ctx_create (neo_ctx_set_stream(NULL) returns to it)
-  neo_params params{};
-  DevParams dev{};
-  std::map<int, MapEntry> maps;
-  std::string err;
-  std::recursive_mutex mu;  // recursive: the host-pointer entry points hold it across their *_dev call
-  int *tickets = nullptr;  // ring of work counters for optimize_group_kernel launches (one per launch in flight)
-  unsigned ticket_next = 0;
-  // device-side table of maps (rebuilt when a map changes)
-  void *table2d = nullptr, *table3d = nullptr;
-  int n2d = 0, n3d = 0;
-  bool table_dirty = true;
-  // scratch for the host-pointer entry points
-  void *scratch = nullptr;
-  size_t scratch_bytes = 0;
-  bool profile = false;
-  ProfileSlot prof[NEO_KERNEL_COUNT];
-  long long *sample_counter = nullptr;  // optional device array [B] (neo_optimize_sample_counter)
-  const int *dispatch_order = nullptr;  // optional device permutation [B] (neo_optimize_dispatch_order)
-  int order_B = 0;                      // batch size the permutation was given for (ignored for any other B)
-  int *order_buf = nullptr;             // device copy of a host permutation (neo_optimize_dispatch_order_host)
-  size_t order_cap = 0;
-};
-
-namespace {
-
-int fail(neo_ctx *c, int code, const std::string &msg) {
-  if (c) c->err = msg;
-  return code;
-}
-
-#define HIPCHK(c, call)                                                                     \
-  do {                                                                                      \
-    hipError_t e_ = (call);                                                                 \
-    if (e_ != hipSuccess)                                                                   \
-      return fail(c, NEO_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));       \
-  } while (0)
-
 void fill_dev_params(neo_ctx *c) {
   const neo_params &p = c->params;
   DevParams &d = c->dev;
@@ -843,25 +385,6 @@ void fill_dev_params(neo_ctx *c) {
   d.stale_T = p.bugcompat_stale_T;
   d.dbg = p.flags;
 }
-
-struct ProfScope {
-  neo_ctx *c;
-  int k;
-  hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(neo_ctx *c_, int k_) : c(c_), k(k_) {
-    if (c->profile) {
-      hipEventCreate(&a);
-      hipEventCreate(&b);
-      hipEventRecord(a, c->stream);
-    }
-  }
-  ~ProfScope() {
-    if (c->profile) {
-      hipEventRecord(b, c->stream);
-      c->prof[k].pending.emplace_back(a, b);
-    }
-  }
-};
 
 int ensure_scratch(neo_ctx *c, size_t bytes) {
   if (bytes <= c->scratch_bytes) return NEO_OK;
@@ -919,221 +442,39 @@ int rebuild_tables(neo_ctx *c) {
   return NEO_OK;
 }
 
+// (callers do not hold the context lock yet: take it for the error string)
 int check_shape(neo_ctx *c, int B, int M, int D) {
   if (!c) return NEO_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   if (B < 0 || M < 1 || M > NEO_MAX_PIECES || D < 2 || D > NEO_MAX_DIM)
     return fail(c, NEO_ERR_INVALID, "shape out of range (1 <= M <= 64, D in {2,3})");
   if (D * (M - 1) + M > kSlots * kWave) return fail(c, NEO_ERR_INVALID, "n = D(M-1)+M exceeds 256");
   return NEO_OK;
 }
 
-// ---- dispatch over (D, slots, sample dtype, map kind, element type) ---------------
-int slots_for(int M, int D) {
-  const int n = D * (M - 1) + M;
-  const int ns = (n + kWave - 1) / kWave;
-  return ns <= 1 ? 1 : (ns == 2 ? 2 : 4);
-}
-
-struct EvalArgs {
-  int B, M;
-  const double *x, *head, *tail;
-  double *cost, *costs4, *grad, *coeffs;
-  int *status;
-};
-
-template <int D, typename Real, class MapT, class LookupT>
-int launch_eval(neo_ctx *c, const MapT &map, const EvalArgs &a) {
-  const dim3 grid(a.B), blk(kWave);
-#define NEO_EVAL(NS)                                                                                         \
-  hipLaunchKernelGGL((eval_kernel<D, NS, Real, MapT, LookupT>), grid, blk, 0, c->stream, a.B, a.M, c->dev, map, \
-                     a.x, a.head, a.tail, a.cost, a.costs4, a.grad, a.coeffs, a.status)
-  switch (slots_for(a.M, D)) {
-    case 1: NEO_EVAL(1); break;
-    case 2: NEO_EVAL(2); break;
-    default: NEO_EVAL(4); break;
-  }
-#undef NEO_EVAL
-  return NEO_OK;
-}
-
-int dispatch_eval(neo_ctx *c, const MapEntry &e, int D, const EvalArgs &a) {
-#ifdef NEO_SLIM_BUILD  // kernel experiments (tools/probe): only the cfg2 instantiation compiles, in 20 s
-  if (e.kind != 0 && D == 3 && e.elem == NEO_F32 && e.m3.layout == 0 && c->params.sample_dtype == NEO_F32)
-    return launch_eval<3, float, Map3D, Lookup3D<float, float, 0>>(c, e.m3, a);
-  return fail(c, NEO_ERR_INVALID, "slim build: cfg2 kernels only");
-#else
-  const bool f32 = c->params.sample_dtype == NEO_F32;
-  if (e.kind == 0) {
-    if (D == 2)
-      return f32 ? launch_eval<2, float, Map2D, Lookup2D<float>>(c, e.m2, a)
-                 : launch_eval<2, double, Map2D, Lookup2D<double>>(c, e.m2, a);
-    return f32 ? launch_eval<3, float, Map2D, Lookup2D<float>>(c, e.m2, a)
-               : launch_eval<3, double, Map2D, Lookup2D<double>>(c, e.m2, a);
-  }
-  if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
-#define NEO_3D(LAY)                                                                                  \
-  if (e.elem == NEO_F32)                                                                             \
-    return f32 ? launch_eval<3, float, Map3D, Lookup3D<float, float, LAY>>(c, e.m3, a)               \
-               : launch_eval<3, double, Map3D, Lookup3D<double, float, LAY>>(c, e.m3, a);            \
-  return f32 ? launch_eval<3, float, Map3D, Lookup3D<float, __half, LAY>>(c, e.m3, a)                \
-             : launch_eval<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, e.m3, a);
-  if (e.m3.layout == 0) { NEO_3D(0) }
-  if (e.m3.layout == 2) { NEO_3D(2) }
-  NEO_3D(1)
-#undef NEO_3D
-#endif
-}
 
 constexpr int kTwoWavesFromBatch = 4096;  // 4 trajectories per SIMD of an MI355X (measured: 2048 -> one wave is
                                           // faster, 9.1 vs 10.1 ms; 4096 -> two are, 11.0 vs 13.6 ms)
 
-struct OptArgs {
-  int B, M;
-  const void *table;
-  const int *slots;
-  double *x;
-  const double *head, *tail;
-  double *costs4, *costs4_last;
-  int *nit, *nfev, *status;
-};
-
-template <int D, typename Real, class MapT, class LookupT, int WAVES = 1>
-int launch_opt(neo_ctx *c, const OptArgs &a) {
-  const dim3 grid(a.B), blk(kWave);
-  const size_t dyn = (size_t)2 * NEO_LBFGS_M * (D * (a.M - 1) + a.M) * sizeof(double);  // L-BFGS pairs in LDS
-#define NEO_OPT(NS)                                                                                           \
-  hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES>), grid, blk, dyn, c->stream, a.B, a.M, c->dev, \
-                     static_cast<const MapT *>(a.table), a.slots, a.x, a.head, a.tail, a.costs4,      \
-                     a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter,                                \
-                     (c->order_B == a.B ? c->dispatch_order : nullptr))
-  switch (slots_for(a.M, D)) {
-    case 1: NEO_OPT(1); break;
-    case 2: NEO_OPT(2); break;
-    default:
-      if constexpr (WAVES == 1 || NEO_W2_MAX_SLOTS >= 4) NEO_OPT(4);  // (two waves only up to NEO_W2_MAX_SLOTS)
-      break;
-  }
-#undef NEO_OPT
-  return NEO_OK;
-}
-
-constexpr int kTicketRing = 64;
-
-template <typename Real, class LookupT, int W, int NS>
-int launch_group_w(neo_ctx *c, const OptArgs &a) {
-  constexpr int D = 3, G = kWave / W;
-  if (!c->tickets) {
-    HIPCHK(c, hipMalloc((void **)&c->tickets, kTicketRing * sizeof(int)));
-  }
-  int *ticket = c->tickets + (c->ticket_next++ % kTicketRing);
-  HIPCHK(c, hipMemsetAsync(ticket, 0, sizeof(int), c->stream));
-  const int n = D * (a.M - 1) + a.M;
-  const size_t dyn = (size_t)G * 2 * NEO_LBFGS_M * n * sizeof(double);
-  const int waves = std::min((a.B + G - 1) / G, 4096);  // persistent groups: they draw trajectories off the ticket
-  hipLaunchKernelGGL((optimize_group_kernel<D, Real, Map3D, LookupT, W, NS>), dim3(waves), dim3(kWave), dyn, c->stream,
-                     a.B, a.M, c->dev, static_cast<const Map3D *>(a.table), a.x, a.head, a.tail, a.costs4, a.costs4_last,
-                     a.nit, a.nfev, a.status, c->sample_counter, (c->order_B == a.B ? c->dispatch_order : nullptr),
-                     ticket);
-  return NEO_OK;
-}
-
-// n <= 16: eight trajectories per wavefront when the pieces fit 8 lanes (flags bit 256: sixteen-lane groups, for
-// comparison), else four
-template <typename Real, class LookupT>
-int launch_group(neo_ctx *c, const OptArgs &a) {
-  const int n = 3 * (a.M - 1) + a.M;
-  if (n > 16) return launch_group_w<Real, LookupT, 16, 2>(c, a);  // n <= 32 (M <= 8): four per wavefront, two slots
-  if (a.M <= 8 && !(c->params.flags & 256)) return launch_group_w<Real, LookupT, 8, 2>(c, a);
-  return launch_group_w<Real, LookupT, 16, 1>(c, a);
+int fail_locked(neo_ctx *c, int code, const char *msg) {
+  std::lock_guard<std::recursive_mutex> g(c->mu);
+  return fail(c, code, msg);
 }
 
 int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArgs &a) {
-#ifdef NEO_SLIM_BUILD  // kernel experiments (tools/probe): only the cfg2 instantiation compiles, in 20 s
-  if (kind != 0 && D == 3 && elem == NEO_F32 && layout == 0 && c->params.sample_dtype == NEO_F32) {
-    if ((c->params.flags & NEO_FLAG_LANE_GROUPS) && !a.slots && a.M <= 16 && D * (a.M - 1) + a.M <= 32)
-      return launch_group<float, Lookup3D<float, float, 0>>(c, a);
-    const bool two2 = (c->params.flags & NEO_FLAG_TWO_WAVES_PER_SIMD) && slots_for(a.M, D) <= NEO_W2_MAX_SLOTS;
-    return two2 ? launch_opt<3, float, Map3D, Lookup3D<float, float, 0>, 2>(c, a)
-                : launch_opt<3, float, Map3D, Lookup3D<float, float, 0>>(c, a);
-  }
-  return fail(c, NEO_ERR_INVALID, "slim build: cfg2 kernels only");
-#else
   const bool f32 = c->params.sample_dtype == NEO_F32;
-  if (kind == 0) {
-    if (D == 2)
-      return f32 ? launch_opt<2, float, Map2D, Lookup2D<float>>(c, a) : launch_opt<2, double, Map2D, Lookup2D<double>>(c, a);
-    return f32 ? launch_opt<3, float, Map2D, Lookup2D<float>>(c, a) : launch_opt<3, double, Map2D, Lookup2D<double>>(c, a);
-  }
+  if (kind == 0) return launch_opt_2d(c, D, f32, a);
   if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
+  const int fl = c->params.flags;
+  if ((fl & NEO_FLAG_LANE_GROUPS) && f32 && layout == 0 && !a.slots && a.M <= 16 && D * (a.M - 1) + a.M <= 32)
+    return launch_opt_groups(c, elem, a);
   // two trajectories per SIMD for calls that queue for the SIMDs anyway (3-D fields, fp32 sampling, the
   // linear and cell-packed layouts, n <= 128: beyond that the spills cost more than the sharing gains)
-  const int fl = c->params.flags;
-  if ((fl & NEO_FLAG_LANE_GROUPS) && f32 && layout == 0 && !a.slots && a.M <= 16 && D * (a.M - 1) + a.M <= 32) {
-    if (elem == NEO_F32) return launch_group<float, Lookup3D<float, float, 0>>(c, a);
-    return launch_group<float, Lookup3D<float, __half, 0>>(c, a);
-  }
   const bool two = f32 && layout != 1 && slots_for(a.M, D) <= NEO_W2_MAX_SLOTS &&
                    ((a.B >= kTwoWavesFromBatch && !(fl & NEO_FLAG_ONE_WAVE_PER_SIMD)) || (fl & NEO_FLAG_TWO_WAVES_PER_SIMD));
-#define NEO_3D(LAY)                                                                       \
-  if (elem == NEO_F32)                                                                    \
-    return f32 ? launch_opt<3, float, Map3D, Lookup3D<float, float, LAY>>(c, a)           \
-               : launch_opt<3, double, Map3D, Lookup3D<double, float, LAY>>(c, a);        \
-  return f32 ? launch_opt<3, float, Map3D, Lookup3D<float, __half, LAY>>(c, a)            \
-             : launch_opt<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, a);
-#define NEO_3D2(LAY)                                                                      \
-  if (elem == NEO_F32) return launch_opt<3, float, Map3D, Lookup3D<float, float, LAY>, 2>(c, a); \
-  return launch_opt<3, float, Map3D, Lookup3D<float, __half, LAY>, 2>(c, a);
-  if (two && layout == 0) { NEO_3D2(0) }
-  if (two && layout == 2) { NEO_3D2(2) }
-  if (layout == 0) { NEO_3D(0) }
-  if (layout == 2) { NEO_3D(2) }
-  NEO_3D(1)
-#undef NEO_3D
-#undef NEO_3D2
-#endif
+  if (two) return launch_opt_3d_w2(c, elem, layout, a);
+  return f32 ? launch_opt_3d_f32(c, elem, layout, a) : launch_opt_3d_f64(c, elem, layout, a);
 }
-
-struct SampleArgs {
-  int B, M;
-  const double *coeffs, *ts;
-  double *costs2, *grad_C, *grad_T;
-};
-
-template <int D, typename Real, class MapT, class LookupT>
-int launch_sample(neo_ctx *c, const MapT &map, const SampleArgs &a) {
-  hipLaunchKernelGGL((sample_kernel<D, Real, MapT, LookupT>), dim3(a.B), dim3(kWave), 0, c->stream, a.B, a.M, c->dev,
-                     map, a.coeffs, a.ts, a.costs2, a.grad_C, a.grad_T);
-  return NEO_OK;
-}
-
-int dispatch_sample(neo_ctx *c, const MapEntry &e, int D, const SampleArgs &a) {
-#ifdef NEO_SLIM_BUILD  // kernel experiments (tools/probe): only the cfg2 instantiation compiles, in 20 s
-  if (e.kind != 0 && D == 3 && e.elem == NEO_F32 && e.m3.layout == 0 && c->params.sample_dtype == NEO_F32)
-    return launch_sample<3, float, Map3D, Lookup3D<float, float, 0>>(c, e.m3, a);
-  return fail(c, NEO_ERR_INVALID, "slim build: cfg2 kernels only");
-#else
-  const bool f32 = c->params.sample_dtype == NEO_F32;
-  if (e.kind == 0) {
-    if (D == 2)
-      return f32 ? launch_sample<2, float, Map2D, Lookup2D<float>>(c, e.m2, a)
-                 : launch_sample<2, double, Map2D, Lookup2D<double>>(c, e.m2, a);
-    return f32 ? launch_sample<3, float, Map2D, Lookup2D<float>>(c, e.m2, a)
-               : launch_sample<3, double, Map2D, Lookup2D<double>>(c, e.m2, a);
-  }
-  if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
-#define NEO_3D(LAY)                                                                                  \
-  if (e.elem == NEO_F32)                                                                             \
-    return f32 ? launch_sample<3, float, Map3D, Lookup3D<float, float, LAY>>(c, e.m3, a)             \
-               : launch_sample<3, double, Map3D, Lookup3D<double, float, LAY>>(c, e.m3, a);          \
-  return f32 ? launch_sample<3, float, Map3D, Lookup3D<float, __half, LAY>>(c, e.m3, a)              \
-             : launch_sample<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, e.m3, a);
-  if (e.m3.layout == 0) { NEO_3D(0) }
-  if (e.m3.layout == 2) { NEO_3D(2) }
-  NEO_3D(1)
-#undef NEO_3D
-#endif
-}
-
 
 void drain_profile(neo_ctx *c) {
   for (int k = 0; k < NEO_KERNEL_COUNT; ++k) {
@@ -1248,14 +589,22 @@ int neo_params_set(neo_ctx *c, const neo_params *p) {
 
 int neo_ctx_synchronize(neo_ctx *c) {
   if (!c) return NEO_ERR_INVALID;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipStream_t st;
+  {
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    st = c->stream;
+  }
+  const hipError_t e = hipStreamSynchronize(st);  // (not under the lock: other threads may keep launching)
+  if (e != hipSuccess) return fail_locked(c, NEO_ERR_HIP, hipGetErrorString(e));
   return NEO_OK;
 }
 
+// Map updates wait for ALL device work first (hipDeviceSynchronize), not only for the context's current stream:
+// `_dev` launches of neo_ctx_set_stream callers may still be reading the scene's buffer on other streams.
 static int drop_locked(neo_ctx *c, int scene_id) {
   auto it = c->maps.find(scene_id);
   if (it != c->maps.end()) {
-    hipStreamSynchronize(c->stream);
+    hipDeviceSynchronize();
     if (it->second.data) hipFree(it->second.data);
     c->maps.erase(it);
     c->table_dirty = true;
@@ -1284,41 +633,25 @@ int neo_esdf_upload_2d(neo_ctx *c, int scene_id, const double *dist, const doubl
   MapEntry e;
   e.kind = 0;
   e.elem = NEO_F64;
-  HIPCHK(c, hipMalloc(&e.data, ncell * sizeof(double4)));
+  DevBuf rec;
+  HIPCHK(c, rec.alloc(ncell * sizeof(double4)));
   HIPCHK(c, hipMemcpyAsync(d0, dist, ncell * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d1, gx, ncell * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d2, gy, ncell * sizeof(double), hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(pack2d_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, d0, d1, d2,
-                     (int)ncell, static_cast<double4 *>(e.data));
+                     (int)ncell, rec.as<double4>());
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  e.data = rec.release();
   e.m2 = Map2D{static_cast<const double4 *>(e.data), W, H, res, ox, oy};
   c->maps[scene_id] = e;
   c->table_dirty = true;
   return NEO_OK;
 }
 
-int neo_esdf_build_2d(neo_ctx *c, int scene_id, const int8_t *occ, int W, int H, double res, double ox, double oy,
-                      double *out_dist, double *out_gx, double *out_gy) {
-  if (!c || !occ || W < 1 || H < 1 || !(res > 0.0)) return NEO_ERR_INVALID;
-  std::lock_guard<std::recursive_mutex> g(c->mu);
-  hipSetDevice(c->device);
+// the device work of neo_esdf_build_2d into `rec`; scratch carved by the caller
+static int build_2d_into(neo_ctx *c, double4 *rec, const int8_t *occ, int W, int H, double res, double *out_dist,
+                         double *out_gx, double *out_gy) {
   const size_t ncell = (size_t)W * H;
-  // a map update of the same size keeps its record buffer (no hipFree / hipMalloc per update)
-  void *reuse = nullptr;
-  {
-    auto it = c->maps.find(scene_id);
-    if (it != c->maps.end() && it->second.kind == 0 && it->second.data &&
-        (size_t)it->second.m2.W * it->second.m2.H == ncell) {
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      reuse = it->second.data;
-      it->second.data = nullptr;
-    }
-  }
-  drop_locked(c, scene_id);
-  const size_t need = ncell * (sizeof(int8_t) + 2 * sizeof(int) + 3 * sizeof(double)) +
-                      (size_t)H * (W + 1) * sizeof(double) + 4096;
-  int rc = ensure_scratch(c, need);
-  if (rc) return rc;
   Carver cv(c->scratch);
   int8_t *d_occ = cv.take<int8_t>(ncell);
   int *d_g = cv.take<int>(ncell);
@@ -1327,13 +660,6 @@ int neo_esdf_build_2d(neo_ctx *c, int scene_id, const int8_t *occ, int W, int H,
   double *d_dist = cv.take<double>(ncell);
   double *d_gx = cv.take<double>(ncell);
   double *d_gy = cv.take<double>(ncell);
-  MapEntry e;
-  e.kind = 0;
-  e.elem = NEO_F64;
-  if (reuse)
-    e.data = reuse;
-  else
-    HIPCHK(c, hipMalloc(&e.data, ncell * sizeof(double4)));
   HIPCHK(c, hipMemcpyAsync(d_occ, occ, ncell, hipMemcpyHostToDevice, c->stream));
   {
     ProfScope ps(c, NEO_KERNEL_ESDF_BUILD);
@@ -1347,12 +673,52 @@ int neo_esdf_build_2d(neo_ctx *c, int scene_id, const int8_t *occ, int W, int H,
                          d_dist);
     }
     hipLaunchKernelGGL(gradient_pack_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream,
-                       d_dist, W, H, static_cast<double4 *>(e.data), d_gx, d_gy);
+                       d_dist, W, H, rec, d_gx, d_gy);
   }
+  HIPCHK(c, hipGetLastError());
   if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, d_dist, ncell * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (out_gx) HIPCHK(c, hipMemcpyAsync(out_gx, d_gx, ncell * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (out_gy) HIPCHK(c, hipMemcpyAsync(out_gy, d_gy, ncell * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NEO_OK;
+}
+
+int neo_esdf_build_2d(neo_ctx *c, int scene_id, const int8_t *occ, int W, int H, double res, double ox, double oy,
+                      double *out_dist, double *out_gx, double *out_gy) {
+  if (!c || !occ || W < 1 || H < 1 || !(res > 0.0)) return NEO_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> g(c->mu);
+  hipSetDevice(c->device);
+  const size_t ncell = (size_t)W * H;
+  const size_t need = ncell * (sizeof(int8_t) + 2 * sizeof(int) + 3 * sizeof(double)) +
+                      (size_t)H * (W + 1) * sizeof(double) + 4096;
+  int rc = ensure_scratch(c, need);
+  if (rc) return rc;
+  // a map update of the same size rewrites the scene's record buffer in place (no hipFree / hipMalloc per
+  // update), once nothing on the device can still be reading it
+  auto it = c->maps.find(scene_id);
+  const bool reuse = it != c->maps.end() && it->second.kind == 0 && it->second.data &&
+                     (size_t)it->second.m2.W * it->second.m2.H == ncell;
+  if (reuse) {
+    HIPCHK(c, hipDeviceSynchronize());
+    rc = build_2d_into(c, static_cast<double4 *>(it->second.data), occ, W, H, res, out_dist, out_gx, out_gy);
+    if (rc) {
+      drop_locked(c, scene_id);  // the buffer may be half rewritten: the scene has no map any more
+      return rc;
+    }
+    const Map2D m{static_cast<const double4 *>(it->second.data), W, H, res, ox, oy};
+    if (memcmp(&m, &it->second.m2, sizeof(m)) != 0) c->table_dirty = true;  // same buffer: usually the same descriptor
+    it->second.m2 = m;
+    return NEO_OK;
+  }
+  drop_locked(c, scene_id);
+  DevBuf rec;
+  HIPCHK(c, rec.alloc(ncell * sizeof(double4)));
+  rc = build_2d_into(c, rec.as<double4>(), occ, W, H, res, out_dist, out_gx, out_gy);
+  if (rc) return rc;
+  MapEntry e;
+  e.kind = 0;
+  e.elem = NEO_F64;
+  e.data = rec.release();
   e.m2 = Map2D{static_cast<const double4 *>(e.data), W, H, res, ox, oy};
   c->maps[scene_id] = e;
   c->table_dirty = true;
@@ -1362,12 +728,15 @@ int neo_esdf_build_2d(neo_ctx *c, int scene_id, const int8_t *occ, int W, int H,
 int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype, int src_is_device, int nx, int ny,
                        int nz, double res, const double origin[3], int store_dtype, int layout) {
   if (!c || !dist || !origin || nx < 2 || ny < 2 || nz < 2 || !(res > 0.0)) return NEO_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   if (src_dtype != NEO_F64 && src_dtype != NEO_F32) return fail(c, NEO_ERR_INVALID, "src_dtype must be f64 or f32");
   if (store_dtype != NEO_F32 && store_dtype != NEO_F16)
     return fail(c, NEO_ERR_INVALID, "store_dtype must be f32 or f16");
   if (layout != NEO_LAYOUT_LINEAR && layout != NEO_LAYOUT_BRICK4 && layout != NEO_LAYOUT_CELL8)
     return fail(c, NEO_ERR_INVALID, "bad layout");
-  std::lock_guard<std::recursive_mutex> g(c->mu);
+  // the lookups form voxel indices with 24-bit multiplies: (iz * ny + iy) * nx + ix
+  if ((size_t)ny * nz >= ((size_t)1 << 24) || (size_t)nx >= ((size_t)1 << 24))
+    return fail(c, NEO_ERR_INVALID, "field too large: ny * nz and nx must be below 2^24");
   hipSetDevice(c->device);
   drop_locked(c, scene_id);
   const size_t nvox = (size_t)nx * ny * nz;
@@ -1376,42 +745,43 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
   const size_t nstore = layout == NEO_LAYOUT_BRICK4 ? (size_t)bx * by * bz * 64 : (layout == NEO_LAYOUT_CELL8 ? nvox * 8 : nvox);
   if ((nstore + 64) * dsz >= (size_t)4 << 30) return fail(c, NEO_ERR_INVALID, "field too large for 32-bit buffer offsets in this layout");
   const void *src = dist;
-  void *staged = nullptr;
+  DevBuf staged, field;
   if (!src_is_device) {
-    HIPCHK(c, hipMalloc(&staged, nvox * ssz));
-    HIPCHK(c, hipMemcpyAsync(staged, dist, nvox * ssz, hipMemcpyHostToDevice, c->stream));
-    src = staged;
+    HIPCHK(c, staged.alloc(nvox * ssz));
+    HIPCHK(c, hipMemcpyAsync(staged.p, dist, nvox * ssz, hipMemcpyHostToDevice, c->stream));
+    src = staged.p;
   }
   MapEntry e;
   e.kind = 1;
   e.elem = store_dtype;
   // +64 elements of slack: the x-pair load of the last voxel row touches one element past the end
-  HIPCHK(c, hipMalloc(&e.data, (nstore + 64) * dsz));
-  HIPCHK(c, hipMemsetAsync(e.data, 0, (nstore + 64) * dsz, c->stream));
+  HIPCHK(c, field.alloc((nstore + 64) * dsz));
+  HIPCHK(c, hipMemsetAsync(field.p, 0, (nstore + 64) * dsz, c->stream));
   const dim3 grid((unsigned)((nvox + 255) / 256)), blk(256);
   if (layout == NEO_LAYOUT_CELL8) {
     if (src_dtype == NEO_F64 && store_dtype == NEO_F32)
-      hipLaunchKernelGGL((pack3d_cell8_kernel<double, float>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz, (float *)e.data);
+      hipLaunchKernelGGL((pack3d_cell8_kernel<double, float>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz, (float *)field.p);
     else if (src_dtype == NEO_F64)
-      hipLaunchKernelGGL((pack3d_cell8_kernel<double, __half>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz, (__half *)e.data);
+      hipLaunchKernelGGL((pack3d_cell8_kernel<double, __half>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz, (__half *)field.p);
     else if (store_dtype == NEO_F32)
-      hipLaunchKernelGGL((pack3d_cell8_kernel<float, float>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz, (float *)e.data);
+      hipLaunchKernelGGL((pack3d_cell8_kernel<float, float>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz, (float *)field.p);
     else
-      hipLaunchKernelGGL((pack3d_cell8_kernel<float, __half>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz, (__half *)e.data);
+      hipLaunchKernelGGL((pack3d_cell8_kernel<float, __half>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz, (__half *)field.p);
   } else if (src_dtype == NEO_F64 && store_dtype == NEO_F32)
     hipLaunchKernelGGL((pack3d_kernel<double, float>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz,
-                       layout, bx, by, (float *)e.data);
+                       layout, bx, by, (float *)field.p);
   else if (src_dtype == NEO_F64)
     hipLaunchKernelGGL((pack3d_kernel<double, __half>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz,
-                       layout, bx, by, (__half *)e.data);
+                       layout, bx, by, (__half *)field.p);
   else if (store_dtype == NEO_F32)
     hipLaunchKernelGGL((pack3d_kernel<float, float>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz,
-                       layout, bx, by, (float *)e.data);
+                       layout, bx, by, (float *)field.p);
   else
     hipLaunchKernelGGL((pack3d_kernel<float, __half>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz,
-                       layout, bx, by, (__half *)e.data);
+                       layout, bx, by, (__half *)field.p);
+  HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (staged) hipFree(staged);
+  e.data = field.release();
   e.m3 = Map3D{e.data, nx, ny, nz, layout, bx, by, res, origin[0], origin[1], origin[2],
                (unsigned int)((nstore + 64) * dsz)};
   c->maps[scene_id] = e;
@@ -1422,45 +792,40 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
 int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_device, int nx, int ny, int nz,
                       double res, const double origin[3], int store_dtype, int layout, float *out_dist) {
   if (!c || !occ || !origin || nx < 2 || ny < 2 || nz < 2 || !(res > 0.0)) return NEO_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> g(c->mu);
   if (store_dtype != NEO_F32 && store_dtype != NEO_F16) return fail(c, NEO_ERR_INVALID, "store_dtype must be f32 or f16");
   const size_t nvox = (size_t)nx * ny * nz;
-  float *d_dist = nullptr;
+  DevBuf d_dist;
   {
-    std::lock_guard<std::recursive_mutex> g(c->mu);
     hipSetDevice(c->device);
     const size_t lines = (size_t)std::max(nx * ny, std::max(nx * nz, ny * nz));
     const size_t nmax = (size_t)std::max(nx, std::max(ny, nz));
-    void *d_occ = nullptr, *d_g = nullptr, *d_v = nullptr, *d_z = nullptr;
+    DevBuf d_occ, d_g, d_v, d_z;
     const uint8_t *src = occ;
     if (!occ_is_device) {
-      HIPCHK(c, hipMalloc(&d_occ, nvox));
-      HIPCHK(c, hipMemcpyAsync(d_occ, occ, nvox, hipMemcpyHostToDevice, c->stream));
-      src = static_cast<const uint8_t *>(d_occ);
+      HIPCHK(c, d_occ.alloc(nvox));
+      HIPCHK(c, hipMemcpyAsync(d_occ.p, occ, nvox, hipMemcpyHostToDevice, c->stream));
+      src = d_occ.as<uint8_t>();
     }
-    HIPCHK(c, hipMalloc(&d_g, nvox * sizeof(int)));
-    HIPCHK(c, hipMalloc(&d_v, lines * nmax * sizeof(int)));
-    HIPCHK(c, hipMalloc(&d_z, lines * (2 * nmax + 2) * sizeof(double)));
-    HIPCHK(c, hipMalloc((void **)&d_dist, nvox * sizeof(float)));
+    HIPCHK(c, d_g.alloc(nvox * sizeof(int)));
+    HIPCHK(c, d_v.alloc(lines * nmax * sizeof(int)));
+    HIPCHK(c, d_z.alloc(lines * (2 * nmax + 2) * sizeof(double)));
+    HIPCHK(c, d_dist.alloc(nvox * sizeof(float)));
     {
       ProfScope ps(c, NEO_KERNEL_ESDF_BUILD);
       const int blk = 64;
       hipLaunchKernelGGL(edt3_x_kernel, dim3((unsigned)(((size_t)ny * nz + blk - 1) / blk)), dim3(blk), 0, c->stream, src,
-                         nx, ny, nz, (int *)d_g);
+                         nx, ny, nz, d_g.as<int>());
       hipLaunchKernelGGL(edt3_y_kernel, dim3((unsigned)(((size_t)nx * nz + blk - 1) / blk)), dim3(blk), 0, c->stream,
-                         (int *)d_g, nx, ny, nz, (int *)d_v, (double *)d_z);
+                         d_g.as<int>(), nx, ny, nz, d_v.as<int>(), d_z.as<double>());
       hipLaunchKernelGGL((edt3_z_kernel<float>), dim3((unsigned)(((size_t)nx * ny + blk - 1) / blk)), dim3(blk), 0,
-                         c->stream, (int *)d_g, nx, ny, nz, res, (int *)d_v, (double *)d_z, d_dist);
+                         c->stream, d_g.as<int>(), nx, ny, nz, res, d_v.as<int>(), d_z.as<double>(), d_dist.as<float>());
     }
-    if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, d_dist, nvox * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipGetLastError());
+    if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, d_dist.p, nvox * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (d_occ) hipFree(d_occ);
-    hipFree(d_g);
-    hipFree(d_v);
-    hipFree(d_z);
   }
-  const int rc = neo_esdf_upload_3d(c, scene_id, d_dist, NEO_F32, 1, nx, ny, nz, res, origin, store_dtype, layout);
-  hipFree(d_dist);
-  return rc;
+  return neo_esdf_upload_3d(c, scene_id, d_dist.p, NEO_F32, 1, nx, ny, nz, res, origin, store_dtype, layout);
 }
 
 int neo_esdf_query(neo_ctx *c, int scene_id, int n, const double *pts, double *dist, double *grad) {
@@ -1498,7 +863,7 @@ int neo_cost_grad_batch_dev(neo_ctx *c, int scene_id, int B, int M, int D, const
                             int32_t *status) {
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
-  if (!x || !head || !tail || !cost || !costs4 || !grad) return fail(c, NEO_ERR_INVALID, "null buffer");
+  if (!x || !head || !tail || !cost || !costs4 || !grad) return fail_locked(c, NEO_ERR_INVALID, "null buffer");
   std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   auto it = c->maps.find(scene_id);
@@ -1517,7 +882,7 @@ int neo_cost_grad_batch(neo_ctx *c, int scene_id, int B, int M, int D, const dou
                         int32_t *status) {
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
-  if (!x || !head || !tail || !cost || !costs4 || !grad) return fail(c, NEO_ERR_INVALID, "null buffer");
+  if (!x || !head || !tail || !cost || !costs4 || !grad) return fail_locked(c, NEO_ERR_INVALID, "null buffer");
   if (B == 0) return NEO_OK;
   std::lock_guard<std::recursive_mutex> whole_call(c->mu);  // scratch buffers stay ours until the copies back are done
   const size_t n = (size_t)D * (M - 1) + M, bs = (size_t)B;
@@ -1558,9 +923,9 @@ int neo_sampled_terms_batch_dev(neo_ctx *c, int scene_id, int B, int M, int D, c
                                 const double *ts, double *costs2, double *grad_C, double *grad_T) {
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
-  if (!coeffs || !ts || !costs2 || !grad_C || !grad_T) return fail(c, NEO_ERR_INVALID, "null buffer");
+  if (!coeffs || !ts || !costs2 || !grad_C || !grad_T) return fail_locked(c, NEO_ERR_INVALID, "null buffer");
   if (((uintptr_t)coeffs | (uintptr_t)grad_C) & 15)
-    return fail(c, NEO_ERR_INVALID, "coeffs and grad_C must be 16-byte aligned");
+    return fail_locked(c, NEO_ERR_INVALID, "coeffs and grad_C must be 16-byte aligned");
   std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   auto it = c->maps.find(scene_id);
@@ -1578,7 +943,7 @@ int neo_sampled_terms_batch(neo_ctx *c, int scene_id, int B, int M, int D, const
                             double *costs2, double *grad_C, double *grad_T) {
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
-  if (!coeffs || !ts || !costs2 || !grad_C || !grad_T) return fail(c, NEO_ERR_INVALID, "null buffer");
+  if (!coeffs || !ts || !costs2 || !grad_C || !grad_T) return fail_locked(c, NEO_ERR_INVALID, "null buffer");
   if (B == 0) return NEO_OK;
   std::lock_guard<std::recursive_mutex> whole_call(c->mu);  // scratch buffers stay ours until the copies back are done
   const size_t bs = (size_t)B, nc = (size_t)6 * M * D;
@@ -1615,7 +980,7 @@ int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, i
                            int32_t *nfev, int32_t *status) {
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
-  if (!x || !head || !tail || !costs4 || !nit || !nfev || !status) return fail(c, NEO_ERR_INVALID, "null buffer");
+  if (!x || !head || !tail || !costs4 || !nit || !nfev || !status) return fail_locked(c, NEO_ERR_INVALID, "null buffer");
   std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   if (B == 0) return NEO_OK;
@@ -1626,14 +991,21 @@ int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, i
   const void *table;
   const int *slots = scene_ids;
   std::vector<int> one;
+  int nmaps = 1;
   if (scene_ids) {
-    // all maps of a multi-scene call must be of one kind/element type: take it from scene_id
+    // one kernel instantiation serves the whole call: every map a slot can name (all maps of the reference
+    // scene's kind in this context) must share its element type and layout
     auto it = c->maps.find(scene_id);
     if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for the reference scene");
     kind = it->second.kind;
     elem = it->second.elem;
     layout = it->second.m3.layout;
+    for (const auto &kv : c->maps)
+      if (kv.second.kind == kind && (kv.second.elem != elem || (kind == 1 && kv.second.m3.layout != layout)))
+        return fail(c, NEO_ERR_INVALID, "multi-scene call: the context holds maps of this kind with different element "
+                                        "types or layouts");
     table = kind == 0 ? c->table2d : c->table3d;
+    nmaps = kind == 0 ? c->n2d : c->n3d;
   } else {
     auto it = c->maps.find(scene_id);
     if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for this scene");
@@ -1644,7 +1016,7 @@ int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, i
     table = base + (size_t)it->second.slot * (kind == 0 ? sizeof(Map2D) : sizeof(Map3D));
   }
   ProfScope ps(c, NEO_KERNEL_OPTIMIZE);
-  const OptArgs oa{B, M, table, slots, x, head, tail, costs4, costs4_last, nit, nfev, status};
+  const OptArgs oa{B, M, table, slots, nmaps, x, head, tail, costs4, costs4_last, nit, nfev, status};
   rc = dispatch_opt(c, kind, elem, layout, D, oa);
   if (rc) return rc;
   HIPCHK(c, hipGetLastError());
@@ -1665,7 +1037,7 @@ int neo_optimize_batch(neo_ctx *c, int scene_id, const int32_t *scene_ids, int B
                        int32_t *nfev, int32_t *status) {
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
-  if (!x || !head || !tail || !costs4 || !nit || !nfev || !status) return fail(c, NEO_ERR_INVALID, "null buffer");
+  if (!x || !head || !tail || !costs4 || !nit || !nfev || !status) return fail_locked(c, NEO_ERR_INVALID, "null buffer");
   if (B == 0) return NEO_OK;
   std::lock_guard<std::recursive_mutex> whole_call(c->mu);  // scratch buffers stay ours until the copies back are done
   const size_t n = (size_t)D * (M - 1) + M, bs = (size_t)B;
@@ -1674,9 +1046,13 @@ int neo_optimize_batch(neo_ctx *c, int scene_id, const int32_t *scene_ids, int B
   std::vector<int> slots;
   if (scene_ids) {
     slots.resize(bs);
+    int kind0 = -1;
     for (size_t i = 0; i < bs; ++i) {
       const int s = neo_scene_slot(c, scene_ids[i]);
       if (s < 0) return fail(c, NEO_ERR_NO_MAP, "no ESDF for one of scene_ids");
+      const int k = c->maps.find(scene_ids[i])->second.kind;
+      if (kind0 < 0) kind0 = k;
+      if (k != kind0) return fail(c, NEO_ERR_INVALID, "scene_ids mix 2-D and 3-D maps");
       slots[i] = s;
     }
   }
@@ -1720,7 +1096,7 @@ int neo_eval_traj_batch(neo_ctx *c, int B, int M, int D, const double *x, const 
                         double hz, int K, double *state, int32_t *count) {
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
-  if (!x || !head || !tail || !state || !count || K < 0 || !(hz > 0.0)) return fail(c, NEO_ERR_INVALID, "bad argument");
+  if (!x || !head || !tail || !state || !count || K < 0 || !(hz > 0.0)) return fail_locked(c, NEO_ERR_INVALID, "bad argument");
   if (B == 0 || K == 0) return NEO_OK;
   std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);

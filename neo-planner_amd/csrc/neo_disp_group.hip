@@ -1,0 +1,43 @@
+// neo_disp_group.hip -- optimize_group_kernel family: several small trajectories per wavefront (NEO_FLAG_LANE_GROUPS)
+#include "neo_host.hpp"
+#include "neo_kernels.hpp"
+#include "neo_group_kernel.hpp"
+
+namespace neo {
+
+constexpr int kTicketRing = 64;
+
+template <typename Real, class LookupT, int W, int NS>
+int launch_group_w(neo_ctx *c, const OptArgs &a) {
+  constexpr int D = 3, G = kWave / W;
+  if (!c->tickets) {
+    HIPCHK(c, hipMalloc((void **)&c->tickets, kTicketRing * sizeof(int)));
+  }
+  int *ticket = c->tickets + (c->ticket_next++ % kTicketRing);
+  HIPCHK(c, hipMemsetAsync(ticket, 0, sizeof(int), c->stream));
+  const int n = D * (a.M - 1) + a.M;
+  const size_t dyn = (size_t)G * 2 * NEO_LBFGS_M * n * sizeof(double);
+  const int waves = std::min((a.B + G - 1) / G, 4096);  // persistent groups: they draw trajectories off the ticket
+  hipLaunchKernelGGL((optimize_group_kernel<D, Real, Map3D, LookupT, W, NS>), dim3(waves), dim3(kWave), dyn, c->stream,
+                     a.B, a.M, c->dev, static_cast<const Map3D *>(a.table), a.x, a.head, a.tail, a.costs4, a.costs4_last,
+                     a.nit, a.nfev, a.status, c->sample_counter, (c->order_B == a.B ? c->dispatch_order : nullptr),
+                     ticket);
+  return NEO_OK;
+}
+
+// n <= 16: eight trajectories per wavefront when the pieces fit 8 lanes (flags bit 256: sixteen-lane groups, for
+// comparison), else four
+template <typename Real, class LookupT>
+int launch_group(neo_ctx *c, const OptArgs &a) {
+  const int n = 3 * (a.M - 1) + a.M;
+  if (n > 16) return launch_group_w<Real, LookupT, 16, 2>(c, a);  // n <= 32 (M <= 8): four per wavefront, two slots
+  if (a.M <= 8 && !(c->params.flags & 256)) return launch_group_w<Real, LookupT, 8, 2>(c, a);
+  return launch_group_w<Real, LookupT, 16, 1>(c, a);
+}
+
+int launch_opt_groups(neo_ctx *c, int elem, const OptArgs &a) {
+  if (elem == NEO_F32) return launch_group<float, Lookup3D<float, float, 0>>(c, a);
+  return launch_group<float, Lookup3D<float, __half, 0>>(c, a);
+}
+
+}  // namespace neo

@@ -1,0 +1,16 @@
+// neo_disp_opt3d_f64.hip -- optimize_kernel on 3-D fields, fp64 sampling (parity mode), one wavefront per SIMD
+#include "neo_launch_opt.hpp"
+
+namespace neo {
+
+int launch_opt_3d_f64(neo_ctx *c, int elem, int layout, const OptArgs &a) {
+#define NEO_3D(LAY)                                                                                \
+  if (elem == NEO_F32) return launch_opt<3, double, Map3D, Lookup3D<double, float, LAY>>(c, a);      \
+  return launch_opt<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, a);
+  if (layout == 0) { NEO_3D(0) }
+  if (layout == 2) { NEO_3D(2) }
+  NEO_3D(1)
+#undef NEO_3D
+}
+
+}  // namespace neo

@@ -1,0 +1,42 @@
+// neo_disp_sample.hip -- sample_kernel family: the ESDF-lookup kernel (expert_planner.py:392-466)
+#include "neo_host.hpp"
+#include "neo_kernels.hpp"
+
+namespace neo {
+
+template <int D, typename Real, class MapT, class LookupT>
+int launch_sample(neo_ctx *c, const MapT &map, const SampleArgs &a) {
+  hipLaunchKernelGGL((sample_kernel<D, Real, MapT, LookupT>), dim3(a.B), dim3(kWave), 0, c->stream, a.B, a.M, c->dev,
+                     map, a.coeffs, a.ts, a.costs2, a.grad_C, a.grad_T);
+  return NEO_OK;
+}
+
+int dispatch_sample(neo_ctx *c, const MapEntry &e, int D, const SampleArgs &a) {
+#ifdef NEO_SLIM_BUILD  // kernel experiments (tools/probe): only the cfg2 instantiation compiles, in 20 s
+  if (e.kind != 0 && D == 3 && e.elem == NEO_F32 && e.m3.layout == 0 && c->params.sample_dtype == NEO_F32)
+    return launch_sample<3, float, Map3D, Lookup3D<float, float, 0>>(c, e.m3, a);
+  return fail(c, NEO_ERR_INVALID, "slim build: cfg2 kernels only");
+#else
+  const bool f32 = c->params.sample_dtype == NEO_F32;
+  if (e.kind == 0) {
+    if (D == 2)
+      return f32 ? launch_sample<2, float, Map2D, Lookup2D<float>>(c, e.m2, a)
+                 : launch_sample<2, double, Map2D, Lookup2D<double>>(c, e.m2, a);
+    return f32 ? launch_sample<3, float, Map2D, Lookup2D<float>>(c, e.m2, a)
+               : launch_sample<3, double, Map2D, Lookup2D<double>>(c, e.m2, a);
+  }
+  if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
+#define NEO_3D(LAY)                                                                                  \
+  if (e.elem == NEO_F32)                                                                             \
+    return f32 ? launch_sample<3, float, Map3D, Lookup3D<float, float, LAY>>(c, e.m3, a)             \
+               : launch_sample<3, double, Map3D, Lookup3D<double, float, LAY>>(c, e.m3, a);          \
+  return f32 ? launch_sample<3, float, Map3D, Lookup3D<float, __half, LAY>>(c, e.m3, a)              \
+             : launch_sample<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, e.m3, a);
+  if (e.m3.layout == 0) { NEO_3D(0) }
+  if (e.m3.layout == 2) { NEO_3D(2) }
+  NEO_3D(1)
+#undef NEO_3D
+#endif
+}
+
+}  // namespace neo

@@ -1,4 +1,4 @@
-// neo_group_kernel.hpp -- several trajectories per wavefront for small problems (included by neo_kernels.hip).
+// neo_group_kernel.hpp -- several trajectories per wavefront for small problems (instantiated by neo_disp_group.hip).
 //
 // A lane group of W = 8 or 16 lanes owns one trajectory (n <= 16 variables, M <= W pieces: the reference's M = 3),
 // eight or four groups share a wavefront.  Every round all groups evaluate cost and gradient together (the expensive,

@@ -1,0 +1,159 @@
+// neo_host.hpp -- host-side state shared by the translation units of libneo_planner_hip.so: the context behind
+// the opaque neo_ctx of include/neo_planner.h, the argument packs of the kernel families and the per-family
+// dispatch entry points (defined in neo_disp_*.hip, one family per translation unit so they build in parallel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/neo_planner.h"
+#include "neo_device.hpp"
+
+namespace neo {
+struct MapEntry {
+  int kind = -1;  // 0 = 2-D reference map, 1 = 3-D field
+  int elem = NEO_F64;
+  void *data = nullptr;  // device
+  Map2D m2{};
+  Map3D m3{};
+  int slot = -1;  // index into the device-side map table
+};
+
+struct ProfileSlot {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  int64_t launches = 0;
+  double ms = 0.0;
+};
+
+}  // namespace neo
+
+struct neo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipStream_t home_stream = nullptr;  // the stream of neo_ctx_create (neo_ctx_set_stream(NULL) returns to it)
+  neo_params params{};
+  neo::DevParams dev{};
+  std::map<int, neo::MapEntry> maps;
+  std::string err;
+  std::recursive_mutex mu;  // recursive: the host-pointer entry points hold it across their *_dev call
+  int *tickets = nullptr;  // ring of work counters for optimize_group_kernel launches (one per launch in flight)
+  unsigned ticket_next = 0;
+  // device-side table of maps (rebuilt when a map changes)
+  void *table2d = nullptr, *table3d = nullptr;
+  int n2d = 0, n3d = 0;
+  bool table_dirty = true;
+  // scratch for the host-pointer entry points
+  void *scratch = nullptr;
+  size_t scratch_bytes = 0;
+  bool profile = false;
+  neo::ProfileSlot prof[NEO_KERNEL_COUNT];
+  long long *sample_counter = nullptr;  // optional device array [B] (neo_optimize_sample_counter)
+  const int *dispatch_order = nullptr;  // optional device permutation [B] (neo_optimize_dispatch_order)
+  int order_B = 0;                      // batch size the permutation was given for (ignored for any other B)
+  int *order_buf = nullptr;             // device copy of a host permutation (neo_optimize_dispatch_order_host)
+  size_t order_cap = 0;
+};
+
+namespace neo {
+
+inline int fail(neo_ctx *c, int code, const std::string &msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                     \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(c, NEO_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));       \
+  } while (0)
+
+// device allocation released on every exit path unless release()d into a longer-lived owner
+struct DevBuf {
+  void *p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() {
+    if (p) hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  void *release() {
+    void *q = p;
+    p = nullptr;
+    return q;
+  }
+  template <typename T>
+  T *as() const { return static_cast<T *>(p); }
+};
+
+struct ProfScope {
+  neo_ctx *c;
+  int k;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(neo_ctx *c_, int k_) : c(c_), k(k_) {
+    if (c->profile) {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, c->stream);
+    }
+  }
+  ~ProfScope() {
+    if (c->profile) {
+      hipEventRecord(b, c->stream);
+      c->prof[k].pending.emplace_back(a, b);
+    }
+  }
+};
+
+struct EvalArgs {
+  int B, M;
+  const double *x, *head, *tail;
+  double *cost, *costs4, *grad, *coeffs;
+  int *status;
+};
+
+struct OptArgs {
+  int B, M;
+  const void *table;
+  const int *slots;  // device array [B] of map-table slots, or NULL (all trajectories use table[0])
+  int nmaps;         // entries of `table` (slots are checked against it on the device)
+  double *x;
+  const double *head, *tail;
+  double *costs4, *costs4_last;
+  int *nit, *nfev, *status;
+};
+
+struct SampleArgs {
+  int B, M;
+  const double *coeffs, *ts;
+  double *costs2, *grad_C, *grad_T;
+};
+
+// FLAT slots of the optimiser vectors: n <= 64, 128 or 256 variables
+inline int slots_for(int M, int D) {
+  const int n = D * (M - 1) + M;
+  const int ns = (n + kWave - 1) / kWave;
+  return ns <= 1 ? 1 : (ns == 2 ? 2 : 4);
+}
+
+// ---- per-family dispatch (neo_disp_*.hip)
+int dispatch_eval(neo_ctx *c, const MapEntry &e, int D, const EvalArgs &a);
+int dispatch_sample(neo_ctx *c, const MapEntry &e, int D, const SampleArgs &a);
+// the families behind dispatch_opt (neo_abi.hip)
+int launch_opt_2d(neo_ctx *c, int D, bool f32, const OptArgs &a);           // neo_disp_opt2d.hip
+int launch_opt_3d_f32(neo_ctx *c, int elem, int layout, const OptArgs &a);  // neo_disp_opt3d_f32.hip
+int launch_opt_3d_f64(neo_ctx *c, int elem, int layout, const OptArgs &a);  // neo_disp_opt3d_f64.hip
+int launch_opt_3d_w2(neo_ctx *c, int elem, int layout, const OptArgs &a);   // neo_disp_opt3d_w2.hip
+int launch_opt_groups(neo_ctx *c, int elem, const OptArgs &a);              // neo_disp_group.hip
+
+}  // namespace neo

@@ -1,0 +1,412 @@
+// neo_kernels.hpp -- the fused kernels of libneo_planner_hip.so as templates (gfx950 only); every translation
+// unit of the library instantiates the family it dispatches to (neo_disp_*.hip), so that the families compile in parallel.
+//
+//   eval_kernel      get_cost + get_grad for a batch            (expert_planner.py:539-585)
+//   optimize_kernel  plan_once: the whole L-BFGS-B run on-chip  (expert_planner.py:205-237)
+//   sample_kernel    add_sampled_cost + add_sampled_grad_CT     (expert_planner.py:392-466)
+//
+// One 64-lane workgroup (= one wavefront) per trajectory: the optimiser never leaves the chip,
+// finished trajectories free their slot for the next ones, no host round trips.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include "../../include/neo_planner.h"
+#ifndef NEO_FUSED_U
+#define NEO_FUSED_U (sizeof(Real) == 4 ? 4 : 2)
+#endif
+#ifndef NEO_W2_U
+#define NEO_W2_U 2
+#endif
+#ifndef NEO_W2_MAX_SLOTS
+#define NEO_W2_MAX_SLOTS 2  // two waves per SIMD only up to n = 128 variables (M = 41: +5 % on an fp32 field, -2 % at cfg5)
+#endif
+#include "neo_device.hpp"
+#include "neo_lbfgs.hpp"
+
+namespace neo {
+
+// ------------------------------------------------------------------ device backend of the optimiser
+// SU: samples per lane in flight in the sample loop (minco_sample)
+template <int D, int NS, typename Real, class MapT, class LookupT, int SU = NEO_FUSED_U>
+struct DevBackend {
+  // FLAT layout with NS slots: n <= 64 * NS
+  struct Vec {
+    double v[NS];
+  };
+  Traj<D> t;
+  const DevParams &prm;
+  const MapT &map;
+  double *xs;    // LDS [256]: FLAT <-> PIECE staging
+  double *sc;    // LDS [2m]: rho / alpha of the two-loop recursion
+  LineSearch *lsp;  // LDS: line-search state (wave-uniform)
+  double *cst;      // LDS [12]: cost terms of the last evaluation / current x / previous x
+  double *hist;  // LDS [2][m][n]: the stored (s, y) pairs of this trajectory
+  int npad, m;
+  double *coeff_out;  // optional [6M][D] (eval kernel)
+  long long samples = 0;  // quadrature samples visited so far (lane-uniform), for the bench's byte count
+#ifdef NEO_STAMPS  // timing experiments (tools/gpu_straggler.py): 100 MHz wall-clock ticks per phase
+  long long tk[4] = {0, 0, 0, 0};  // forward, sample, backward, evaluations
+#endif
+
+  __device__ DevBackend(const DevParams &p, const MapT &mp) : prm(p), map(mp) {}
+
+  __device__ __forceinline__ double dot(const Vec &a, const Vec &b) const {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s += a.v[k] * b.v[k];
+    return wave_sum(s);
+  }
+  __device__ __forceinline__ double amax(const Vec &a) const {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s = fmax(s, fabs(a.v[k]));
+    return wave_max_nonneg(s);
+  }
+  __device__ __forceinline__ void copy(Vec &d, const Vec &s) const {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) d.v[k] = s.v[k];
+  }
+  __device__ __forceinline__ void neg(Vec &d, const Vec &s) const {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) d.v[k] = -s.v[k];
+  }
+  __device__ __forceinline__ void axpy(double a, const Vec &x, Vec &y) const {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) y.v[k] += a * x.v[k];
+  }
+  __device__ __forceinline__ void lincomb(Vec &o, const Vec &a, double s, const Vec &b) const {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) o.v[k] = a.v[k] + s * b.v[k];
+  }
+  __device__ __forceinline__ void scale(Vec &v, double s) const {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) v.v[k] *= s;
+  }
+  __device__ __forceinline__ void hist_put(int slot, const Vec &s, const Vec &y) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      if (k * kWave + lane < t.n) {
+        hist[slot * t.n + k * kWave + lane] = s.v[k];
+        hist[(m + slot) * t.n + k * kWave + lane] = y.v[k];
+      }
+    __syncthreads();
+  }
+  __device__ __forceinline__ void hist_get(int row, Vec &v) const {
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < NS; ++k) v.v[k] = (k * kWave + lane < t.n) ? hist[row * t.n + k * kWave + lane] : 0.0;
+  }
+  __device__ __forceinline__ void hist_get_s(int slot, Vec &v) const { hist_get(slot, v); }
+  __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
+  __device__ __forceinline__ void sput(int i, double v) {
+    sc[i] = v;
+    __syncthreads();
+  }
+  __device__ __forceinline__ double sget(int i) const { return sc[i]; }
+#ifndef NEO_LS_IN_REGS  // measured: LDS is faster (registers spill: 14.0 vs 15.5 ms at cfg2)
+  __device__ __forceinline__ LineSearch &ls() { return *lsp; }
+  __device__ __forceinline__ double *cost_store() { return cst; }
+#else
+  // registers: with one wave per SIMD the file is not the binding constraint, LDS round trips are
+  LineSearch ls_reg;
+  double cst_reg[12];
+  __device__ __forceinline__ LineSearch &ls() { return ls_reg; }
+  __device__ __forceinline__ double *cost_store() { return cst_reg; }
+#endif
+
+  // FLAT x -> PIECE inputs
+  __device__ __forceinline__ void scatter_x(const Vec &x) {
+    const int lane = lane_id();
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      if (k * kWave + lane < t.n) xs[k * kWave + lane] = x.v[k];
+    __syncthreads();
+    const int M = t.M;
+    const bool act = lane < M;
+    t.tau = act ? xs[t.nq + lane] : 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      t.P0[d] = (lane == 0 || !act) ? t.head[d] : xs[d * (M - 1) + (lane > 0 ? lane - 1 : 0)];
+      t.P1[d] = (lane >= M - 1) ? t.tail[d] : xs[d * (M - 1) + lane];
+    }
+  }
+
+  // one evaluation of cost and gradient (get_cost + get_grad, :539-585)
+  __device__ __forceinline__ int eval(const Vec &x, double &f, Vec &g, double *costs) {
+    const int lane = lane_id();
+#ifdef NEO_STAMPS
+    const long long s0 = wall_clock64();
+#endif
+    scatter_x(x);
+    double energy, tsum;
+    const int st = minco_forward<D>(t, prm, energy, tsum);
+#ifdef NEO_STAMPS
+    const long long s1 = wall_clock64();
+#endif
+    if (st != 0) {
+      f = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) costs[k] = 0.0;
+      return st;
+    }
+    samples += (long long)wave_sum(lane < t.M ? t.ns : 0);
+    if (coeff_out != nullptr && lane < t.M) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int d = 0; d < D; ++d) coeff_out[(size_t)(6 * lane + k) * D + d] = t.c[k][d];
+    }
+    double gC[6][D], gT = 0.0, cf, ck;
+    {
+      Real cr[6][D], gCr[6][D], gTr;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int d = 0; d < D; ++d) cr[k][d] = (Real)t.c[k][d];
+      LookupT lk(map);
+      minco_sample<Real, D, LookupT, SU>(t.M, t.L, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int d = 0; d < D; ++d) gC[k][d] = (double)gCr[k][d];
+      gT = (double)gTr;
+    }
+#ifdef NEO_STAMPS
+    const long long s2 = wall_clock64();
+#endif
+    costs[0] = uniform(energy);
+    costs[1] = uniform(tsum);
+    costs[2] = uniform(cf);
+    costs[3] = uniform(ck);
+    f = costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3];
+    double gq[D], gtau;
+    const int bst = minco_backward<D>(t, prm, gC, gT, gq, gtau);
+    if (bst != 0) return bst;
+    // PIECE -> FLAT
+    __syncthreads();
+    if (lane >= 1 && lane < t.M) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) xs[d * (t.M - 1) + lane - 1] = gq[d];
+    }
+    if (lane < t.M) xs[t.nq + lane] = gtau;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NS; ++k) g.v[k] = (k * kWave + lane < t.n) ? xs[k * kWave + lane] : 0.0;
+#ifdef NEO_STAMPS
+    const long long s3 = wall_clock64();
+    tk[0] += s1 - s0;
+    tk[1] += s2 - s1;
+    tk[2] += s3 - s2;
+    tk[3] += 1;
+#endif
+    return 0;
+  }
+};
+
+template <int D>
+__device__ __forceinline__ void load_boundary(Traj<D> &t, const double *head, const double *tail, int M) {
+  t.M = M;
+  t.nq = D * (M - 1);
+  t.n = t.nq + M;
+  t.L = sample_lanes_per_piece(M);
+  t.head = head;
+  t.tail = tail;
+}
+
+struct MapTable {
+  const void *maps;  // array of MapT indexed by scene slot
+};
+
+// ------------------------------------------------------------------ kernels
+template <int D, int NS, typename Real, class MapT, class LookupT>
+__global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm, MapT map,
+                                                      const double *__restrict__ x,
+                                                      const double *__restrict__ head,
+                                                      const double *__restrict__ tail,
+                                                      double *__restrict__ cost, double *__restrict__ costs4,
+                                                      double *__restrict__ grad, double *__restrict__ coeffs,
+                                                      int *__restrict__ status) {
+  __shared__ double xs[NS * kWave];
+  __shared__ double sc[2 * NEO_LBFGS_M];
+  __shared__ LineSearch lsm;
+  __shared__ double cst[12];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  using BE = DevBackend<D, NS, Real, MapT, LookupT>;
+  BE be(prm, map);
+  be.xs = xs;
+  be.sc = sc;
+  be.lsp = &lsm;
+  be.cst = cst;
+  be.hist = nullptr;
+  be.m = NEO_LBFGS_M;
+  load_boundary<D>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
+  const int n = be.t.n;
+  be.npad = NS * kWave;
+  be.coeff_out = coeffs ? coeffs + (size_t)b * 6 * M * D : nullptr;
+  const int lane = lane_id();
+  typename BE::Vec xv, gv;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) xv.v[k] = (k * kWave + lane < n) ? x[(size_t)b * n + k * kWave + lane] : 0.0;
+  double f;
+  double *costs = cst;
+  const int st = be.eval(xv, f, gv, costs);
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+    if (k * kWave + lane < n) grad[(size_t)b * n + k * kWave + lane] = gv.v[k];
+  if (lane == 0) {
+    cost[b] = f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) costs4[(size_t)b * 4 + k] = costs[k];
+    if (status) status[b] = st;
+  }
+}
+
+// WAVES = wavefronts per SIMD the register allocation aims at.  1: the whole file (256 VGPRs + AGPRs) for one
+// trajectory -- the shortest evaluation, for batches that leave SIMDs to spare.  2: half the file, some state
+// spilled to scratch -- each evaluation is slower, but two trajectories share a SIMD's issue slots, which wins
+// once the batch queues for the 1024 SIMDs anyway (cfg2 with several batches in flight: +10 %).  Same
+// source, same arithmetic, bit-identical results.
+template <int D, int NS, typename Real, class MapT, class LookupT, int WAVES>
+__global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
+                                                          const int *__restrict__ scene_slot, int nmaps,
+                                                          double *__restrict__ x,
+                                                          const double *__restrict__ head,
+                                                          const double *__restrict__ tail,
+                                                          double *__restrict__ costs4,
+                                                          double *__restrict__ costs4_last,
+                                                          int *__restrict__ nit, int *__restrict__ nfev,
+                                                          int *__restrict__ status,
+                                                          long long *__restrict__ nsamples,
+                                                          const int *__restrict__ order) {
+  __shared__ double xs[NS * kWave];
+  __shared__ double sc[2 * NEO_LBFGS_M];
+  __shared__ LineSearch lsm;
+  __shared__ double cst[12];
+  if ((int)blockIdx.x >= B) return;
+  // workgroups are dispatched in index order: `order` lets the caller start the runs it expects to
+  // be long first (list scheduling: a long run that starts last sets the duration of the launch)
+  const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
+  // the two-waves variant has half the registers: two samples per lane in flight instead of four (with the lean
+  // Horner form, cfg2 with three batches in flight: 414 k -> 541 k traj/s; scratch 640 -> 336 B per lane)
+  using BE = DevBackend<D, NS, Real, MapT, LookupT, (WAVES == 2 ? NEO_W2_U : NEO_FUSED_U)>;
+  // a slot outside the table (a stale or foreign slot array): the trajectory is left untouched and flagged
+  const int slot = scene_slot ? scene_slot[b] : 0;
+  if (slot < 0 || slot >= nmaps) {
+    if (lane_id() == 0) {
+      status[b] = NEO_TRAJ_BAD_SCENE;
+      nit[b] = 0;
+      nfev[b] = 0;
+    }
+    return;
+  }
+  const MapT map = maps[slot];
+  BE be(prm, map);
+  be.xs = xs;
+  be.sc = sc;
+  be.lsp = &lsm;
+  be.cst = cst;
+  be.m = NEO_LBFGS_M;
+  be.coeff_out = nullptr;
+  load_boundary<D>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
+  const int n = be.t.n;
+  be.npad = NS * kWave;
+  extern __shared__ double dyn_lds[];  // 2 * maxcor * n doubles (launch parameter)
+  be.hist = dyn_lds;
+  const int lane = lane_id();
+  typename BE::Vec xv;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) xv.v[k] = (k * kWave + lane < n) ? x[(size_t)b * n + k * kWave + lane] : 0.0;
+  LbfgsOpts o{prm.ftol, prm.gtol, prm.maxls, prm.maxiter, prm.maxfun, NEO_LBFGS_M};
+  LbfgsResult res;
+#ifdef NEO_STAMPS
+  const long long k0 = wall_clock64();
+#endif
+  lbfgs_minimize(be, xv, o, res);
+#ifdef NEO_STAMPS
+  if (lane == 0 && nsamples) {  // the counter buffer is [B][8] in this build
+    long long *o8 = nsamples + (size_t)b * 8;
+    o8[1] = be.tk[3]; o8[2] = be.tk[0]; o8[3] = be.tk[1]; o8[4] = be.tk[2];
+    o8[5] = wall_clock64() - k0; o8[6] = k0; o8[7] = blockIdx.x;
+    o8[0] = be.samples;
+  }
+  nsamples = nullptr;
+#endif
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+    if (k * kWave + lane < n) x[(size_t)b * n + k * kWave + lane] = xv.v[k];
+  if (lane == 0) {
+    int st = res.status;
+    // weighted collision cost of the last evaluated x against the tolerance (:233-237)
+    if (res.costs_last[3] * prm.w[3] > prm.coll_tol) st |= NEO_TRAJ_FLAG_COLLISION;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      costs4[(size_t)b * 4 + k] = res.costs[k];
+      if (costs4_last) costs4_last[(size_t)b * 4 + k] = res.costs_last[k];
+    }
+    nit[b] = res.nit;
+    nfev[b] = res.nfev;
+    status[b] = st;
+    if (nsamples) nsamples[b] = be.samples;
+  }
+}
+
+// add_sampled_cost + add_sampled_grad_CT (expert_planner.py:392-466) as a kernel of its own: the ESDF
+// lookup kernel.  Input: polynomial coefficients and durations; output: the two sampled cost terms and
+// their partials w.r.t. coefficients and durations.  One wavefront per trajectory; every lane reads the
+// coefficients of its piece straight into the SAMPLE layout and the first lane of each piece writes the
+// piece's partials.  fp32: <= 128 VGPRs, so four waves per SIMD -- the whole cfg2 batch is resident at once and
+// the gathers of different trajectories overlap (one sample per lane in flight is enough then).
+#ifndef NEO_SAMPLE_U
+#define NEO_SAMPLE_U 1
+#endif
+template <int D, typename Real, class MapT, class LookupT>
+__global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? 4 : 2) void sample_kernel(int B, int M, DevParams prm, MapT map,
+                                                                                  const double *__restrict__ coeffs,
+                                                                                  const double *__restrict__ ts,
+                                                                                  double *__restrict__ costs2,
+                                                                                  double *__restrict__ grad_C,
+                                                                                  double *__restrict__ grad_T) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int lane = lane_id();
+  const int L = sample_lanes_per_piece(M);
+  const int piece = (lane * ((65536 + L - 1) / L)) >> 16;
+  const int r = lane - piece * L;
+  const bool act = piece < M;
+  const double T = act ? ts[(size_t)b * M + piece] : 1.0;
+  const int ns = act ? (int)(T / prm.delta_t) : 0;
+  Real c[6][D], gC[6][D], gT;
+  {
+    // the 6*D doubles of a piece are contiguous and 16-byte aligned (6*D is even)
+    const double2 *src = reinterpret_cast<const double2 *>(coeffs + ((size_t)b * 6 * M + 6 * (act ? piece : 0)) * D);
+#pragma unroll
+    for (int q = 0; q < 3 * D; ++q) {
+      const double2 v = src[q];
+      const int e0 = 2 * q, e1 = 2 * q + 1;
+      c[e0 / D][e0 % D] = act ? (Real)v.x : Real(0);
+      c[e1 / D][e1 % D] = act ? (Real)v.y : Real(0);
+    }
+  }
+  double cf, ck;
+  LookupT lk(map);
+  minco_sample<Real, D, LookupT, NEO_SAMPLE_U, true>(M, L, ns, c, prm, lk, gC, gT, cf, ck);
+  if (act && r == 0) {
+    double2 *dst = reinterpret_cast<double2 *>(grad_C + ((size_t)b * 6 * M + 6 * piece) * D);
+#pragma unroll
+    for (int q = 0; q < 3 * D; ++q) {
+      const int e0 = 2 * q, e1 = 2 * q + 1;
+      dst[q] = make_double2((double)gC[e0 / D][e0 % D], (double)gC[e1 / D][e1 % D]);
+    }
+    grad_T[(size_t)b * M + piece] = (double)gT;
+  }
+  if (lane == 0) {
+    costs2[(size_t)b * 2 + 0] = cf;
+    costs2[(size_t)b * 2 + 1] = ck;
+  }
+}
+
+}  // namespace neo

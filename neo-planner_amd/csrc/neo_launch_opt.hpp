@@ -1,0 +1,28 @@
+// neo_launch_opt.hpp -- launch of one optimize_kernel family member (shared by the neo_disp_opt*.hip units)
+#pragma once
+#include "neo_host.hpp"
+#include "neo_kernels.hpp"
+
+namespace neo {
+
+template <int D, typename Real, class MapT, class LookupT, int WAVES = 1>
+int launch_opt(neo_ctx *c, const OptArgs &a) {
+  const dim3 grid(a.B), blk(kWave);
+  const size_t dyn = (size_t)2 * NEO_LBFGS_M * (D * (a.M - 1) + a.M) * sizeof(double);  // L-BFGS pairs in LDS
+#define NEO_OPT(NS)                                                                                           \
+  hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES>), grid, blk, dyn, c->stream, a.B, a.M, c->dev, \
+                     static_cast<const MapT *>(a.table), a.slots, a.nmaps, a.x, a.head, a.tail, a.costs4,      \
+                     a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter,                                \
+                     (c->order_B == a.B ? c->dispatch_order : nullptr))
+  switch (slots_for(a.M, D)) {
+    case 1: NEO_OPT(1); break;
+    case 2: NEO_OPT(2); break;
+    default:
+      if constexpr (WAVES == 1 || NEO_W2_MAX_SLOTS >= 4) NEO_OPT(4);  // (two waves only up to NEO_W2_MAX_SLOTS)
+      break;
+  }
+#undef NEO_OPT
+  return NEO_OK;
+}
+
+}  // namespace neo

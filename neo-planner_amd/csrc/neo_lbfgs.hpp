@@ -17,7 +17,7 @@
 // Pinned by tests/test_lbfgs_host.py against SciPy 1.15.3 iterate traces (tests/golden g3_*).
 //
 // The template runs on whatever `Backend` provides: the HIP kernels give it
-// wavefront-cooperative vectors (neo_kernels.hip), the host test harness plain arrays.
+// wavefront-cooperative vectors (neo_kernels.hpp), the host test harness plain arrays.
 #pragma once
 #include "neo_linesearch.hpp"
 

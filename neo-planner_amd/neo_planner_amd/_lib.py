@@ -13,7 +13,7 @@ NEO_OK = 0
 NEO_F64, NEO_F32, NEO_F16 = 0, 1, 2
 NEO_LAYOUT_LINEAR, NEO_LAYOUT_BRICK4, NEO_LAYOUT_CELL8 = 0, 1, 2
 NEO_TRAJ_CONVERGED_GRAD, NEO_TRAJ_CONVERGED_F, NEO_TRAJ_ABNORMAL = 0, 1, 2
-NEO_TRAJ_MAXITER, NEO_TRAJ_NUMERIC_RANGE, NEO_TRAJ_NONFINITE = 3, 4, 5
+NEO_TRAJ_MAXITER, NEO_TRAJ_NUMERIC_RANGE, NEO_TRAJ_NONFINITE, NEO_TRAJ_BAD_SCENE = 3, 4, 5, 6
 NEO_TRAJ_FLAG_COLLISION = 0x100
 NEO_KERNEL_EVAL, NEO_KERNEL_OPTIMIZE, NEO_KERNEL_ESDF_BUILD, NEO_KERNEL_ESDF_SAMPLE = 0, 1, 2, 3
 NEO_FLAG_ONE_WAVE_PER_SIMD, NEO_FLAG_TWO_WAVES_PER_SIMD, NEO_FLAG_LANE_GROUPS = 32, 64, 128

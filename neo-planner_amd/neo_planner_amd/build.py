@@ -1,4 +1,8 @@
-"""Builds libneo_planner_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Builds libneo_planner_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+The library is several translation units -- the C ABI plus one unit per kernel family (neo_disp_*.hip) -- compiled
+in parallel and linked into one shared object; objects are cached under csrc/build/ by source time stamps."""
+import concurrent.futures
 import os
 import shutil
 import subprocess
@@ -7,36 +11,66 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(PKG), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(PKG)), "include")
 LIB = os.path.join(PKG, "libneo_planner_hip.so")
-SOURCES = ["neo_kernels.hip"]
-DEPS = ["neo_kernels.hip", "neo_device.hpp", "neo_lbfgs.hpp", "neo_linesearch.hpp", "neo_lbfgs_sm.hpp", "neo_group.hpp",
-        "neo_group_kernel.hpp"]
+OBJDIR = os.path.join(CSRC, "build")
+SOURCES = ["neo_abi.hip", "neo_disp_eval.hip", "neo_disp_sample.hip", "neo_disp_opt2d.hip", "neo_disp_opt3d_f32.hip",
+           "neo_disp_opt3d_f64.hip", "neo_disp_opt3d_w2.hip", "neo_disp_group.hip"]
+HEADERS = ["neo_device.hpp", "neo_kernels.hpp", "neo_host.hpp", "neo_launch_opt.hpp", "neo_lbfgs.hpp",
+           "neo_linesearch.hpp", "neo_lbfgs_sm.hpp", "neo_group.hpp", "neo_group_kernel.hpp"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, d) for d in DEPS] + [os.path.join(INCLUDE, "neo_planner.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
-
-
-def build(force=False, verbose=False):
-    """compile the HIP library if it is missing or older than its sources; returns its path"""
-    if not force and not _stale():
-        return LIB
+def _hipcc():
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libneo_planner_hip.so")
+    return hipcc
+
+
+def _flags():
     # NEO_BUILD_DEFS="-DNEO_STAMPS ..." : experiment builds only (tools/); the product is built without
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-I", INCLUDE] + os.environ.get("NEO_BUILD_DEFS", "").split() + \
-          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I", INCLUDE] + \
+        os.environ.get("NEO_BUILD_DEFS", "").split()
+
+
+def _newest_header():
+    deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "neo_planner.h")]
+    return max(os.path.getmtime(d) for d in deps)
+
+
+def _compile(src, obj, verbose):
+    cmd = [_hipcc()] + _flags() + ["-c", os.path.join(CSRC, src), "-o", obj + ".tmp"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(obj + ".tmp", obj)
+
+
+def build(force=False, verbose=False, jobs=None):
+    """compile the translation units that are missing or older than their sources (in parallel), link; returns the
+    library's path"""
+    src_t = max([_newest_header()] + [os.path.getmtime(os.path.join(CSRC, s)) for s in SOURCES])
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= src_t:
+        return LIB          # (the GPU box receives the built library without the object cache)
+    os.makedirs(OBJDIR, exist_ok=True)
+    tag = "_".join(os.environ.get("NEO_BUILD_DEFS", "").split()).replace("-D", "").replace("=", "-")
+    hdr_t = _newest_header()
+    todo, objs = [], []
+    for s in SOURCES:
+        obj = os.path.join(OBJDIR, s.replace(".hip", (("." + tag) if tag else "") + ".o"))
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(os.path.join(CSRC, s))):
+            todo.append((s, obj))
+    jobs = jobs or int(os.environ.get("NEO_BUILD_JOBS", "0")) or min(len(todo) or 1, os.cpu_count() or 1, 8)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(jobs, 1)) as ex:
+        for f in [ex.submit(_compile, s, o, verbose) for s, o in todo]:
+            f.result()
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

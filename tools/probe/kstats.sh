@@ -1,15 +1,22 @@
 #!/bin/bash
-# register / scratch footprint of the cfg2 kernels of a slim build: tools/probe/kstats.sh [extra -D flags]
+# register / scratch footprint of the kernels of one translation unit:
+#   tools/probe/kstats.sh [unit.hip ...] [-Dflags]       default unit: neo_disp_opt3d_w2.hip (the two-waves optimiser)
+# -DNEO_SLIM_BUILD keeps only the cfg2 instantiation (linear fp32 field) of the optimiser units.
 cd "$(dirname "$0")/../../neo-planner_amd/csrc" || exit 1
 mkdir -p /tmp/isa
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -S --cuda-device-only -w -DNEO_SLIM_BUILD "$@" -o /tmp/isa/slim.s neo_kernels.hip || exit 1
-python3 - <<'PY'
-import re
-txt=open('/tmp/isa/slim.s').read()
-for m in re.finditer(r'\.name:\s+(\S+)\n(.*?)\.wavefront_size', txt, re.S):
-    name=m.group(1); body=m.group(2)
-    if 'optimize_kernel' not in name and 'sample_kernel' not in name: continue
-    g=lambda k: re.search(k+r':\s+(\d+)', body)
-    short=re.sub(r'.*(optimize_kernel|sample_kernel)ILi3E', r'\1<', name)[:40]
-    print(short, 'vgpr', g(r'\.vgpr_count').group(1), 'agpr', g(r'\.agpr_count').group(1) if g(r'\.agpr_count') else '-', 'spill', g(r'\.vgpr_spill_count').group(1), 'scratch', g(r'\.private_segment_fixed_size').group(1))
+units=(); flags=()
+for a in "$@"; do case "$a" in *.hip) units+=("$a");; *) flags+=("$a");; esac; done
+[ ${#units[@]} -eq 0 ] && units=(neo_disp_opt3d_w2.hip)
+for u in "${units[@]}"; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -S --cuda-device-only -w "${flags[@]}" -o /tmp/isa/${u%.hip}.s $u || exit 1
+  python3 - /tmp/isa/${u%.hip}.s <<'PY'
+import re, sys
+txt=open(sys.argv[1]).read()
+meta=txt[txt.index('amdhsa.kernels:'):]
+for blk in re.split(r'\n  - ', meta)[1:]:
+    g=lambda k: (re.search(r'\.'+k+r':\s+(\S+)', blk) or [None,'-'])[1]
+    short=re.sub(r'^_ZN3neo\d+', '', g('name'))[:64]
+    print(f"{short:64s} vgpr {g('vgpr_count'):>3} agpr {g('agpr_count'):>3} sgpr {g('sgpr_count'):>3} "
+          f"vspill {g('vgpr_spill_count'):>3} sspill {g('sgpr_spill_count'):>3} scratch {g('private_segment_fixed_size'):>4} lds {g('group_segment_fixed_size'):>5}")
 PY
+done

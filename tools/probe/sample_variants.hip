@@ -1,6 +1,6 @@
 // probe: variants of the stand-alone ESDF sample kernel (D = 3, fp32 arithmetic, fp32 linear field), timed
 // with HIP events.  Built by tools/gpu_sample_bench.py into tools/probe/_build/libsample_variants.so.
-// Not part of the product; winners move into neo_device.hpp / neo_kernels.hip.
+// Not part of the product; winners move into neo_device.hpp / neo_kernels.hpp.
 #include "../../neo-planner_amd/csrc/neo_device.hpp"
 #include <cstdio>
 #include <type_traits>
