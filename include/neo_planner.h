@@ -234,6 +234,11 @@ int neo_profile_enable(neo_ctx *ctx, int on);
 /* optional DEVICE array [B] that the next neo_optimize_batch_dev launches fill with the number of
  * quadrature samples (ESDF lookups) each trajectory evaluated; NULL switches it off. */
 int neo_optimize_sample_counter(neo_ctx *ctx, int64_t *dev_counts);
+/* diagnostics: optional DEVICE array [B][cap][4] that the next neo_optimize_batch[_dev] launches fill with one record
+ * per counted evaluation of every trajectory -- (f, line-search step, quadrature samples, iteration) -- so that a run
+ * can be laid beside the CPU optimiser's evaluation by evaluation (tools/classify_divergence.py); NULL switches it off.
+ * Not supported by the lane-group kernel. */
+int neo_optimize_trace(neo_ctx *ctx, double *dev_trace, int cap);
 /* optional DEVICE permutation [B] for the next neo_optimize_batch_dev launches: workgroup i works on
  * trajectory order[i].  Results stay in the caller's order.  Workgroups start in index order, so
  * putting the runs expected to be long first shortens the launch (a late long run is its tail);

@@ -1130,6 +1130,14 @@ int neo_optimize_sample_counter(neo_ctx *c, int64_t *dev_counts) {
   return NEO_OK;
 }
 
+int neo_optimize_trace(neo_ctx *c, double *dev_trace, int cap) {
+  if (!c || cap < 0) return NEO_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> g(c->mu);
+  c->trace = (dev_trace && cap > 0) ? dev_trace : nullptr;
+  c->trace_cap = c->trace ? cap : 0;
+  return NEO_OK;
+}
+
 int neo_optimize_dispatch_order(neo_ctx *c, const int32_t *dev_order, int B) {
   if (!c || B < 0) return NEO_ERR_INVALID;
   std::lock_guard<std::recursive_mutex> g(c->mu);

@@ -59,6 +59,8 @@ struct neo_ctx {
   long long *sample_counter = nullptr;  // optional device array [B] (neo_optimize_sample_counter)
   const int *dispatch_order = nullptr;  // optional device permutation [B] (neo_optimize_dispatch_order)
   int order_B = 0;                      // batch size the permutation was given for (ignored for any other B)
+  double *trace = nullptr;              // optional device array [B][trace_cap][4] (neo_optimize_trace)
+  int trace_cap = 0;
   int *order_buf = nullptr;             // device copy of a host permutation (neo_optimize_dispatch_order_host)
   size_t order_cap = 0;
 };

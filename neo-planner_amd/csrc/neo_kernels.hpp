@@ -45,6 +45,9 @@ struct DevBackend {
   int npad, m;
   double *coeff_out;  // optional [6M][D] (eval kernel)
   long long samples = 0;  // quadrature samples visited so far (lane-uniform), for the bench's byte count
+  int last_ns = 0;        // samples of the last evaluation
+  double *trace = nullptr;  // optional [trace_cap][4] of this trajectory: (f, step, samples, iteration) per evaluation
+  int trace_cap = 0;
 #ifdef NEO_STAMPS  // timing experiments (tools/gpu_straggler.py): 100 MHz wall-clock ticks per phase
   long long tk[4] = {0, 0, 0, 0};  // forward, sample, backward, evaluations
 #endif
@@ -116,6 +119,17 @@ struct DevBackend {
   __device__ __forceinline__ double *cost_store() { return cst_reg; }
 #endif
 
+  // diagnostics (neo_optimize_trace): one record per counted evaluation
+  __device__ __forceinline__ void note_eval(int nfev, int iter, double stp, double f) {
+    if (trace != nullptr && nfev <= trace_cap && lane_id() == 0) {
+      double *r = trace + (size_t)(nfev - 1) * 4;
+      r[0] = f;
+      r[1] = stp;
+      r[2] = (double)last_ns;
+      r[3] = (double)iter;
+    }
+  }
+
   // FLAT x -> PIECE inputs
   __device__ __forceinline__ void scatter_x(const Vec &x) {
     const int lane = lane_id();
@@ -152,7 +166,8 @@ struct DevBackend {
       for (int k = 0; k < 4; ++k) costs[k] = 0.0;
       return st;
     }
-    samples += (long long)wave_sum(lane < t.M ? t.ns : 0);
+    last_ns = wave_sum(lane < t.M ? t.ns : 0);
+    samples += (long long)last_ns;
     if (coeff_out != nullptr && lane < t.M) {
 #pragma unroll
       for (int k = 0; k < 6; ++k)
@@ -281,7 +296,8 @@ __global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, De
                                                           int *__restrict__ nit, int *__restrict__ nfev,
                                                           int *__restrict__ status,
                                                           long long *__restrict__ nsamples,
-                                                          const int *__restrict__ order) {
+                                                          const int *__restrict__ order, double *__restrict__ trace,
+                                                          int trace_cap) {
   __shared__ double xs[NS * kWave];
   __shared__ double sc[2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm;
@@ -311,6 +327,8 @@ __global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, De
   be.cst = cst;
   be.m = NEO_LBFGS_M;
   be.coeff_out = nullptr;
+  be.trace = trace ? trace + (size_t)b * trace_cap * 4 : nullptr;
+  be.trace_cap = trace_cap;
   load_boundary<D>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
   const int n = be.t.n;
   be.npad = NS * kWave;

@@ -13,7 +13,7 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
   hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES>), grid, blk, dyn, c->stream, a.B, a.M, c->dev, \
                      static_cast<const MapT *>(a.table), a.slots, a.nmaps, a.x, a.head, a.tail, a.costs4,      \
                      a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter,                                \
-                     (c->order_B == a.B ? c->dispatch_order : nullptr))
+                     (c->order_B == a.B ? c->dispatch_order : nullptr), c->trace, c->trace_cap)
   switch (slots_for(a.M, D)) {
     case 1: NEO_OPT(1); break;
     case 2: NEO_OPT(2); break;

@@ -57,6 +57,8 @@ struct LbfgsResult {
 //   LineSearch& ls(); double* cost_store();   storage for the search state and 3 x 4 cost terms
 //       (on the GPU both live in LDS: wave-uniform data that would otherwise pin ~50 VGPRs)
 //   int  eval(const Vec& x, double& f, Vec& g, double* costs4);   0 = ok
+//   void note_eval(int nfev, int iter, double stp, double f);     diagnostics hook after every counted evaluation
+//       (a no-op in the product unless a trace buffer was given: neo_optimize_trace)
 template <class Backend>
 NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpts &o,
                            LbfgsResult &res) {
@@ -84,6 +86,7 @@ NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpt
 
   int est = be.eval(x, f, g, costs);
   nfev++;
+  be.note_eval(nfev, 0, 0.0, f);
   for (int k = 0; k < 4; ++k) cur[k] = costs[k];
   if (est != 0) return finish(est);
   if (!(f - f == 0.0)) return finish(TERM_NONFINITE);
@@ -157,6 +160,7 @@ NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpt
         be.lincomb(x, t, stp, d);
         est = be.eval(x, f, g, costs);
         nfev++;
+        be.note_eval(nfev, iter, stp, f);
         if (est != 0) {
           term = est;
           break;

@@ -27,7 +27,7 @@ EXPORTS = [
     "neo_optimize_workspace_bytes", "neo_eval_traj_batch", "neo_profile_enable", "neo_profile_read",
     "neo_profile_reset", "neo_optimize_sample_counter", "neo_optimize_dispatch_order",
     "neo_sampled_terms_batch", "neo_sampled_terms_batch_dev", "neo_esdf_build_3d",
-    "neo_optimize_dispatch_order_host", "neo_ctx_set_stream",
+    "neo_optimize_dispatch_order_host", "neo_ctx_set_stream", "neo_optimize_trace",
 ]
 
 
@@ -92,6 +92,7 @@ def load():
     L.neo_profile_read.argtypes = [c_p, c_i, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(c_d)]
     L.neo_profile_reset.argtypes = [c_p]
     L.neo_optimize_sample_counter.argtypes = [c_p, c_p]
+    L.neo_optimize_trace.argtypes = [c_p, c_p, c_i]
     L.neo_optimize_dispatch_order.argtypes = [c_p, c_p, c_i]
     L.neo_optimize_dispatch_order_host.argtypes = [c_p, c_p, c_i]
     L.neo_sampled_terms_batch.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 5

@@ -73,7 +73,7 @@ def load():
         L.mc_cost.argtypes = [c_p, c_p, c_p, c_p]
         L.mc_grad.argtypes = [c_p, c_p, c_p, c_p, c_p, c_p, c_p]
         L.mc_optimize_batch.argtypes = [ctypes.POINTER(Params), ctypes.POINTER(Map), c_i, c_i, c_i] + [c_p] * 8 + \
-                                       [c_i, c_d, c_p]
+                                       [c_i, c_d, c_p, c_p, c_i]
         _lib = L
     return _lib
 
@@ -219,9 +219,10 @@ class NativePlanner:
             raise ValueError("collision cost too large")
 
 
-def optimize_batch(map, x0, head, tail, M, D, params=None, threads=1, limit_s=0.0):
+def optimize_batch(map, x0, head, tail, M, D, params=None, threads=1, limit_s=0.0, trace_cap=0):
     """plan_once for every row of x0 [B][n] on `threads` host threads (optimiser: csrc/neo_lbfgs.hpp).
-    Returns dict(x, costs, costs_last, nit, nfev, status, done, finished)."""
+    Returns dict(x, costs, costs_last, nit, nfev, status, done, finished[, trace]); trace [B][trace_cap][4] =
+    (f, step, samples, iteration) per counted evaluation."""
     L = load()
     p = params if params is not None else make_params()
     x = np.array(x0, dtype=np.float64, order="C")
@@ -234,9 +235,14 @@ def optimize_batch(map, x0, head, tail, M, D, params=None, threads=1, limit_s=0.
     nfev = np.zeros(B, dtype=np.int32)
     st = np.zeros(B, dtype=np.int32)
     done = np.zeros(B, dtype=np.uint8)
+    trace = np.zeros((B, trace_cap, 4)) if trace_cap > 0 else None
     fin = L.mc_optimize_batch(ctypes.byref(p), ctypes.byref(map.c), B, M, D, x.ctypes.data, head.ctypes.data,
                               tail.ctypes.data, c4.ctypes.data, c4l.ctypes.data, nit.ctypes.data, nfev.ctypes.data,
-                              st.ctypes.data, int(threads), float(limit_s), done.ctypes.data)
+                              st.ctypes.data, int(threads), float(limit_s), done.ctypes.data,
+                              trace.ctypes.data if trace is not None else None, int(trace_cap))
     if fin < 0:
         raise ValueError("bad arguments")
-    return dict(x=x, costs=c4, costs_last=c4l, nit=nit, nfev=nfev, status=st, done=done.astype(bool), finished=fin)
+    out = dict(x=x, costs=c4, costs_last=c4l, nit=nit, nfev=nfev, status=st, done=done.astype(bool), finished=fin)
+    if trace is not None:
+        out["trace"] = trace
+    return out

@@ -542,6 +542,19 @@ struct HostBackend {
   void hist_get_y(int slot, Vec &v) const { v.assign(&Y[(size_t)slot * n], &Y[(size_t)slot * n] + n); }
   void sput(int i, double v) { scal[i] = v; }
   double sget(int i) const { return scal[i]; }
+  double *trace = nullptr;  // optional [trace_cap][4]: (f, step, samples, iteration) per counted evaluation
+  int trace_cap = 0;
+  void note_eval(int nfev, int iter, double stp, double f) {
+    if (trace && nfev <= trace_cap) {
+      double *r = trace + (size_t)(nfev - 1) * 4;
+      int ns = 0;
+      for (int i = 0; i < pl.M; ++i) ns += (int)(pl.ts[i] / pl.p.delta_t);
+      r[0] = f;
+      r[1] = stp;
+      r[2] = (double)ns;
+      r[3] = (double)iter;
+    }
+  }
   // SciPy calls fun(x) then jac(x): the reference solves the system twice per trial point
   int eval(const Vec &x, double &f, Vec &g, double *costs4) {
     fit(g);
@@ -555,10 +568,12 @@ struct HostBackend {
 };
 
 int optimize_one(const mc_params &p, const mc_map &m, int M, int D, double *x, const double *head, const double *tail,
-                 double *costs4, double *costs4_last, int *nit, int *nfev, int *status) {
+                 double *costs4, double *costs4_last, int *nit, int *nfev, int *status, double *trace, int trace_cap) {
   const int n = D * (M - 1) + M;
   Planner pl(p, m, M, D, head, tail);
   HostBackend be(pl, n, 10);
+  be.trace = trace;
+  be.trace_cap = trace_cap;
   HostBackend::Vec xv(x, x + n);
   neo::LbfgsOpts o{p.ftol, p.gtol, p.maxls, p.maxiter, p.maxfun, 10};
   neo::LbfgsResult res;
@@ -608,10 +623,11 @@ int mc_grad(void *h, const double *x, double *grad, double *coeffs, double *grad
 
 // plan_once for B trajectories on `threads` host threads, optimiser = csrc/neo_lbfgs.hpp on plain arrays.
 // x[B][n] in/out, head/tail [B][3][D]; outputs as neo_optimize_batch.  limit_s > 0: stop handing out new
-// trajectories after that many seconds; done[B] = 1 for the finished ones.  Returns the number finished.
+// trajectories after that many seconds; done[B] = 1 for the finished ones.  trace: optional [B][trace_cap][4]
+// records (f, step, samples, iteration) per counted evaluation.  Returns the number finished.
 int mc_optimize_batch(const mc_params *p, const mc_map *m, int B, int M, int D, double *x, const double *head,
                       const double *tail, double *costs4, double *costs4_last, int32_t *nit, int32_t *nfev,
-                      int32_t *status, int threads, double limit_s, uint8_t *done) {
+                      int32_t *status, int threads, double limit_s, uint8_t *done, double *trace, int trace_cap) {
   if (!p || !m || B < 0 || M < 1 || M > 64 || D < 2 || D > 3) return -1;
   const int n = D * (M - 1) + M;
   std::atomic<int> next{0}, fin{0};
@@ -626,7 +642,7 @@ int mc_optimize_batch(const mc_params *p, const mc_map *m, int B, int M, int D, 
       int it = 0, fe = 0, st = 0;
       optimize_one(*p, *m, M, D, x + (size_t)b * n, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D,
                    costs4 ? costs4 + (size_t)b * 4 : nullptr, costs4_last ? costs4_last + (size_t)b * 4 : nullptr, &it, &fe,
-                   &st);
+                   &st, trace ? trace + (size_t)b * trace_cap * 4 : nullptr, trace_cap);
       nit[b] = it;
       nfev[b] = fe;
       status[b] = st;

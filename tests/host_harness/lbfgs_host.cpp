@@ -65,6 +65,7 @@ struct HostBackend {
     fit(g, n);
     return cb(x.data(), n, &f, g.data(), costs, user);
   }
+  void note_eval(int, int, double, double) {}
 };
 }  // namespace
 
