@@ -1,4 +1,5 @@
-// neo_device.hpp -- device-side MINCO cost/gradient for one trajectory per wavefront (gfx950).
+// neo_device.hpp -- device-side MINCO cost/gradient for one trajectory per lane group (gfx950): the whole
+// wavefront (WaveLanes) or, for small problems, 16 or 8 lanes (GroupLanes<W>).  ONE source for both.
 //
 // One 64-lane wavefront owns one trajectory.  Two lane layouts are used:
 //   PIECE  layout: lane p  <-> polynomial piece p (p < M <= 64) and joint p (its start);
@@ -386,6 +387,85 @@ struct Lookup3D {
   }
 };
 
+// ------------------------------------------------------------------ lane groups
+// The per-trajectory functions below are written once for a GROUP of lanes that owns one trajectory:
+//   WaveLanes      the whole 64-lane wavefront (optimize / eval / sample kernels);
+//   GroupLanes<W>  W = 16 or 8 lanes: four or eight small trajectories share a wavefront (optimize_group_kernel) and
+//                  run the same instruction stream in lock step.
+// `lane()` is the lane inside the group; cross-lane traffic (sums, neighbour moves, broadcasts) stays inside the
+// group, which for W <= 16 lies inside one 16-lane DPP row.  All lanes of a wavefront call the functions together.
+struct WaveLanes {
+  static constexpr int W = kWave;
+  static __device__ __forceinline__ int lane() { return lane_id(); }
+  static __device__ __forceinline__ int base() { return 0; }
+  static __device__ __forceinline__ double read(double v, int src /*wave-uniform*/) { return rdlane(v, src); }
+  static __device__ __forceinline__ double prev(double v, double fill) { return from_prev(v, fill); }
+  static __device__ __forceinline__ double next(double v, double fill) { return from_next(v, fill); }
+  static __device__ __forceinline__ double sum(double v) { return wave_sum(v); }
+  static __device__ __forceinline__ int sum(int v) { return wave_sum(v); }
+  static __device__ __forceinline__ int any(int pred) { return __any(pred); }
+  static __host__ __device__ __forceinline__ int lanes_per_piece(int M);
+};
+
+template <int W_>
+struct GroupLanes {
+  static_assert(W_ == 16 || W_ == 8, "a group is a DPP row or half of one");
+  static constexpr int W = W_;
+  static __device__ __forceinline__ int lane() { return lane_id() & (W - 1); }
+  static __device__ __forceinline__ int base() { return lane_id() & ~(W - 1); }
+  // sums / maxima over the group, result in every lane.  W = 16: the in-row part of wave_sum (row_shr scan, then the
+  // last lane's value to everybody).  W = 8: xor butterfly (quad_perm swaps, then row_half_mirror), which never reads
+  // the other group of the row.  Both associate ((v0+v1)+(v2+v3)) + ((v4+v5)+(v6+v7)) [+ the same of the upper half].
+  template <class T, class Op>
+  static __device__ __forceinline__ T reduce(T v, Op op) {
+    if constexpr (W == 16) {
+      if constexpr (sizeof(T) == 8) {
+        v = op(v, dpp_d<0x111>(v)); v = op(v, dpp_d<0x112>(v)); v = op(v, dpp_d<0x114>(v)); v = op(v, dpp_d<0x118>(v));
+      } else {
+        v = op(v, dpp_i<0x111>(v)); v = op(v, dpp_i<0x112>(v)); v = op(v, dpp_i<0x114>(v)); v = op(v, dpp_i<0x118>(v));
+      }
+      return __shfl(v, base() + W - 1, kWave);
+    } else {
+      // quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E, row_half_mirror = 0x141
+      if constexpr (sizeof(T) == 8) {
+        v = op(v, dpp_d<0xB1>(v)); v = op(v, dpp_d<0x4E>(v)); v = op(v, dpp_d<0x141>(v));
+      } else {
+        v = op(v, dpp_i<0xB1>(v)); v = op(v, dpp_i<0x4E>(v)); v = op(v, dpp_i<0x141>(v));
+      }
+      return v;
+    }
+  }
+  static __device__ __forceinline__ double sum(double v) {
+    return reduce(v, [](double a, double b) { return a + b; });
+  }
+  static __device__ __forceinline__ int sum(int v) {
+    return reduce(v, [](int a, int b) { return a + b; });
+  }
+  static __device__ __forceinline__ double max_nonneg(double v) {
+    return reduce(v, [](double a, double b) { return fmax(a, b); });
+  }
+  static __device__ __forceinline__ int any(int pred) {
+    return reduce(pred ? 1 : 0, [](int a, int b) { return a | b; });
+  }
+  static __device__ __forceinline__ double read(double v, int src /* lane inside the group, the same for all groups */) {
+    return __shfl(v, base() + src, kWave);
+  }
+  static __device__ __forceinline__ double prev(double v, double fill) {
+    const double o = dpp_d<0x138>(v);  // wave_shr:1
+    return lane() == 0 ? fill : o;
+  }
+  static __device__ __forceinline__ double next(double v, double fill) {
+    const double o = dpp_d<0x130>(v);  // wave_shl:1
+    return lane() == W - 1 ? fill : o;
+  }
+  static __host__ __device__ __forceinline__ int lanes_per_piece(int M) {
+    int L = W / M;
+    if (L < 1) L = 1;
+    if (L >= 8) L = (L >= 16 && W >= 16) ? 16 : 8;
+    return L;
+  }
+};
+
 // ------------------------------------------------------------------ per-trajectory state
 template <int D>
 struct Traj {
@@ -410,6 +490,7 @@ struct Traj {
 // The transposed system of the adjoint pass reuses the same pivot inverses: the Schur complements of
 // K^T are the transposes of those of K, so its N is N^T and its E is N^T Lo_{p+1}^T -- no second
 // factorisation, no second set of divisions.
+template <class LG = WaveLanes>
 __device__ __forceinline__ void thomas_factor(int M, const double (&Lo)[2][2], const double (&Di)[2][2],
                                               const double (&Up)[2][2], double (&N)[2][2], double (&E)[2][2]) {
   // The recurrence E_p = (Di_p - Lo_p E_{p-1})^-1 Up_p is carried as a fraction E = Eh / dl so that the
@@ -417,13 +498,13 @@ __device__ __forceinline__ void thomas_factor(int M, const double (&Lo)[2][2], c
   // Eh_p = s dl_{p-1} adj(Dh) Up_p,  dl_p = s det(Dh),  s = a power of two that brings dl_p to
   // [0.5, 1) so nothing over/underflows.  Each lane keeps its own Dh and dl_{p-1} and forms
   // N_p = dl_{p-1} adj(Dh)/det(Dh) and E_p = Eh_p/dl_p after the loop, all lanes in parallel.
-  const int lane = lane_id();
+  const int lane = LG::lane();
   double Eh[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, dl = 1.0;  // lane 0: E_0 = 0
   double Dh[2][2] = {{1.0, 0.0}, {0.0, 1.0}}, dprev = 1.0;
   for (int p = 1; p < M; ++p) {
-    const double e00 = rdlane(Eh[0][0], p - 1), e01 = rdlane(Eh[0][1], p - 1);
-    const double e10 = rdlane(Eh[1][0], p - 1), e11 = rdlane(Eh[1][1], p - 1);
-    const double dp = rdlane(dl, p - 1);
+    const double e00 = LG::read(Eh[0][0], p - 1), e01 = LG::read(Eh[0][1], p - 1);
+    const double e10 = LG::read(Eh[1][0], p - 1), e11 = LG::read(Eh[1][1], p - 1);
+    const double dp = LG::read(dl, p - 1);
     const double h00 = dp * Di[0][0] - (Lo[0][0] * e00 + Lo[0][1] * e10);
     const double h01 = dp * Di[0][1] - (Lo[0][0] * e01 + Lo[0][1] * e11);
     const double h10 = dp * Di[1][0] - (Lo[1][0] * e00 + Lo[1][1] * e10);
@@ -467,12 +548,12 @@ __device__ __forceinline__ void thomas_factor(int M, const double (&Lo)[2][2], c
 // prefix / suffix scans over the lanes: ceil(log2 M) steps, every lane busy, 10x shorter
 // dependent chain.  |A| < 1 for these diagonally dominant systems, so the products decay
 // (checked against the sequential sweep to 6e-15 over T in [0.5,5]^M, M <= 64).
-template <int D>
+template <int D, class LG = WaveLanes>
 __device__ __forceinline__ void thomas_solve(int M, const double (&Lo)[2][2], const double (&N)[2][2],
                                              const double (&E)[2][2], const double (&R)[2][D],
                                              const double (&y0)[2][D], const double (&yM)[2][D],
                                              double (&y)[2][D]) {
-  const int lane = lane_id();
+  const int lane = LG::lane();
   double A[2][2], b[2][D];
   // ---- forward: lane 0 is the constant map v -> y_0
   {
@@ -570,10 +651,10 @@ __device__ __forceinline__ void joint_blocks(const Traj<D> &t, double a1, double
 
 // forward pass.  Inputs (PIECE layout): t.tau, t.P0, t.P1 set by the caller, head/tail uniform.
 // Returns 0 or NUMERIC_RANGE (4) when exp(-tau) overflows like math.exp does (:481).
-template <int D>
+template <int D, class LG = WaveLanes>
 __device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, double &energy,
                                              double &time_sum) {
-  const int lane = lane_id();
+  const int lane = LG::lane();
   const bool act = lane < t.M;
   int bad = 0;
   // map_tau2T (:477-483)
@@ -584,7 +665,7 @@ __device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, d
     t.T = (prm.T_max - prm.T_min) / (1.0 + ex) + prm.T_min;
     t.tau = ex;  // get_grad_T2tau needs exp(-tau) again (:490): keep it instead of tau
   }
-  if (__any(bad)) return 4;
+  if (LG::any(bad)) return 4;
   t.i1 = 1.0 / t.T;
   t.i2 = t.i1 * t.i1;
   t.i3 = t.i2 * t.i1;
@@ -593,14 +674,14 @@ __device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, d
 
   if (t.M > 1) {
     double Lo[2][2], Di[2][2], Up[2][2], E[2][2], R[2][D], y0[2][D], yM[2][D], y[2][D];
-    const double a1 = from_prev(t.i1, 1.0), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;
+    const double a1 = LG::prev(t.i1, 1.0), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;
     joint_blocks(t, a1, a2, a3, Lo, Di, Up);
-    thomas_factor((prm.dbg & (2 | 8)) ? 1 : t.M, Lo, Di, Up, t.N, E);
+    thomas_factor<LG>((prm.dbg & (2 | 8)) ? 1 : t.M, Lo, Di, Up, t.N, E);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       // displacement of piece p-1 and of piece p
       const double dPb = t.P1[d] - t.P0[d];
-      const double dPa = from_prev(dPb, 0.0);
+      const double dPa = LG::prev(dPb, 0.0);
       R[0][d] = -(60.0 * a3 * dPa - 60.0 * t.i3 * dPb);
       R[1][d] = -(360.0 * a4 * dPa + 360.0 * t.i4 * dPb);
       y0[0][d] = t.head[1 * D + d];
@@ -608,7 +689,7 @@ __device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, d
       yM[0][d] = t.tail[1 * D + d];
       yM[1][d] = t.tail[2 * D + d];
     }
-    thomas_solve<D>((prm.dbg & (2 | 16)) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);
+    thomas_solve<D, LG>((prm.dbg & (2 | 16)) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       t.V0[d] = lane == 0 ? t.head[1 * D + d] : y[0][d];
@@ -623,7 +704,7 @@ __device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, d
   }
 #pragma unroll
   for (int d = 0; d < D; ++d) {
-    const double v1 = from_next(t.V0[d], 0.0), a1 = from_next(t.A0[d], 0.0);
+    const double v1 = LG::next(t.V0[d], 0.0), a1 = LG::next(t.A0[d], 0.0);
     t.V1[d] = (lane == t.M - 1) ? t.tail[1 * D + d] : v1;
     t.A1[d] = (lane == t.M - 1) ? t.tail[2 * D + d] : a1;
   }
@@ -646,8 +727,8 @@ __device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, d
     e += 36.0 * T * c3 * c3 + 144.0 * T2 * c3 * c4 + 240.0 * T3 * c3 * c5 + 192.0 * T3 * c4 * c4 +
          720.0 * T4 * c4 * c5 + 720.0 * T5 * c5 * c5;
   }
-  energy = wave_sum(act ? e : 0.0);
-  time_sum = wave_sum(act ? t.T : 0.0);  // add_time_cost (:386-387)
+  energy = LG::sum(act ? e : 0.0);
+  time_sum = LG::sum(act ? t.T : 0.0);  // add_time_cost (:386-387)
   return 0;
 }
 
@@ -686,6 +767,8 @@ __host__ __device__ __forceinline__ int sample_lanes_per_piece(int M) {
   if (L >= 8) L = L >= 64 ? 64 : (L >= 32 ? 32 : (L >= 16 ? 16 : 8));
   return L;
 }
+
+__host__ __device__ __forceinline__ int WaveLanes::lanes_per_piece(int M) { return sample_lanes_per_piece(M); }
 
 template <typename Real, int CTRL>
 __device__ __forceinline__ Real dpp_real(Real v) {
@@ -731,12 +814,12 @@ __device__ __forceinline__ Real fold_piece_lanes(Real v, int L, int r) {
 // SAMPLE_IO = true (stand-alone kernel): cp / ns_in are already those of the SAMPLE-layout lane's piece, and
 //   gC / gT are left in the first lane (r = 0) of each piece.
 // Costs are returned wave-uniform.  U = samples per lane whose gathers are put in flight together.
-template <typename Real, int D, class LookupT, int U, bool SAMPLE_IO = false>
+template <typename Real, int D, class LookupT, int U, bool SAMPLE_IO = false, class LG = WaveLanes>
 __device__ __forceinline__ void minco_sample(int M, int L, int ns_in, const Real (&cp)[6][D],
                                              const DevParams &prm, const LookupT &lk, Real (&gC)[6][D], Real &gT,
                                              double &cost_feas, double &cost_coll) {
 #pragma clang fp contract(on)  // fuse a*b+c only as written: the same arithmetic whatever the unrolling around it
-  const int lane = lane_id();
+  const int lane = LG::lane();
   const int piece = (lane * ((65536 + L - 1) / L)) >> 16;  // lane / L for lane < 64
   const int r = lane - piece * L;
   const bool act = piece < M;
@@ -753,8 +836,8 @@ __device__ __forceinline__ void minco_sample(int M, int L, int ns_in, const Real
 #pragma unroll
     for (int k = 0; k < 6; ++k)
 #pragma unroll
-      for (int d = 0; d < D; ++d) c[k][d] = __shfl(cp[k][d], piece, kWave);
-    const int ns_sh = __shfl(ns_in, piece, kWave);
+      for (int d = 0; d < D; ++d) c[k][d] = __shfl(cp[k][d], LG::base() + piece, kWave);
+    const int ns_sh = __shfl(ns_in, LG::base() + piece, kWave);
     ns = act ? ns_sh : 0;
   }
   const int iters = (prm.dbg & 1) ? 0 : wave_max_nonneg((ns + L - 1) / L);
@@ -873,7 +956,7 @@ __device__ __forceinline__ void minco_sample(int M, int L, int ns_in, const Real
   auto fold = [&](Real v) -> Real {
     const Real f = fold_piece_lanes<Real>(v, L, r);
     if constexpr (SAMPLE_IO) return f;
-    return __shfl(f, lane * L, kWave);
+    return __shfl(f, LG::base() + lane * L, kWave);
   };
 #pragma unroll
   for (int k = 0; k < 6; ++k)
@@ -882,8 +965,8 @@ __device__ __forceinline__ void minco_sample(int M, int L, int ns_in, const Real
   gT = fold(aT);
   const Real pf = fold(aF), pk = fold(aK);
   const bool mine = SAMPLE_IO ? (act && r == 0) : (lane < M);
-  cost_feas = wave_sum(mine ? (double)pf : 0.0);
-  cost_coll = wave_sum(mine ? (double)pk : 0.0);
+  cost_feas = LG::sum(mine ? (double)pf : 0.0);
+  cost_coll = LG::sum(mine ? (double)pk : 0.0);
 }
 
 // backward pass (PIECE layout): gC = dW/dc incl. sampled part, gT = direct dW/dT incl. sampled part
@@ -892,13 +975,13 @@ __device__ __forceinline__ void minco_sample(int M, int L, int ns_in, const Real
 // Returns 0, or 4 where the reference would leave through OverflowError: it raises Python floats to
 // a power in two places, `(np.dot(c, beta3).item())**2` (:382) and `(1+math.exp(-tau))**2` (:490),
 // and Python raises once such a result exceeds the double range instead of returning inf.
-template <int D>
+template <int D, class LG = WaveLanes>
 __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams &prm, double (&gC)[6][D],
                                               double gT, double (&gq)[D], double &gtau) {
-  const int lane = lane_id();
+  const int lane = LG::lane();
   const int M = t.M;
   int pow_overflow = 0;
-  const double a1 = from_prev(t.i1, 1.0), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;  // piece p-1
+  const double a1 = LG::prev(t.i1, 1.0), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;  // piece p-1
   const double T = t.T, T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
   const double w0 = prm.w[0];
   double jerk_end[D], snap_end[D], crackle[D];
@@ -935,7 +1018,7 @@ __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams 
 #pragma unroll
   for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int d = 0; d < D; ++d) S[k][d] = from_prev(gz[3 + k][d], 0.0) + gz[k][d];
+    for (int d = 0; d < D; ++d) S[k][d] = LG::prev(gz[3 + k][d], 0.0) + gz[k][d];
 
   double lam[2][D];
 #pragma unroll
@@ -960,7 +1043,7 @@ __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams 
       R[1][d] = S[2][d];
       z0[0][d] = z0[1][d] = 0.0;
     }
-    thomas_solve<D>((prm.dbg & (2 | 16)) ? 1 : M, LoT, NT, ET, R, z0, z0, y);
+    thomas_solve<D, LG>((prm.dbg & (2 | 16)) ? 1 : M, LoT, NT, ET, R, z0, z0, y);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       lam[0][d] = (lane >= 1 && lane < M) ? y[0][d] : 0.0;
@@ -975,8 +1058,8 @@ __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams 
     const double dp_prev = -60.0 * a3 * l1 - 360.0 * a4 * l2;
     const double dp_here = (60.0 * a3 + 60.0 * t.i3) * l1 + (360.0 * a4 - 360.0 * t.i4) * l2;
     const double dp_next = -60.0 * t.i3 * l1 + 360.0 * t.i4 * l2;
-    const double from_left = from_prev(dp_next, 0.0);   // joint p-1 pushes on p_{p}
-    const double from_right = from_next(dp_prev, 0.0);  // joint p+1 pushes on p_{p}
+    const double from_left = LG::prev(dp_next, 0.0);   // joint p-1 pushes on p_{p}
+    const double from_right = LG::next(dp_prev, 0.0);  // joint p+1 pushes on p_{p}
     gq[d] = S[0][d] - dp_here - (lane >= 2 ? from_left : 0.0) - (lane + 1 <= M - 1 ? from_right : 0.0);
     // tail sensitivity on lane M-1: S_M = gz[3:6] of the last piece, minus joint M-1's pull
     const double lt1 = (M > 1) ? l1 : 0.0, lt2 = (M > 1) ? l2 : 0.0;
@@ -991,7 +1074,7 @@ __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams 
     const double v1 = t.V1[d], a1 = t.A1[d], je = jerk_end[d];
     gTt -= gz[3][d] * v1 + gz[4][d] * a1 + gz[5][d] * je;
     // joint p+1 (this piece ends there): rows +je.Z, +se.Z
-    const double ln1 = from_next(lam[0][d], 0.0), ln2 = from_next(lam[1][d], 0.0);
+    const double ln1 = LG::next(lam[0][d], 0.0), ln2 = LG::next(lam[1][d], 0.0);
     if (lane + 1 <= M - 1) {
       const double d_je = snap_end[d] - (60.0 * t.i3 * v1 - 36.0 * t.i2 * a1 + 9.0 * t.i1 * je);
       const double d_se = crackle[d] - (360.0 * t.i4 * v1 - 192.0 * t.i3 * a1 + 36.0 * t.i2 * je);
@@ -1006,7 +1089,7 @@ __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams 
   }
   // the reference evaluates the tail rows' d/dT with the previous piece's duration (:528-533)
   {
-    const double Ts = from_prev(T, T);
+    const double Ts = LG::prev(T, T);
     if (prm.stale_T && M >= 2 && lane == M - 1) {
       const double S2 = Ts * Ts, S3 = S2 * Ts, S4 = S2 * S2;
 #pragma unroll
@@ -1027,7 +1110,7 @@ __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams 
   // `(1 + math.exp(-tau))**2` (:490) is a Python-float power too: OverflowError beyond sqrt(DBL_MAX)
   if (lane < M && (1.0 + ex) > 1.3407807929942596e154) pow_overflow = 1;
   gtau = gTt * (prm.T_max - prm.T_min) * ex / ((1.0 + ex) * (1.0 + ex));
-  return __any(pow_overflow) ? 4 : 0;
+  return LG::any(pow_overflow) ? 4 : 0;
 }
 
 }  // namespace neo

@@ -9,7 +9,7 @@
 // instead of 64 / M, so sums are associated differently than in optimize_kernel and results agree with it to
 // fp32 rounding, not bit for bit.
 #pragma once
-#include "neo_group.hpp"
+#include "neo_device.hpp"
 #include "neo_lbfgs_sm.hpp"
 
 namespace neo {
@@ -35,13 +35,13 @@ struct GroupBackend {
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < NS; ++k) s += a.v[k] * b.v[k];
-    return grp::grp_sum<W>(s);
+    return GroupLanes<W>::sum(s);
   }
   __device__ __forceinline__ double amax(const Vec &a) const {
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < NS; ++k) s = fmax(s, fabs(a.v[k]));
-    return grp::grp_max_nonneg<W>(s);
+    return GroupLanes<W>::max_nonneg(s);
   }
   __device__ __forceinline__ void copy(Vec &d, const Vec &s) const {
 #pragma unroll
@@ -64,7 +64,7 @@ struct GroupBackend {
     for (int k = 0; k < NS; ++k) v.v[k] *= s;
   }
   __device__ __forceinline__ void hist_put(int slot, const Vec &s, const Vec &y) {
-    const int gl = grp::glane<W>();
+    const int gl = GroupLanes<W>::lane();
 #pragma unroll
     for (int k = 0; k < NS; ++k)
       if (k * W + gl < t.n) {
@@ -74,7 +74,7 @@ struct GroupBackend {
     __syncthreads();
   }
   __device__ __forceinline__ void hist_get(int row, Vec &v) const {
-    const int gl = grp::glane<W>();
+    const int gl = GroupLanes<W>::lane();
 #pragma unroll
     for (int k = 0; k < NS; ++k) v.v[k] = (k * W + gl < t.n) ? hist[row * t.n + k * W + gl] : 0.0;
   }
@@ -90,7 +90,7 @@ struct GroupBackend {
 
   // one evaluation (get_cost + get_grad, :539-585); costs into registers, nsamp = samples visited
   __device__ __forceinline__ int eval(const Vec &x, double &f, Vec &g, double (&costs)[4], int &nsamp) {
-    const int lane = grp::glane<W>();
+    const int lane = GroupLanes<W>::lane();
     const int M = t.M;
     __syncthreads();
 #pragma unroll
@@ -105,11 +105,11 @@ struct GroupBackend {
       t.P1[d] = (lane >= M - 1) ? t.tail[d] : xs[d * (M - 1) + lane];
     }
     double energy = 0.0, tsum = 0.0;
-    const int st = grp::minco_forward<W, D>(t, prm, energy, tsum);
+    const int st = minco_forward<D, GroupLanes<W>>(t, prm, energy, tsum);
     // (a group whose forward pass fails -- exp overflow -- still walks through the rest on the state its last
     //  good evaluation left in `t`: the wavefront-wide loop bounds need finite values, and its own results are
     //  zeroed below exactly as DevBackend::eval returns them)
-    nsamp = grp::grp_sum<W>(act ? t.ns : 0);
+    nsamp = GroupLanes<W>::sum(act ? t.ns : 0);
     double gC[6][D], gT = 0.0, cf, ck;
     {
       Real cr[6][D], gCr[6][D], gTr;
@@ -118,7 +118,7 @@ struct GroupBackend {
 #pragma unroll
         for (int d = 0; d < D; ++d) cr[k][d] = (Real)t.c[k][d];
       LookupT lk(map);
-      grp::minco_sample<W, Real, D, LookupT, SU>(M, t.L, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
+      minco_sample<Real, D, LookupT, SU, false, GroupLanes<W>>(M, t.L, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
 #pragma unroll
       for (int k = 0; k < 6; ++k)
 #pragma unroll
@@ -131,7 +131,7 @@ struct GroupBackend {
     costs[3] = ck;
     f = costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3];
     double gq[D], gtau;
-    const int bst = grp::minco_backward<W, D>(t, prm, gC, gT, gq, gtau);
+    const int bst = minco_backward<D, GroupLanes<W>>(t, prm, gC, gT, gq, gtau);
     __syncthreads();
     if (lane >= 1 && lane < M) {
 #pragma unroll
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kWave, NEO_GRP_OCC) void optimize_group_kernel(int 
   const MapT map = maps[0];
   BE be(prm, map);
   be.t = Traj<D>{};
-  const int gl = grp::glane<W>();
+  const int gl = GroupLanes<W>::lane();
   const int g = lane_id() / W;
   const int nq = D * (M - 1), n = nq + M;
   be.xs = xs[g];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kWave, NEO_GRP_OCC) void optimize_group_kernel(int 
   be.t.M = M;
   be.t.nq = nq;
   be.t.n = n;
-  be.t.L = grp::sample_lanes_per_piece<W>(M);
+  be.t.L = GroupLanes<W>::lanes_per_piece(M);
 
   LbfgsOpts o{prm.ftol, prm.gtol, prm.maxls, prm.maxiter, prm.maxfun, NEO_LBFGS_M};
   LbfgsMachine<BE> mach(be, o);
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kWave, NEO_GRP_OCC) void optimize_group_kernel(int 
   auto take = [&]() {
     int tk = 0;
     if (gl == 0) tk = atomicAdd(ticket, 1);
-    tk = __shfl(tk, grp::gbase<W>(), kWave);
+    tk = __shfl(tk, GroupLanes<W>::base(), kWave);
     busy = tk < B;
     b = busy ? (order ? order[tk] : tk) : 0;
     be.t.head = head + (size_t)b * 3 * D;

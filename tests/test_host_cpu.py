@@ -106,11 +106,14 @@ def test_flag_constants_match_the_header():
     assert [f for f, _ in _lib.NeoParams._fields_][-1] == "flags"
 
 
-def test_generated_group_header_is_in_sync():
-    """csrc/neo_group.hpp is generated from csrc/neo_device.hpp (tools/gen_group_header.py): the committed copy
-    must be what the generator produces from the committed source"""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("gen_group_header", os.path.join(REPO, "tools", "gen_group_header.py"))
-    gen = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(gen)
-    assert gen.generate() == open(gen.DST).read()
+def test_one_source_for_the_lane_group_kernel():
+    """the several-trajectories-per-wavefront kernel instantiates the same device functions as the default kernel
+    (csrc/neo_device.hpp templated on the lane-group policy): no generated or hand-kept second copy of the numerics"""
+    csrc = os.path.join(REPO, "neo-planner_amd", "csrc")
+    assert not os.path.exists(os.path.join(csrc, "neo_group.hpp"))
+    dev = open(os.path.join(csrc, "neo_device.hpp")).read()
+    grp = open(os.path.join(csrc, "neo_group_kernel.hpp")).read()
+    for fn in ("minco_forward", "minco_sample", "minco_backward"):
+        assert dev.count(f" {fn}(") == 1, fn                      # defined once ...
+        assert f"{fn}<" in grp and "GroupLanes<W>" in grp         # ... and instantiated for the groups
+    assert "struct WaveLanes" in dev and "struct GroupLanes" in dev

@@ -33,6 +33,8 @@ for path in sorted(glob.glob(os.path.join(REPO, "tests", "golden", "g3_trace_*.n
             ctx.check(ctx.lib.neo_optimize_trace(ctx.h, None, 0))
             runs.append((tr[0].cpu().numpy().copy(), pl.last_nfev))
     pl.plan_once = traced
+    if os.environ.get("NEO_G3_ONLY") and os.environ["NEO_G3_ONLY"] not in path:
+        continue
     if int(d["np_seed"]) >= 0:
         np.random.seed(int(d["np_seed"]))
     err = ""
@@ -59,11 +61,14 @@ for path in sorted(glob.glob(os.path.join(REPO, "tests", "golden", "g3_trace_*.n
             break
         rf = d[f"r{k}_eval_f"]
         row.setdefault("nfev", []).append((int(nf), int(d[f"r{k}_nfev"])))
+        tol = float(os.environ.get("NEO_G3_RTOL", "1e-9"))
         for j in range(min(nf, len(rf), cap)):
-            if abs(t[j, 0] - rf[j]) > 1e-9 * max(abs(rf[j]), 1e-300):
+            if abs(t[j, 0] - rf[j]) > tol * max(abs(rf[j]), 1e-300):
                 first = dict(run=k, evaluation=j, f_gpu=float(t[j, 0]), f_ref=float(rf[j]), step=float(t[j, 1]),
                              iteration=int(t[j, 3]), samples=int(t[j, 2]),
-                             prev_rel_df=float(abs(t[j - 1, 0] - rf[j - 1]) / abs(rf[j - 1])) if j else None)
+                             prev_rel_df=float(abs(t[j - 1, 0] - rf[j - 1]) / abs(rf[j - 1])) if j else None,
+                             tail=[(int(t[q, 3]), float(t[q, 1]), float(t[q, 0]), float(rf[q]) if q < len(rf) else None)
+                                   for q in range(max(j - 2, 0), min(nf, j + 10))])
                 break
         if first:
             break
