@@ -97,7 +97,7 @@ def parse(argv=None):
     ap.add_argument("--waypoints", type=int, default=20)
     ap.add_argument("--grid", type=int, default=300)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--layout", default="linear", choices=["linear", "brick4", "cell8"])
+    ap.add_argument("--layout", default="linear", choices=["linear", "yz4", "cell8"])
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall budget of the NumPy-port sample")
     ap.add_argument("--native-seconds", type=float, default=4.0, help="wall budget of each cpu_native run")
     ap.add_argument("--no-cpu", action="store_true")

@@ -74,7 +74,9 @@ enum { NEO_F64 = 0, NEO_F32 = 1, NEO_F16 = 2 };
 /* voxel order of a 3-D field in HBM */
 enum {
   NEO_LAYOUT_LINEAR = 0, /* [z][y][x] */
-  NEO_LAYOUT_BRICK4 = 1, /* 4x4x4 bricks (256 B for f32), bricks in [bz][by][bx] order */
+  NEO_LAYOUT_YZ4 = 1,    /* yz-quads: voxel (x,y,z) stores d(y,z), d(y+1,z), d(y,z+1), d(y+1,z+1) contiguously, records in
+                            [z][y][x] order: the 8 corners of a cell are 2 adjacent records (32 contiguous bytes), one
+                            cache line per lookup and x-adjacent cells share half their bytes (4x the memory) */
   NEO_LAYOUT_CELL8 = 2,  /* cell-packed: the 2x2x2 corners of every interpolation cell contiguous (8x the
                             memory; one aligned 32-byte read per lookup instead of four gathers) */
 };

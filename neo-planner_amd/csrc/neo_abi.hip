@@ -242,24 +242,35 @@ __global__ void pack2d_kernel(const double *__restrict__ dist, const double *__r
   if (i < n) rec[i] = make_double4(dist[i], gx[i], gy[i], 0.0);
 }
 
-// 3-D field: convert element type and (optionally) re-tile into 4x4x4 bricks
+// 3-D field: convert element type (linear layout)
 template <typename SrcT, typename DstT>
-__global__ void pack3d_kernel(const SrcT *__restrict__ src, int nx, int ny, int nz, int layout, int bx, int by,
-                              DstT *__restrict__ dst) {
+__global__ void pack3d_kernel(const SrcT *__restrict__ src, int nx, int ny, int nz, DstT *__restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)nx * ny * nz;
+  if (i >= total) return;
+  const float v = (float)src[i];
+  if constexpr (sizeof(DstT) == 2)
+    dst[i] = __float2half(v);
+  else
+    dst[i] = (DstT)v;
+}
+
+// yz-quad layout: dst[voxel][w] = src at (ix, iy + (w & 1), iz + (w >> 1)), clamped at the upper faces
+template <typename SrcT, typename DstT>
+__global__ void pack3d_yz4_kernel(const SrcT *__restrict__ src, int nx, int ny, int nz, DstT *__restrict__ dst) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)nx * ny * nz;
   if (i >= total) return;
   const int ix = (int)(i % nx), iy = (int)((i / nx) % ny), iz = (int)(i / ((size_t)nx * ny));
-  size_t o = i;
-  if (layout == 1) {
-    const size_t brick = ((size_t)(iz >> 2) * by + (iy >> 2)) * bx + (ix >> 2);
-    o = brick * 64 + ((iz & 3) << 4) + ((iy & 3) << 2) + (ix & 3);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int y = min(iy + (w & 1), ny - 1), z = min(iz + (w >> 1), nz - 1);
+    const float v = (float)src[((size_t)z * ny + y) * nx + ix];
+    if constexpr (sizeof(DstT) == 2)
+      dst[i * 4 + w] = __float2half(v);
+    else
+      dst[i * 4 + w] = (DstT)v;
   }
-  const float v = (float)src[i];
-  if constexpr (sizeof(DstT) == 2)
-    dst[o] = __float2half(v);
-  else
-    dst[o] = (DstT)v;
 }
 
 // cell-packed layout: dst[cell][dz][dy][dx] = src at (ix+dx, iy+dy, iz+dz), clamped at the upper faces
@@ -469,8 +480,8 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
   if ((fl & NEO_FLAG_LANE_GROUPS) && f32 && layout == 0 && !a.slots && a.M <= 16 && D * (a.M - 1) + a.M <= 32)
     return launch_opt_groups(c, elem, a);
   // two trajectories per SIMD for calls that queue for the SIMDs anyway (3-D fields, fp32 sampling, the
-  // linear and cell-packed layouts, n <= 128: beyond that the spills cost more than the sharing gains)
-  const bool two = f32 && layout != 1 && slots_for(a.M, D) <= NEO_W2_MAX_SLOTS &&
+  // n <= 128: beyond that the spills cost more than the sharing gains)
+  const bool two = f32 && slots_for(a.M, D) <= NEO_W2_MAX_SLOTS &&
                    ((a.B >= kTwoWavesFromBatch && !(fl & NEO_FLAG_ONE_WAVE_PER_SIMD)) || (fl & NEO_FLAG_TWO_WAVES_PER_SIMD));
   if (two) return launch_opt_3d_w2(c, elem, layout, a);
   return f32 ? launch_opt_3d_f32(c, elem, layout, a) : launch_opt_3d_f64(c, elem, layout, a);
@@ -732,7 +743,7 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
   if (src_dtype != NEO_F64 && src_dtype != NEO_F32) return fail(c, NEO_ERR_INVALID, "src_dtype must be f64 or f32");
   if (store_dtype != NEO_F32 && store_dtype != NEO_F16)
     return fail(c, NEO_ERR_INVALID, "store_dtype must be f32 or f16");
-  if (layout != NEO_LAYOUT_LINEAR && layout != NEO_LAYOUT_BRICK4 && layout != NEO_LAYOUT_CELL8)
+  if (layout != NEO_LAYOUT_LINEAR && layout != NEO_LAYOUT_YZ4 && layout != NEO_LAYOUT_CELL8)
     return fail(c, NEO_ERR_INVALID, "bad layout");
   // the lookups form voxel indices with 24-bit multiplies: (iz * ny + iy) * nx + ix
   if ((size_t)ny * nz >= ((size_t)1 << 24) || (size_t)nx >= ((size_t)1 << 24))
@@ -741,8 +752,7 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
   drop_locked(c, scene_id);
   const size_t nvox = (size_t)nx * ny * nz;
   const size_t ssz = src_dtype == NEO_F64 ? 8 : 4, dsz = store_dtype == NEO_F32 ? 4 : 2;
-  const int bx = (nx + 3) / 4, by = (ny + 3) / 4, bz = (nz + 3) / 4;
-  const size_t nstore = layout == NEO_LAYOUT_BRICK4 ? (size_t)bx * by * bz * 64 : (layout == NEO_LAYOUT_CELL8 ? nvox * 8 : nvox);
+  const size_t nstore = layout == NEO_LAYOUT_YZ4 ? nvox * 4 : (layout == NEO_LAYOUT_CELL8 ? nvox * 8 : nvox);
   if ((nstore + 64) * dsz >= (size_t)4 << 30) return fail(c, NEO_ERR_INVALID, "field too large for 32-bit buffer offsets in this layout");
   const void *src = dist;
   DevBuf staged, field;
@@ -758,32 +768,28 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
   HIPCHK(c, field.alloc((nstore + 64) * dsz));
   HIPCHK(c, hipMemsetAsync(field.p, 0, (nstore + 64) * dsz, c->stream));
   const dim3 grid((unsigned)((nvox + 255) / 256)), blk(256);
-  if (layout == NEO_LAYOUT_CELL8) {
-    if (src_dtype == NEO_F64 && store_dtype == NEO_F32)
-      hipLaunchKernelGGL((pack3d_cell8_kernel<double, float>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz, (float *)field.p);
-    else if (src_dtype == NEO_F64)
-      hipLaunchKernelGGL((pack3d_cell8_kernel<double, __half>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz, (__half *)field.p);
-    else if (store_dtype == NEO_F32)
-      hipLaunchKernelGGL((pack3d_cell8_kernel<float, float>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz, (float *)field.p);
-    else
-      hipLaunchKernelGGL((pack3d_cell8_kernel<float, __half>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz, (__half *)field.p);
-  } else if (src_dtype == NEO_F64 && store_dtype == NEO_F32)
-    hipLaunchKernelGGL((pack3d_kernel<double, float>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz,
-                       layout, bx, by, (float *)field.p);
-  else if (src_dtype == NEO_F64)
-    hipLaunchKernelGGL((pack3d_kernel<double, __half>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz,
-                       layout, bx, by, (__half *)field.p);
-  else if (store_dtype == NEO_F32)
-    hipLaunchKernelGGL((pack3d_kernel<float, float>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz,
-                       layout, bx, by, (float *)field.p);
+#define NEO_PACK(KERNEL)                                                                                               \
+  do {                                                                                                             \
+    if (src_dtype == NEO_F64 && store_dtype == NEO_F32)                                                            \
+      hipLaunchKernelGGL((KERNEL<double, float>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz, (float *)field.p);   \
+    else if (src_dtype == NEO_F64)                                                                                 \
+      hipLaunchKernelGGL((KERNEL<double, __half>), grid, blk, 0, c->stream, (const double *)src, nx, ny, nz, (__half *)field.p); \
+    else if (store_dtype == NEO_F32)                                                                               \
+      hipLaunchKernelGGL((KERNEL<float, float>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz, (float *)field.p);     \
+    else                                                                                                           \
+      hipLaunchKernelGGL((KERNEL<float, __half>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz, (__half *)field.p);   \
+  } while (0)
+  if (layout == NEO_LAYOUT_CELL8)
+    NEO_PACK(pack3d_cell8_kernel);
+  else if (layout == NEO_LAYOUT_YZ4)
+    NEO_PACK(pack3d_yz4_kernel);
   else
-    hipLaunchKernelGGL((pack3d_kernel<float, __half>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz,
-                       layout, bx, by, (__half *)field.p);
+    NEO_PACK(pack3d_kernel);
+#undef NEO_PACK
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   e.data = field.release();
-  e.m3 = Map3D{e.data, nx, ny, nz, layout, bx, by, res, origin[0], origin[1], origin[2],
-               (unsigned int)((nstore + 64) * dsz)};
+  e.m3 = Map3D{e.data, nx, ny, nz, layout, res, origin[0], origin[1], origin[2], (unsigned int)((nstore + 64) * dsz)};
   c->maps[scene_id] = e;
   c->table_dirty = true;
   return NEO_OK;

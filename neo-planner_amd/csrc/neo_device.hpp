@@ -50,8 +50,8 @@ struct Map2D {
 struct Map3D {
   const void *data;
   int nx, ny, nz;
-  int layout;  // 0 linear [z][y][x], 1 = 4x4x4 bricks, 2 = cell-packed (8 corners of every cell contiguous)
-  int bx, by;  // bricks per axis (layout 1)
+  int layout;  // 0 linear [z][y][x], 1 = yz-quads (the 2x2 (y,z) neighbourhood of every voxel contiguous, x-major),
+               // 2 = cell-packed (8 corners of every cell contiguous)
   double res, ox, oy, oz;
   unsigned int bytes;  // size of the stored field (buffer-descriptor range)
 };
@@ -239,7 +239,7 @@ __device__ __forceinline__ void load_pair<__half>(const __half *p, float &a, flo
 }
 
 // trilinear distance + analytic gradient (oracle/minco_np.py:Grid3DESDF defines the semantics)
-// LAYOUT is a template parameter (0 linear, 1 bricks, 2 cell-packed, 9 = read Map3D::layout at run time,
+// LAYOUT is a template parameter (0 linear, 1 yz-quads, 2 cell-packed, 9 = read Map3D::layout at run time,
 // for the point-query kernel only): a run-time branch on the layout inside the sample
 // loop makes the compiler join the two load paths and wait for each sample's loads right there,
 // which defeats keeping several samples' gathers in flight.
@@ -267,12 +267,6 @@ struct Lookup3D {
   struct Raw {
     float c[2][2][2];
   };
-
-  __device__ __forceinline__ size_t addr(int ix, int iy, int iz) const {
-    if (LAYOUT == 0 || (LAYOUT == 9 && m.layout == 0)) return ((size_t)iz * m.ny + iy) * m.nx + ix;
-    const size_t brick = ((size_t)(iz >> 2) * m.by + (iy >> 2)) * m.bx + (ix >> 2);
-    return brick * 64 + ((iz & 3) << 4) + ((iy & 3) << 2) + (ix & 3);
-  }
 
   // `on` = false (an idle sample slot): treated like a point outside the field -- corner (0,0,0) for every
   // idle lane, i.e. one cache line per wavefront instead of 64 scattered gathers
@@ -348,13 +342,30 @@ struct Lookup3D {
             load_pair<E>(vox + base + so, q.c[dz][dy][0], q.c[dz][dy][1]);
         }
     } else {
+      // yz-quads: voxel (ix, iy, iz) stores {d(iy,iz), d(iy+1,iz), d(iy,iz+1), d(iy+1,iz+1)} at x = ix, records in
+      // [z][y][x] order: the 8 corners of a cell are the records ix and ix + 1 = 32 contiguous bytes (fp32; 16 for fp16),
+      // and x-adjacent cells share half of them -- 4x the memory of the linear layout instead of 8x, one line per
+      // lookup instead of four, and a sample triple walking along x stays on its 128-byte line for 8 cells
+      const unsigned int cell = __umul24(__umul24((unsigned)a.i0[2], (unsigned)m.ny) + (unsigned)a.i0[1], (unsigned)m.nx) +
+                                (unsigned)a.i0[0];
+      if constexpr (sizeof(E) == 4) {
+        const auto lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cell * 16u), 0, 0);
+        const auto hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cell * 16u + 16u), 0, 0);
+        q.c[0][0][0] = __uint_as_float(lo[0]); q.c[0][1][0] = __uint_as_float(lo[1]);
+        q.c[1][0][0] = __uint_as_float(lo[2]); q.c[1][1][0] = __uint_as_float(lo[3]);
+        q.c[0][0][1] = __uint_as_float(hi[0]); q.c[0][1][1] = __uint_as_float(hi[1]);
+        q.c[1][0][1] = __uint_as_float(hi[2]); q.c[1][1][1] = __uint_as_float(hi[3]);
+      } else {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cell * 8u), 0, 0);
 #pragma unroll
-      for (int dz = 0; dz < 2; ++dz)
+        for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx)
-            q.c[dz][dy][dx] = elem_to_float<E>(vox[addr(a.i0[0] + dx, a.i0[1] + dy, a.i0[2] + dz)]);
+          for (int dz = 0; dz < 2; ++dz) {
+            const unsigned int u = v[2 * dx + dz];
+            q.c[dz][0][dx] = __half2float(__ushort_as_half((unsigned short)(u & 0xffffu)));
+            q.c[dz][1][dx] = __half2float(__ushort_as_half((unsigned short)(u >> 16)));
+          }
+      }
     }
     return q;
   }

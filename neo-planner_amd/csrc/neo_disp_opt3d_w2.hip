@@ -11,7 +11,8 @@ int launch_opt_3d_w2(neo_ctx *c, int elem, int layout, const OptArgs &a) {
   if (elem == NEO_F32) return launch_opt<3, float, Map3D, Lookup3D<float, float, LAY>, 2>(c, a);    \
   return launch_opt<3, float, Map3D, Lookup3D<float, __half, LAY>, 2>(c, a);
   if (layout == 0) { NEO_3D2(0) }
-  NEO_3D2(2)
+  if (layout == 2) { NEO_3D2(2) }
+  NEO_3D2(1)
 #undef NEO_3D2
 #endif
 }

@@ -10,7 +10,8 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(PKG), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(PKG)), "include")
-LIB = os.path.join(PKG, "libneo_planner_hip.so")
+# NEO_BUILD_OUT: where an experiment build (NEO_BUILD_DEFS) is written; the product is always the in-tree path
+LIB = os.environ.get("NEO_BUILD_OUT") or os.path.join(PKG, "libneo_planner_hip.so")
 OBJDIR = os.path.join(CSRC, "build")
 SOURCES = ["neo_abi.hip", "neo_disp_eval.hip", "neo_disp_sample.hip", "neo_disp_opt2d.hip", "neo_disp_opt3d_f32.hip",
            "neo_disp_opt3d_f64.hip", "neo_disp_opt3d_w2.hip", "neo_disp_group.hip"]

@@ -6,7 +6,8 @@ tests/test_oracle_golden.py) and the committed reference fixtures are the checke
 Tolerances
   fp64 sampling mode: per-evaluation cost / gradient / coefficients 1e-10 relative (round-off of
       two different but exact solution methods, cond <= 4e5); optimiser results 1e-4 relative
-      (BASELINE.json), in practice 1e-12 when the run is not decided by round-off.
+      (BASELINE.json) on every recorded reference run bar the two named in KNOWN_PARTED, in practice 1e-12
+      whenever the run is not decided by round-off.
   fp32 sampling mode: per-evaluation 2e-5 relative; optimiser: final cost statistics only.
   ESDF construction and lookups: bit-exact.
 """
@@ -80,7 +81,7 @@ def test_esdf_build_3d_is_the_exact_edt(shape, seed):
     occ = (rng.random(shape) < 0.01).astype(np.uint8)
     occ[0] = 1                                            # ground slab, as every synthetic scene has
     want = (ndimage.distance_transform_edt(1 - occ) * 0.1).astype(np.float32)
-    for layout in ("linear", "brick4", "cell8"):
+    for layout in ("linear", "yz4", "cell8"):
         g3 = npa.ESDF3D.from_occupancy(occ, 0.1, (0.0, -1.0, 0.0), layout=layout, want_dist=True)
         assert np.array_equal(g3.dist, want)
         pts = rng.uniform([0, -1, 0], [shape[2] * 0.1, -1 + shape[1] * 0.1, shape[0] * 0.1], (500, 3))
@@ -106,7 +107,7 @@ def test_trilinear_lookup_matches_oracle_and_ties_back_to_2d():
     rng = np.random.default_rng(1)
     h, w = d["esdf_map"].shape
     pts = rng.uniform([origin[0] - 0.2, origin[1] - 0.2, -0.1], [origin[0] + w * res + 0.2, origin[1] + h * res + 0.2, 0.7], (3000, 3))
-    for layout in ("linear", "brick4", "cell8"):
+    for layout in ("linear", "yz4", "cell8"):
         for store, tol in (("f32", 1e-12), ("f16", 2e-3)):
             g3 = npa.ESDF3D(vol, res, origin, store=store, layout=layout)
             dis, grd = g3.query(pts)
@@ -190,7 +191,7 @@ def test_cost_grad_trilinear_matches_oracle():
     dist = (ndimage.distance_transform_edt(1 - occ) * res).astype(np.float32)
     origin = (-1.0, -6.0, 0.0)
     o3 = onp.Grid3DESDF(dist, res, origin)
-    for layout in ("linear", "brick4", "cell8"):
+    for layout in ("linear", "yz4", "cell8"):
         g3 = npa.ESDF3D(dist, res, origin, store="f32", layout=layout)
         for M, B in ((3, 4), (21, 4), (41, 2)):
             head, tail, wp, ts = _random_requests(rng, B, M, 3, (np.array([0.0, -5.0, 1.0]), np.array([10.5, 5.0, 8.0])))
@@ -281,11 +282,26 @@ def _run_entry(pl, d, m):
     return err
 
 
+# Reference runs the device does not follow to the last evaluation (profiles/r02_g3_report.json, tools/g3_divergence_report.py
+# on the MI355X).  Both are the SAME replan request recorded twice (seeds 4 and 5 draw the same map): same exceptions, same
+# number of L-BFGS-B runs and iterations (10), every evaluation the two runs have in common agrees in f to 1e-12 relative,
+# but the LAST line search (iteration 10, f flat to 13 digits between trial steps) ends on a different trial point:
+# SciPy takes 37 / 39 evaluations, the device 40 / 35 -- dcsrch's sufficient-decrease test `f <= finit + stp * gtest`
+# decided by the last bits of f.  Final control points 1.3e-4 apart (durations 3.1e-4), final cost 9e-7: a hair outside
+# north_star's 1e-4 on x, inside it on cost.  The CPU control (bench.py `parity.control`) shows any two implementations
+# that differ in the last bit part on 37 % of cfg2 runs; on the 18 recorded reference scenarios it is these 2.
+KNOWN_PARTED = {
+    "g3_trace_replan_s4.npz": dict(x_rel_max=2e-4, cost_rel_max=1e-5, nfev=(40, 37)),
+    "g3_trace_replan_s5.npz": dict(x_rel_max=2e-4, cost_rel_max=1e-5, nfev=(35, 39)),
+}
+
+
 def test_planner_reproduces_reference_runs_g3_g5():
-    """plan / warm_start_plan retries / batch_plan / plan_once through the reference-shaped class:
-    same exceptions, same number of L-BFGS-B runs and iterations, final control points, durations,
-    cost and sampled trajectory.  Runs whose tail is steered by round-off (see
-    tests/test_lbfgs_host.py) may stop a step apart: bar 1e-3 on x, 1e-4 on cost for those."""
+    """plan / warm_start_plan retries / batch_plan / plan_once through the reference-shaped class: same exceptions,
+    same number of L-BFGS-B runs and iterations, and final control points within north_star's 1e-4 of the reference's
+    for EVERY recorded run (in fact 1e-9: they follow SciPy evaluation by evaluation) -- except the runs named in
+    KNOWN_PARTED, which are bounded there."""
+    import os
     n = n_exact = 0
     for path in golden("g3_trace_*.npz"):
         d = load(path)
@@ -293,16 +309,22 @@ def test_planner_reproduces_reference_runs_g3_g5():
         pl = npa.MinJerkPlanner(npa.PlannerConfig())
         err = _run_entry(pl, d, m)
         assert err.split(":")[0] == str(d["error"]).split(":")[0], path
+        assert pl.iter_num == int(d["iter_num"]) and pl.opt_running_times == int(d["opt_running_times"]), path
         last = int(d["n_runs"]) - 1
-        exact = (pl.iter_num == int(d["iter_num"]) and pl.opt_running_times == int(d["opt_running_times"])
-                 and (last < 0 or pl.last_nfev == int(d[f"r{last}_nfev"])))
+        exact = last < 0 or pl.last_nfev == int(d[f"r{last}_nfev"])
         n += 1
         n_exact += exact
-        tol = 1e-9 if exact else 1e-3
+        known = KNOWN_PARTED.get(os.path.basename(path))
+        if known is None:
+            assert exact, (path, pl.last_nfev)
+            tol, ctol = 1e-9, 1e-9
+        else:
+            assert not exact, f"{path} follows the reference now: take it out of KNOWN_PARTED"
+            tol, ctol = known["x_rel_max"], known["cost_rel_max"]
         assert rel_err(pl.int_wpts, d["final_int_wpts"]) < tol, path
-        assert rel_err(pl.ts, d["final_ts"]) < tol, path
+        assert rel_err(pl.ts, d["final_ts"]) < 3 * tol, path
         if "final_cost" in d.files:
-            assert abs(pl.final_cost - d["final_cost"]) <= (1e-9 if exact else 1e-4) * abs(d["final_cost"]), path
+            assert abs(pl.final_cost - d["final_cost"]) <= ctol * abs(d["final_cost"]), path
             if "weighted_cost" in d.files and exact and str(d["entry"]) != "batch":
                 assert rel_err(pl.weighted_cost, d["weighted_cost"]) < 1e-9
         if "state_cmd_60" in d.files:
@@ -312,7 +334,7 @@ def test_planner_reproduces_reference_runs_g3_g5():
             assert rel_err(st, d["state_cmd_60"]) < max(tol, 1e-9) * 10
             assert rel_err(pl.get_pos_array(), d["pos_array"]) < max(tol, 1e-9) * 10
             assert rel_err(pl.get_vel_array(), d["vel_array"]) < max(tol, 1e-9) * 10
-    assert n >= 18 and n_exact >= n - 3, (n_exact, n)
+    assert n >= 18 and n_exact == n - len(KNOWN_PARTED), (n_exact, n)
 
 
 def _oracle_plan_once(o_map, head, tail, wp, ts):
