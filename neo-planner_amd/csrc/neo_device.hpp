@@ -856,113 +856,131 @@ __device__ __forceinline__ void minco_sample(int M, int L, int ns_in, const Real
   const Real dt = (Real)prm.delta_t, vmax2 = (Real)(prm.v_max * prm.v_max), safe = (Real)prm.safe_dis;
   const Real w2 = (Real)prm.w[2], w3 = (Real)prm.w[3];
   const Real inv_ns = ns > 0 ? Real(1) / (Real)ns : Real(0);
+  // Two passes over chunks of 64 rounds.  Violations are rare, so the first pass only DETECTS them: U samples per
+  // lane are prepared together, their gathers issued back to back, and all it keeps per sample is one bit -- no
+  // accumulator is live in this loop, which is what lets it hold U lookups in flight per lane in few registers.  The
+  // second pass revisits the flagged samples in ascending order (per lane: the order and the arithmetic of a
+  // single pass, so the sums are the same bits) and accumulates costs and partials; its loop runs as many times as
+  // the busiest lane has violations.
+  auto sample_time = [&](int j) -> Real { return (Real)((double)j * prm.delta_t); };  // beta_full row j: t = j * delta_t (:251)
+  auto detect = [&](int chunk0) -> unsigned long long {
+    const int chunk_end = min(iters, chunk0 + 64);
+    unsigned long long viol = 0ull;
+    for (int it0 = chunk0; it0 < chunk_end; it0 += U) {
+      Real sv[U], vel[U][D];
+      typename LookupT::Addr ad[U];
+      typename LookupT::Raw rw[U];
+      bool on[U];
+      // stand-alone kernel: lanes whose piece has run out of samples sit the round out (exec-masked)
+      if constexpr (SAMPLE_IO)
+        if (r + it0 * L >= ns) continue;
+      // only the position is needed to issue the gathers; the velocity is evaluated while they fly
+      constexpr bool kVelLate = SAMPLE_IO && sizeof(Real) == 4;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = r + (it0 + u) * L;
+        on[u] = j < ns && it0 + u < chunk_end;
+        const Real s = sample_time(j);
+        sv[u] = s;
+        Real pos[D];
+        if constexpr (kVelLate) {
+#pragma unroll
+          for (int d = 0; d < D; ++d)
+            pos[d] = fmaf(fmaf(fmaf(fmaf(fmaf(c[5][d], s, c[4][d]), s, c[3][d]), s, c[2][d]), s, c[1][d]), s, c[0][d]);
+        } else {
+          piece_pos_vel<Real, D>(c, s, pos, vel[u]);
+        }
+        ad[u] = lk.template prepare<D>(pos, on[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) rw[u] = lk.load(ad[u]);
+      if constexpr (kVelLate) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          Real pos[D];
+          piece_pos_vel<Real, D>(c, sv[u], pos, vel[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        Real v2 = Real(0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) v2 += vel[u][d] * vel[u][d];
+        Real gdrop[D];
+        const Real vd = safe - lk.template finish<D>(ad[u], rw[u], gdrop);
+        if (on[u] && (v2 - vmax2 > Real(0) || vd > Real(0))) viol |= 1ull << (it0 + u - chunk0);
+      }
+    }
+    return viol;
+  };
+  // (the accumulators are defined AFTER the first detect pass, so that they hold no registers during it)
+  unsigned long long viol0 = detect(0);
   Real aC[6][D];
 #pragma unroll
   for (int k = 0; k < 6; ++k)
 #pragma unroll
     for (int d = 0; d < D; ++d) aC[k][d] = Real(0);
   Real aT = Real(0), aF = Real(0), aK = Real(0);
-
-  // U samples per lane are prepared together and their gathers issued back to back before any of
-  // them is consumed
-  for (int it0 = 0; it0 < iters; it0 += U) {
-    Real sv[U], vel[U][D];
-    typename LookupT::Addr ad[U];
-    typename LookupT::Raw rw[U];
-    bool on[U];
-    // stand-alone kernel: lanes whose piece has run out of samples sit the round out (exec-masked)
-    if constexpr (SAMPLE_IO)
-      if (r + it0 * L >= ns) continue;
-    // only the position is needed to issue the gathers; the velocity is evaluated while they fly
-    constexpr bool kVelLate = SAMPLE_IO && sizeof(Real) == 4;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int j = r + (it0 + u) * L;
-      on[u] = j < ns;
-      const Real s = (Real)((double)j * prm.delta_t);  // beta_full row j: t = j * delta_t (:251)
-      sv[u] = s;
-      Real pos[D];
-      if constexpr (kVelLate) {
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-          pos[d] = fmaf(fmaf(fmaf(fmaf(fmaf(c[5][d], s, c[4][d]), s, c[3][d]), s, c[2][d]), s, c[1][d]), s, c[0][d]);
-      } else {
-        piece_pos_vel<Real, D>(c, s, pos, vel[u]);
-      }
-      ad[u] = lk.template prepare<D>(pos, on[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) rw[u] = lk.load(ad[u]);
-    if constexpr (kVelLate) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        Real pos[D];
-        piece_pos_vel<Real, D>(c, sv[u], pos, vel[u]);
-      }
-    }
-    // violations are rare: first only the two penalties' arguments for the U samples, one test for the
-    // whole group, and the per-sample accumulation code only if some lane of the wave needs it
-    Real vv[U], vd[U];
-    bool any_violation = false;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
+  // second pass: the flagged samples of a chunk
+  auto accumulate = [&](int chunk0, unsigned long long viol) {
+    while (__any(viol != 0ull)) {
+      const bool has = viol != 0ull;
+      const int k = has ? __builtin_ctzll(viol) : 0;
+      viol &= viol - 1ull;
+      const int j = r + (chunk0 + k) * L;
+      const Real s = sample_time(j);
+      Real pos[D], vel[D], g[D];
+      piece_pos_vel<Real, D>(c, s, pos, vel);
+      const typename LookupT::Addr ad = lk.template prepare<D>(pos, has);
+      const typename LookupT::Raw rw = lk.load(ad);
+      const Real dist = lk.template finish<D>(ad, rw, g);
+      if (!has) continue;
       Real v2 = Real(0);
 #pragma unroll
-      for (int d = 0; d < D; ++d) v2 += vel[u][d] * vel[u][d];
-      vv[u] = v2 - vmax2;
-      Real gdrop[D];
-      vd[u] = safe - lk.template finish<D>(ad[u], rw[u], gdrop);
-      if (on[u] && (vv[u] > Real(0) || vd[u] > Real(0))) any_violation = true;
-    }
-    if (any_violation) {
+      for (int d = 0; d < D; ++d) v2 += vel[d] * vel[d];
+      const Real vv = v2 - vmax2, vd = safe - dist;
+      const Real omg = (j == 0 || j == ns - 1) ? Real(0.5) : Real(1);
+      const Real s2 = s * s, s3 = s2 * s, s4 = s2 * s2, s5 = s4 * s;
+      // dynamic feasibility
+      if (vv > Real(0)) {
+        const Real vq = vv;
+        aF += omg * dt * vq * vq * vq;
+        Real av = Real(0);
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (!on[u]) continue;
-        const int j = r + (it0 + u) * L;
-        const Real s = sv[u];
-        const Real omg = (j == 0 || j == ns - 1) ? Real(0.5) : Real(1);
-        const Real s2 = s * s, s3 = s2 * s, s4 = s2 * s2, s5 = s4 * s;
-        // dynamic feasibility
-        if (vv[u] > Real(0)) {
-          const Real vq = vv[u];
-          aF += omg * dt * vq * vq * vq;
-          Real av = Real(0);
-#pragma unroll
-          for (int d = 0; d < D; ++d) {
-            const Real acc = Real(2) * c[2][d] + s * (Real(6) * c[3][d] + s * (Real(12) * c[4][d] + s * (Real(20) * c[5][d])));
-            av += acc * vel[u][d];
-          }
-          const Real dK = Real(3) * dt * omg * vq * vq;
-          const Real b1[6] = {Real(0), Real(1), Real(2) * s, Real(3) * s2, Real(4) * s3, Real(5) * s4};
-#pragma unroll
-          for (int d = 0; d < D; ++d) {
-            const Real uu = w2 * dK * Real(2) * vel[u][d];
-#pragma unroll
-            for (int k = 1; k < 6; ++k) aC[k][d] += b1[k] * uu;
-          }
-          aT += w2 * (omg * vq * vq * vq * inv_ns + dK * Real(2) * av * (Real)j * inv_ns);
+        for (int d = 0; d < D; ++d) {
+          const Real acc = Real(2) * c[2][d] + s * (Real(6) * c[3][d] + s * (Real(12) * c[4][d] + s * (Real(20) * c[5][d])));
+          av += acc * vel[d];
         }
-        // collision
-        if (vd[u] > Real(0)) {
-          Real g[D];
-          (void)lk.template finish<D>(ad[u], rw[u], g);
-          const Real vq = vd[u];
-          aK += omg * dt * vq * vq * vq;
-          const Real dK = Real(3) * dt * omg * vq * vq;
-          const Real b0[6] = {Real(1), s, s2, s3, s4, s5};
-          Real gv = Real(0);
+        const Real dK = Real(3) * dt * omg * vq * vq;
+        const Real b1[6] = {Real(0), Real(1), Real(2) * s, Real(3) * s2, Real(4) * s3, Real(5) * s4};
 #pragma unroll
-          for (int d = 0; d < D; ++d) {
-            gv += g[d] * vel[u][d];
-            const Real uu = -(w3 * dK * g[d]);
+        for (int d = 0; d < D; ++d) {
+          const Real uu = w2 * dK * Real(2) * vel[d];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) aC[k][d] += b0[k] * uu;
-          }
-          aT += w3 * (omg * vq * vq * vq * inv_ns + dK * (-gv) * (Real)j * inv_ns);
+          for (int kk = 1; kk < 6; ++kk) aC[kk][d] += b1[kk] * uu;
         }
+        aT += w2 * (omg * vq * vq * vq * inv_ns + dK * Real(2) * av * (Real)j * inv_ns);
+      }
+      // collision
+      if (vd > Real(0)) {
+        const Real vq = vd;
+        aK += omg * dt * vq * vq * vq;
+        const Real dK = Real(3) * dt * omg * vq * vq;
+        const Real b0[6] = {Real(1), s, s2, s3, s4, s5};
+        Real gv = Real(0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          gv += g[d] * vel[d];
+          const Real uu = -(w3 * dK * g[d]);
+#pragma unroll
+          for (int kk = 0; kk < 6; ++kk) aC[kk][d] += b0[kk] * uu;
+        }
+        aT += w3 * (omg * vq * vq * vq * inv_ns + dK * (-gv) * (Real)j * inv_ns);
       }
     }
-  }
+  };
+  accumulate(0, viol0);
+  for (int chunk0 = 64; chunk0 < iters; chunk0 += 64) accumulate(chunk0, detect(chunk0));  // (more than 64 rounds: rare)
   // fold the L lanes of each piece (fixed order); PIECE-layout callers get lane piece*L moved to lane piece
   auto fold = [&](Real v) -> Real {
     const Real f = fold_piece_lanes<Real>(v, L, r);

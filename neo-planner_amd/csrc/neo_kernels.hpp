@@ -381,8 +381,11 @@ __global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, De
 #ifndef NEO_SAMPLE_U
 #define NEO_SAMPLE_U 1
 #endif
+#ifndef NEO_SAMPLE_OCC
+#define NEO_SAMPLE_OCC 4  // waves per SIMD the fp32 instantiations are allocated for
+#endif
 template <int D, typename Real, class MapT, class LookupT>
-__global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? 4 : 2) void sample_kernel(int B, int M, DevParams prm, MapT map,
+__global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? NEO_SAMPLE_OCC : 2) void sample_kernel(int B, int M, DevParams prm, MapT map,
                                                                                   const double *__restrict__ coeffs,
                                                                                   const double *__restrict__ ts,
                                                                                   double *__restrict__ costs2,

@@ -5,13 +5,17 @@ that `NeoPlanner.enhanced_traj_plan` feeds to the optimiser.
 reference                                                        here
   nn_trainer/nn_trainer.py:109-155  PlannerNet                    PlannerNet (same sub-module names, so a
                                                                   reference `planner_net.pth` state_dict loads)
+  nn_trainer/nn_trainer_conv.py:107-159 PlannerNet (Conv1d heads) PlannerNetConv (same sub-module names)
   nn_trainer/nn_trainer.py:52-59    process_input_np              process_input_np
   traj_planner/record_planner.py:13-58 form_nn_input              form_nn_input (own quaternion helper)
   traj_planner/nn_planner.py:20-134 NNPlanner (onnxruntime)       NNPlanner (torch forward on the GPU)
   traj_planner/neo_planner.py:10-51 NeoPlanner                    NeoPlanner(MinJerkPlanner)
 
 The reference runs the exported ONNX graph through onnxruntime's CUDA provider; here the same network
-runs as a torch module on ROCm (convolutions: MIOpen; dense layers: hipBLASLt/rocBLAS on MFMA).  The
+runs as a torch module on ROCm.  The backbone's convolutions run as im2col + GEMM (`conv_impl="gemm"`: F.unfold, then
+one fp32 GEMM per layer on hipBLASLt/rocBLAS, i.e. on the matrix cores) because MIOpen picks its naive direct kernel
+for these fp32 NCHW shapes on gfx950 (profiles/r01_cfg3_*: 63 % of the warm start's GPU time); `conv_impl="miopen"`
+keeps nn.Conv2d.  Dense layers: hipBLASLt/rocBLAS on MFMA.  The
 trained weights are not part of the reference tree (.MISSING_LARGE_BLOBS): parity of the *numbers* is
 unpinned, parity of the *architecture and data flow* is tested against an fp64 NumPy forward of the
 same weights (tests/test_initializer.py).  torchvision is not available in this image: the ResNet-18
@@ -101,6 +105,28 @@ def form_nn_input(depth_img, drone_state, des_pos_z, plan_init_state, target_sta
 
 
 # --------------------------------------------------------------------------- network
+CONV_IMPL = "gemm"      # "gemm": im2col + one GEMM per convolution (matrix cores); "miopen": nn.Conv2d as is
+
+
+def _conv2d(conv, x):
+    """nn.Conv2d forward.  With CONV_IMPL == "gemm" on a GPU tensor: F.unfold (im2col) and a [Cout, Cin*kh*kw] x
+    [Cin*kh*kw, L] GEMM per image -- the same sums as the direct convolution in another order (fp32 round-off apart)."""
+    if CONV_IMPL != "gemm" or not x.is_cuda or conv.groups != 1:
+        return conv(x)
+    kh, kw = conv.kernel_size
+    N, _, H, W = x.shape
+    Ho = (H + 2 * conv.padding[0] - conv.dilation[0] * (kh - 1) - 1) // conv.stride[0] + 1
+    Wo = (W + 2 * conv.padding[1] - conv.dilation[1] * (kw - 1) - 1) // conv.stride[1] + 1
+    if kh == 1 and kw == 1 and conv.padding == (0, 0):
+        cols = x[:, :, ::conv.stride[0], ::conv.stride[1]].reshape(N, x.shape[1], -1)
+    else:
+        cols = torch.nn.functional.unfold(x, (kh, kw), dilation=conv.dilation, padding=conv.padding, stride=conv.stride)
+    y = torch.matmul(conv.weight.reshape(conv.out_channels, -1), cols)           # [N, Cout, L]
+    if conv.bias is not None:
+        y = y + conv.bias[None, :, None]
+    return y.reshape(N, conv.out_channels, Ho, Wo)
+
+
 class _BasicBlock(nn.Module):
     def __init__(self, cin, cout, stride):
         super().__init__()
@@ -114,9 +140,9 @@ class _BasicBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
+        idt = x if self.downsample is None else self.downsample[1](_conv2d(self.downsample[0], x))
+        y = self.relu(self.bn1(_conv2d(self.conv1, x)))
+        y = self.bn2(_conv2d(self.conv2, y))
         return self.relu(y + idt)
 
 
@@ -138,7 +164,7 @@ class ResNet18OneChannel(nn.Module):
         self.fc = nn.Linear(512, feature_size)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.relu(self.bn1(_conv2d(self.conv1, x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
@@ -177,6 +203,66 @@ class PlannerNet(nn.Module):
         hw = self.img_width * self.img_height
         img = input[:, :hw].reshape(-1, 1, self.img_height, self.img_width)
         return self.head(self.image_features(img), input[:, hw:])
+
+
+class PlannerNetConv(PlannerNet):
+    """nn_trainer_conv.py:107-159: the variant whose motion branch and fusion head are Conv1d stacks over the feature
+    vector treated as a 1-channel sequence (kernel 3, padding 1, 1 -> 16 -> 32 -> 64 channels, LeakyReLU), flattened
+    into one Linear each.  Same sub-module names and Sequential indices as the reference, so its state_dict loads.
+    Per trajectory: motion branch 24 * (3*16 + 48*32 + 96*64) + 1536*24 MAC, head 48 * (3*16 + 48*32 + 96*64) + 3072*9."""
+
+    def __init__(self, img_height=IMG_HEIGHT, img_width=IMG_WIDTH):
+        super().__init__(img_height, img_width)
+
+        def stack(length, out):
+            return nn.Sequential(
+                nn.Conv1d(1, 16, kernel_size=3, stride=1, padding=1), nn.LeakyReLU(),
+                nn.Conv1d(16, 32, kernel_size=3, stride=1, padding=1), nn.LeakyReLU(),
+                nn.Conv1d(32, 64, kernel_size=3, stride=1, padding=1), nn.LeakyReLU(),
+                nn.Flatten(), nn.Linear(64 * length, out))
+        self.motion_backbone = stack(MOTION_INPUT_SIZE, MOTION_FEATURE_SIZE)
+        self.mlp = stack(IMG_FEATURE_SIZE + MOTION_FEATURE_SIZE, OUTPUT_SIZE)
+
+    def head(self, img_feature, motion):
+        if img_feature.shape[0] != motion.shape[0]:
+            img_feature = img_feature.expand(motion.shape[0], -1)
+        mf = self.motion_backbone(motion.unsqueeze(1))                 # (:149-152) channel dimension added
+        return self.mlp(torch.cat([img_feature, mf], dim=1).unsqueeze(1))
+
+
+def raycast_depth(pillars, canopy=(), eye=(1.5, 0.0, 2.0), yaw=0.0, hfov_deg=87.0, max_range=20.0,
+                  height=IMG_HEIGHT, width=IMG_WIDTH):
+    """Synthetic depth image of a forest scene ("ray-cast of the pillars, 480 x 640"): a pinhole camera
+    at `eye` looking along +x rotated by `yaw`, horizontal field of view `hfov_deg` (a RealSense-like 87 deg), depth =
+    distance along the optical axis to the nearest box or the ground plane z = 0, capped at `max_range`; returned as
+    uint8 scaled by its maximum, exactly what form_nn_input hands to the network (record_planner.py:16-18).
+    pillars: (cx, cy, sx, sy, sz) standing on the ground; canopy: (cx, cy, cz, sx, sy, sz)."""
+    boxes = [((cx - sx / 2, cy - sy / 2, 0.0), (cx + sx / 2, cy + sy / 2, sz)) for (cx, cy, sx, sy, sz) in pillars]
+    boxes += [((cx - sx / 2, cy - sy / 2, cz - sz / 2), (cx + sx / 2, cy + sy / 2, cz + sz / 2))
+              for (cx, cy, cz, sx, sy, sz) in canopy]
+    f = (width / 2) / np.tan(np.radians(hfov_deg) / 2)
+    u = (np.arange(width) - (width - 1) / 2) / f
+    v = (np.arange(height) - (height - 1) / 2) / f
+    # camera frame: x forward, y left, z up
+    d = np.stack(np.broadcast_arrays(np.ones((height, width)), -u[None, :], -v[:, None]), axis=-1)
+    c, s_ = np.cos(yaw), np.sin(yaw)
+    R = np.array([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])
+    dirs = d @ R.T                                                      # world directions, forward component = 1
+    eye = np.asarray(eye, dtype=np.float64)
+    depth = np.full((height, width), max_range)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tg = np.where(dirs[..., 2] < 0, -eye[2] / dirs[..., 2], np.inf)          # ground plane
+        depth = np.minimum(depth, tg)
+        inv = 1.0 / dirs
+        for lo, hi in boxes:
+            t0 = (np.asarray(lo) - eye) * inv
+            t1 = (np.asarray(hi) - eye) * inv
+            tn = np.minimum(t0, t1).max(axis=-1)
+            tf = np.maximum(t0, t1).min(axis=-1)
+            hit = (tf >= np.maximum(tn, 0.0))
+            depth = np.where(hit, np.minimum(depth, np.maximum(tn, 0.0)), depth)
+    depth = np.clip(depth, 0.0, max_range)
+    return (depth / max(depth.max(), 1e-9) * 255).astype(np.uint8)
 
 
 def split_output(out, M=3, nn_output_D=3):
@@ -245,10 +331,13 @@ class BatchInitializer:
     """cfg3: warm starts for B trajectories that share one depth image.  The backbone runs once per
     scene; the dense layers run as [B, 48] x ... GEMMs."""
 
-    def __init__(self, net=None, device=None, T_min=0.5, T_max=5.0):
+    def __init__(self, net=None, device=None, T_min=0.5, T_max=5.0, variant="mlp"):
+        """variant: "mlp" (nn_trainer.py) or "conv" (nn_trainer_conv.py) when no `net` is given"""
         self.device = torch.device(device) if device is not None else torch.device(
             "cuda" if torch.cuda.is_available() else "cpu")
-        self.net = (net if net is not None else PlannerNet()).to(self.device).eval()
+        if net is None:
+            net = PlannerNet() if variant == "mlp" else PlannerNetConv()
+        self.net = net.to(self.device).eval()
         self.T_min, self.T_max = T_min, T_max
 
     @torch.no_grad()

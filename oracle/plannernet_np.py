@@ -85,3 +85,33 @@ def forward(inp, p, img_height, img_width):
     hw = img_height * img_width
     img = inp[:, :hw].reshape(-1, 1, img_height, img_width)
     return head(image_features(img, p), inp[:, hw:], p)
+
+
+# ---- the Conv1d variant (nn_trainer/nn_trainer_conv.py:107-159)
+def conv1d_k3p1(x, p, prefix):
+    """x [N, C, L], kernel 3, stride 1, padding 1, with bias"""
+    w, b = p[prefix + ".weight"], p[prefix + ".bias"]          # [O, C, 3], [O]
+    xp = np.pad(x, ((0, 0), (0, 0), (1, 1)))
+    L = x.shape[2]
+    win = np.stack([xp[:, :, k:k + L] for k in range(3)], axis=-1)     # [N, C, L, 3]
+    return np.einsum("nclk,ock->nol", win, w, optimize=True) + b[None, :, None]
+
+
+def _conv_stack(x, p, prefix):
+    """Sequential(Conv1d, LeakyReLU, Conv1d, LeakyReLU, Conv1d, LeakyReLU, Flatten, Linear): indices 0, 2, 4, 7"""
+    y = x[:, None, :]
+    for i in (0, 2, 4):
+        y = leaky(conv1d_k3p1(y, p, f"{prefix}.{i}"))
+    return linear(y.reshape(y.shape[0], -1), p, f"{prefix}.7")
+
+
+def head_conv(img_feature, motion, p):
+    m = _conv_stack(motion, p, "motion_backbone")
+    x = np.concatenate([np.broadcast_to(img_feature, (m.shape[0], img_feature.shape[1])), m], axis=1)
+    return _conv_stack(x, p, "mlp")
+
+
+def forward_conv(inp, p, img_height, img_width):
+    hw = img_height * img_width
+    img = inp[:, :hw].reshape(-1, 1, img_height, img_width)
+    return head_conv(image_features(img, p), inp[:, hw:], p)

@@ -350,3 +350,91 @@ def test_lane_groups_with_dispatch_order_and_batches_in_flight():
         assert np.array_equal(o["nfev"].cpu().numpy(), ref["nfev"])
         assert np.array_equal(o["costs"].cpu().numpy(), ref["costs"])
         assert np.array_equal(o["status"].cpu().numpy() & 0xff, ref["status"])
+
+
+def test_map_update_while_batches_are_in_flight():
+    """A map update on one thread/stream while `_dev` batches of the same scene are in flight on other streams
+    (the record buffer of a same-size update is rewritten in place): the update waits for the device, so
+    every batch launched BEFORE it sees the old map (results = the old map's, bit for bit) and a batch launched AFTER
+    it the new one; nothing reads a half-written map."""
+    import torch
+    occ_a, occ_b = synth.occupancy_2d(21), synth.occupancy_2d(22)
+    m = npa.ESDF()
+    m.occupancy_map_cb(synth.OccupancyGridMsg(occ_a))
+    ctx = m.ctx
+    B, M = 2048, 5
+    head, tail, wp, ts = synth.replan_requests(9, B, M - 1, D=2, length_range=(8.0, 16.0), jitter=0.3)
+    bp = npa.BatchPlanner(ctx=ctx)
+    ref_a = bp.optimize(m, bp.pack_x(wp, ts), head, tail, order=False)
+    dev = torch.device("cuda", 0)
+    x0 = torch.from_numpy(bp.pack_x(wp, ts)).to(dev)
+    h, tl = torch.from_numpy(head).to(dev), torch.from_numpy(tail).to(dev)
+
+    def issue(st):
+        ctx.set_stream(st.cuda_stream)
+        with torch.cuda.stream(st):
+            o = dict(x=x0.clone(), costs=torch.zeros(B, 4, dtype=torch.float64, device=dev),
+                     last=torch.zeros(B, 4, dtype=torch.float64, device=dev),
+                     nit=torch.zeros(B, dtype=torch.int32, device=dev), nfev=torch.zeros(B, dtype=torch.int32, device=dev),
+                     status=torch.zeros(B, dtype=torch.int32, device=dev))
+            bp.optimize_dev(m, o["x"], h, tl, o["costs"], o["last"], o["nit"], o["nfev"], o["status"])
+        return o
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    try:
+        before = [issue(st) for st in streams for _ in range(2)]        # six batches in flight on three streams
+        ctx.set_stream(None)
+        m.occupancy_map_cb(synth.OccupancyGridMsg(occ_b))               # same size: rewrites the record buffer in place
+        after = issue(streams[0])
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_stream(None)
+    for o in before:
+        assert np.array_equal(o["x"].cpu().numpy(), ref_a["x"])
+        assert np.array_equal(o["nfev"].cpu().numpy(), ref_a["nfev"])
+    ref_b = bp.optimize(m, bp.pack_x(wp, ts), head, tail, order=False)
+    assert np.array_equal(after["x"].cpu().numpy(), ref_b["x"])
+    assert not np.array_equal(ref_a["x"], ref_b["x"])
+
+
+def test_multi_scene_calls_reject_mixed_maps_and_bad_slots():
+    """per-trajectory scenes must all be of one kind / element type / layout (one kernel instantiation serves
+    the call); the host path checks the ids, the device path checks the context's maps and bounds the slots"""
+    import torch
+    ctx = _lib.Context(0)
+    occ3 = synth.occupancy_3d(0, n=48, res=30.0 / 48)
+    a = npa.ESDF3D.from_occupancy(occ3, 30.0 / 48, synth.DOMAIN_ORIGIN, store="f32", ctx=ctx)
+    b = npa.ESDF3D.from_occupancy(occ3, 30.0 / 48, synth.DOMAIN_ORIGIN, store="f32", ctx=ctx)
+    B, M = 64, 4
+    head, tail, wp, ts = synth.replan_requests(2, B, M - 1, D=3, length_range=(8.0, 14.0))
+    bp = npa.BatchPlanner(ctx=ctx, sample_dtype="f32")
+    ids = np.where(np.arange(B) % 2 == 0, a.scene_id, b.scene_id).astype(np.int32)
+    ok = bp.optimize(a, bp.pack_x(wp, ts), head, tail, scene_ids=ids)
+    one = bp.optimize(a, bp.pack_x(wp, ts), head, tail)
+    assert np.array_equal(ok["x"], one["x"])                       # both scenes hold the same field
+    # a third scene with another element type makes multi-scene calls ambiguous -> rejected, not mis-dispatched
+    c16 = npa.ESDF3D.from_occupancy(occ3, 30.0 / 48, synth.DOMAIN_ORIGIN, store="f16", ctx=ctx)
+    with pytest.raises(_lib.NeoError):
+        bp.optimize(a, bp.pack_x(wp, ts), head, tail, scene_ids=ids)
+    ctx.check(ctx.lib.neo_esdf_drop(ctx.h, c16.scene_id))
+    # mixing a 2-D map into the ids
+    m2 = npa.ESDF(ctx=ctx)
+    m2.occupancy_map_cb(synth.OccupancyGridMsg(synth.occupancy_2d(1)))
+    mixed = ids.copy(); mixed[3] = m2.scene_id
+    with pytest.raises(_lib.NeoError):
+        bp.optimize(a, bp.pack_x(wp, ts), head, tail, scene_ids=mixed)
+    # a slot outside the table: that trajectory is flagged NEO_TRAJ_BAD_SCENE and left untouched, the others run
+    dev = torch.device("cuda", 0)
+    bp._sync()
+    slots = torch.full((B,), ctx.lib.neo_scene_slot(ctx.h, a.scene_id), dtype=torch.int32, device=dev)
+    slots[5] = 77
+    x = torch.from_numpy(bp.pack_x(wp, ts)).to(dev)
+    x_in = x.clone()
+    costs = torch.zeros(B, 4, dtype=torch.float64, device=dev); last = torch.zeros_like(costs)
+    nit = torch.zeros(B, dtype=torch.int32, device=dev); nfev = torch.zeros_like(nit); st = torch.zeros_like(nit)
+    bp.optimize_dev(a, x, torch.from_numpy(head).to(dev), torch.from_numpy(tail).to(dev), costs, last, nit, nfev, st, slots=slots)
+    torch.cuda.synchronize()
+    st = st.cpu().numpy()
+    assert (st[5] & 0xff) == _lib.NEO_TRAJ_BAD_SCENE and torch.equal(x[5], x_in[5])
+    assert ((np.delete(st, 5) & 0xff) <= 3).all()
+    assert np.array_equal(np.delete(x.cpu().numpy(), 5, axis=0), np.delete(one["x"], 5, axis=0))

@@ -153,3 +153,63 @@ def test_initializer_on_gpu_feeds_the_optimiser():
     res = bp.optimize(m, bp.pack_x(wp, ts.cpu().numpy()), hd, tl)
     # (an untrained network hands over poor durations: some runs end where the reference raises OverflowError)
     assert (res["status"] <= 2).mean() > 0.75 and np.all(np.isfinite(res["final_cost"][res["status"] <= 2]))
+
+
+def test_conv1d_variant_matches_numpy_fp64_forward_and_reference_names():
+    """nn_trainer_conv.py:107-159: Conv1d motion branch and fusion head; same Sequential indices as the reference"""
+    h, w = 48, 64
+    torch.manual_seed(3)
+    net = ini.PlannerNetConv(img_height=h, img_width=w).eval().double()
+    sd = net.state_dict()
+    for k, shape in (("motion_backbone.0.weight", (16, 1, 3)), ("motion_backbone.2.weight", (32, 16, 3)),
+                     ("motion_backbone.4.weight", (64, 32, 3)), ("motion_backbone.7.weight", (24, 64 * 24)),
+                     ("mlp.0.weight", (16, 1, 3)), ("mlp.4.bias", (64,)), ("mlp.7.weight", (9, 64 * 48)),
+                     ("img_backbone.fc.weight", (24, 512))):
+        assert tuple(sd[k].shape) == shape, k
+    p = {k: v.numpy().astype(np.float64) for k, v in sd.items()}
+    rng = np.random.default_rng(1)
+    inp = np.concatenate([rng.integers(0, 256, (2, h * w)).astype(np.float64), rng.normal(0, 1, (2, 24))], axis=1)
+    with torch.no_grad():
+        out = net(torch.from_numpy(inp)).numpy()
+    ref = pnp.forward_conv(inp, p, h, w)
+    assert out.shape == (2, 9)
+    assert np.max(np.abs(out - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref)))
+    bi = ini.BatchInitializer(device="cpu", variant="conv")
+    assert isinstance(bi.net, ini.PlannerNetConv)
+
+
+def test_gemm_convolution_equals_direct_convolution():
+    """the backbone's im2col + GEMM path (matrix cores on the GPU) computes nn.Conv2d's sums"""
+    torch.manual_seed(0)
+    for cin, cout, k, s_, pad in ((1, 64, 7, 2, 3), (64, 128, 3, 2, 1), (128, 128, 3, 1, 1), (64, 128, 1, 2, 0)):
+        conv = torch.nn.Conv2d(cin, cout, k, s_, pad, bias=False).double()
+        x = torch.randn(2, cin, 30, 41, dtype=torch.float64)
+        ref = conv(x)
+        kh = conv.kernel_size[0]
+        cols = x[:, :, ::s_, ::s_].reshape(2, cin, -1) if (kh == 1 and pad == 0) else \
+            torch.nn.functional.unfold(x, conv.kernel_size, padding=conv.padding, stride=conv.stride)
+        y = torch.matmul(conv.weight.reshape(cout, -1), cols).reshape(ref.shape)
+        assert torch.allclose(y, ref, rtol=1e-12, atol=1e-12)
+    # and the module-level switch leaves CPU tensors on nn.Conv2d
+    assert ini.CONV_IMPL == "gemm"
+    c = torch.nn.Conv2d(1, 4, 3, 1, 1, bias=False)
+    xx = torch.randn(1, 1, 8, 8)
+    assert torch.equal(ini._conv2d(c, xx), c(xx))
+
+
+def test_raycast_depth_image_of_a_pillar():
+    """one 1 m pillar 5 m ahead: it covers the image centre at depth 4.5 m, the ground shows below the horizon, the sky
+    (no hit) saturates; scaling to uint8 by the maximum like record_planner.py:16-18"""
+    img = ini.raycast_depth([(5.0, 0.0, 1.0, 1.0, 6.0)], eye=(0.0, 0.0, 2.0), max_range=20.0)
+    assert img.shape == (ini.IMG_HEIGHT, ini.IMG_WIDTH) and img.dtype == np.uint8
+    centre = img[ini.IMG_HEIGHT // 2, ini.IMG_WIDTH // 2]
+    assert abs(int(centre) - round(4.5 / 20.0 * 255)) <= 1
+    assert img[5, 5] == 255                                   # sky, top-left corner
+    assert img[-1, ini.IMG_WIDTH // 2] < 60                   # ground just ahead (2 m below the camera)
+    left_edge = img[ini.IMG_HEIGHT // 2, 10]
+    assert left_edge == 255                                   # beside the pillar, at the horizon: nothing within range
+    # a floating box appears where it should
+    img2 = ini.raycast_depth([], [(4.0, 1.0, 3.0, 0.5, 0.5, 0.5)], eye=(0.0, 0.0, 2.0))
+    ys, xs = np.nonzero(img2[:ini.IMG_HEIGHT // 2] < 255)     # above the horizon only the box can be hit
+    assert len(ys) and xs.mean() < ini.IMG_WIDTH / 2          # the box sits up and to the left (y = +1 m)
+    assert abs(int(img2[ys[0], xs[0]]) - round(3.75 / 20.0 * 255)) <= 2
