@@ -115,6 +115,26 @@ __device__ __forceinline__ int wave_sum(int v) {
   v += dpp_i<0x143, 0xc>(v);
   return __builtin_amdgcn_readlane(v, 63);
 }
+// inclusive prefix sum / prefix maximum over the lanes of the wavefront (non-negative ints; the same DPP sequence as
+// wave_sum, which is that scan read at lane 63)
+__device__ __forceinline__ int wave_scan_add(int v) {
+  v += dpp_i<0x111>(v);
+  v += dpp_i<0x112>(v);
+  v += dpp_i<0x114>(v);
+  v += dpp_i<0x118>(v);
+  v += dpp_i<0x142, 0xa>(v);
+  v += dpp_i<0x143, 0xc>(v);
+  return v;
+}
+__device__ __forceinline__ int wave_scan_max_nonneg(int v) {
+  v = max(v, dpp_i<0x111>(v));
+  v = max(v, dpp_i<0x112>(v));
+  v = max(v, dpp_i<0x114>(v));
+  v = max(v, dpp_i<0x118>(v));
+  v = max(v, dpp_i<0x142, 0xa>(v));
+  v = max(v, dpp_i<0x143, 0xc>(v));
+  return v;
+}
 // maxima of NON-NEGATIVE values (the 0 fill of the DPP moves is then neutral)
 __device__ __forceinline__ double wave_max_nonneg(double v) {
   v = fmax(v, dpp_d<0x111>(v));
@@ -793,30 +813,129 @@ __device__ __forceinline__ Real dpp_real(Real v) {
 // L <= 4 (M >= 16): wave_shl:1 DPP moves, summed left to right ((v_0 + v_1) + v_2) + v_3.
 // L = 8, 16, 32, 64: halving tree with row_shl DPP moves (lane i <- lane i + s inside its row of 16), rows joined
 // through LDS shuffles.  Other L: a shuffle tree.  Fixed order in every case.
-template <typename Real>
-__device__ __forceinline__ Real fold_piece_lanes(Real v, int L, int r) {
+// All N values of a lane are folded together so that the case distinction on L (wave-uniform) is made ONCE: as 21
+// separate calls it cost 21 branch ladders per evaluation (and 1250 instructions of code in the stand-alone kernel).
+template <typename Real, int N>
+__device__ __forceinline__ void fold_piece_lanes(Real (&v)[N], int L, int r) {
   if (L <= 4) {
-    Real acc = v, t = v;
+    Real t[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) t[q] = v[q];
     for (int i = 1; i < L; ++i) {
-      t = dpp_real<Real, 0x130>(t);
-      acc += t;
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        t[q] = dpp_real<Real, 0x130>(t[q]);
+        v[q] += t[q];
+      }
     }
-    return acc;
+    return;
   }
   if ((L & (L - 1)) == 0) {
-    if (L >= 16) v += dpp_real<Real, 0x108>(v);  // row_shl:8
-    v += dpp_real<Real, 0x104>(v);               // row_shl:4
-    v += dpp_real<Real, 0x102>(v);
-    v += dpp_real<Real, 0x101>(v);
-    if (L >= 32) v += __shfl_down(v, 16, kWave);
-    if (L >= 64) v += __shfl_down(v, 32, kWave);
-    return v;
+    if (L >= 16) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) v[q] += dpp_real<Real, 0x108>(v[q]);  // row_shl:8
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      v[q] += dpp_real<Real, 0x104>(v[q]);  // row_shl:4
+      v[q] += dpp_real<Real, 0x102>(v[q]);
+      v[q] += dpp_real<Real, 0x101>(v[q]);
+    }
+    if (L >= 32) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) v[q] += __shfl_down(v[q], 16, kWave);
+    }
+    if (L >= 64) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) v[q] += __shfl_down(v[q], 32, kWave);
+    }
+    return;
   }
   for (int sft = 1; sft < L; sft <<= 1) {
-    const Real o = __shfl_down(v, sft, kWave);
-    if (r + sft < L) v += o;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const Real o = __shfl_down(v[q], sft, kWave);
+      if (r + sft < L) v[q] += o;
+    }
   }
-  return v;
+}
+
+// ---- SAMPLE layout: which lanes walk which piece's quadrature samples
+struct SampleLanes {
+  int piece;   // piece of this sample lane (valid when act)
+  int r;       // its residue: it walks samples j = r, r + L, r + 2L, ...
+  int L;       // lanes of its piece
+  bool act;
+  int rounds;  // wave-uniform: rounds of the sample loop
+  int lmax;    // wave-uniform: largest L (fold depth); 0 = every piece has the same L (fast DPP folds)
+  int first;   // PIECE layout (lane p < M): first sample lane of piece p
+};
+
+// the same L = sample_lanes_per_piece(M) lanes for every piece (lane groups; pieces with equal sample counts)
+template <class LG>
+__device__ __forceinline__ SampleLanes fixed_sample_lanes(int M, int L, int ns_of_my_piece_if_known = -1) {
+  (void)ns_of_my_piece_if_known;
+  const int lane = LG::lane();
+  SampleLanes sl;
+  sl.piece = (lane * ((65536 + L - 1) / L)) >> 16;  // lane / L for lane < 64
+  sl.r = lane - sl.piece * L;
+  sl.L = L;
+  sl.act = sl.piece < M;
+  sl.rounds = -1;  // from the sample counts, in minco_sample
+  sl.lmax = 0;
+  sl.first = lane * L;
+  return sl;
+}
+
+// Lanes in proportion to the pieces' sample counts (whole wavefront, one trajectory): the smallest number of rounds
+// R for which sum_p ceil(ns_p / R) lanes fit the wavefront, piece p then gets ceil(ns_p / R) adjacent lanes.  Durations
+// are optimisation variables, so the pieces of a trajectory under optimisation differ widely in length: with
+// the same three lanes for every piece the longest piece sets the rounds (cfg2: 8.6 on average against 4.9 for a
+// perfect split).  ns_piece: PIECE layout (lane p < M).  seg: 64 ints of LDS scratch.
+__device__ __forceinline__ SampleLanes balanced_sample_lanes(int M, int ns_piece, int *seg) {
+  const int lane = lane_id();
+  const int mine = lane < M ? ns_piece : 0;
+  const int total = wave_sum(mine);
+  int R = max(1, (total + kWave - 1) / kWave);
+  int Lp = 0;
+  for (;;) {
+    // ceil(ns / R) = floor((ns + R - 1/2) / R): the half keeps the quotient off the integers, so that the rounding of
+    // the reciprocal cannot tip it (exact for ns + R < 2^21)
+    const float fr = (float)R;
+    Lp = mine > 0 ? (int)(((float)mine + fr - 0.5f) * __frcp_rn(fr)) : 0;
+    if (wave_sum(Lp) <= kWave) break;
+    ++R;
+  }
+  const int incl = wave_scan_add(Lp);
+  const int start = incl - Lp;
+  seg[lane] = 0;
+  __syncthreads();
+  if (Lp > 0) seg[start] = ((lane + 1) << 16) | (Lp << 8) | start;
+  __syncthreads();
+  const int key = wave_scan_max_nonneg(seg[lane]);  // the segment this lane falls in: the last start at or before it
+  __syncthreads();                                  // (seg is the caller's staging buffer again after this)
+  SampleLanes sl;
+  sl.piece = max((key >> 16) - 1, 0);
+  sl.L = max((key >> 8) & 0xff, 1);
+  sl.r = lane - (key & 0xff);
+  sl.act = key != 0 && sl.r < sl.L;
+  sl.rounds = R;
+  sl.lmax = wave_max_nonneg(Lp);
+  sl.first = start;
+  return sl;
+}
+
+// sum over the lanes of each piece when the pieces have different numbers of lanes: suffix doubling with LDS
+// shuffles, lane r of a piece adds the value sft lanes on while that lane still belongs to the piece.  Fixed order.
+template <typename Real, int N>
+__device__ __forceinline__ void fold_piece_segments(Real (&v)[N], int r, int L, int lmax) {
+  for (int sft = 1; sft < lmax; sft <<= 1) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const Real o = __shfl_down(v[q], sft, kWave);
+      if (r + sft < L) v[q] += o;
+    }
+  }
 }
 
 // sampled feasibility + collision terms (:392-466), SAMPLE layout.
@@ -826,14 +945,13 @@ __device__ __forceinline__ Real fold_piece_lanes(Real v, int L, int r) {
 //   gC / gT are left in the first lane (r = 0) of each piece.
 // Costs are returned wave-uniform.  U = samples per lane whose gathers are put in flight together.
 template <typename Real, int D, class LookupT, int U, bool SAMPLE_IO = false, class LG = WaveLanes>
-__device__ __forceinline__ void minco_sample(int M, int L, int ns_in, const Real (&cp)[6][D],
+__device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int ns_in, const Real (&cp)[6][D],
                                              const DevParams &prm, const LookupT &lk, Real (&gC)[6][D], Real &gT,
                                              double &cost_feas, double &cost_coll) {
 #pragma clang fp contract(on)  // fuse a*b+c only as written: the same arithmetic whatever the unrolling around it
   const int lane = LG::lane();
-  const int piece = (lane * ((65536 + L - 1) / L)) >> 16;  // lane / L for lane < 64
-  const int r = lane - piece * L;
-  const bool act = piece < M;
+  const int piece = sl.piece, r = sl.r, L = sl.L;  // (L: per lane when the pieces have different numbers of lanes)
+  const bool act = sl.act;
   Real c[6][D];
   int ns;
   if constexpr (SAMPLE_IO) {
@@ -851,148 +969,141 @@ __device__ __forceinline__ void minco_sample(int M, int L, int ns_in, const Real
     const int ns_sh = __shfl(ns_in, LG::base() + piece, kWave);
     ns = act ? ns_sh : 0;
   }
-  const int iters = (prm.dbg & 1) ? 0 : wave_max_nonneg((ns + L - 1) / L);
+  const int iters = (prm.dbg & 1) ? 0 : (sl.rounds >= 0 ? sl.rounds : wave_max_nonneg((ns + L - 1) / L));
 
   const Real dt = (Real)prm.delta_t, vmax2 = (Real)(prm.v_max * prm.v_max), safe = (Real)prm.safe_dis;
   const Real w2 = (Real)prm.w[2], w3 = (Real)prm.w[3];
   const Real inv_ns = ns > 0 ? Real(1) / (Real)ns : Real(0);
-  // Two passes over chunks of 64 rounds.  Violations are rare, so the first pass only DETECTS them: U samples per
-  // lane are prepared together, their gathers issued back to back, and all it keeps per sample is one bit -- no
-  // accumulator is live in this loop, which is what lets it hold U lookups in flight per lane in few registers.  The
-  // second pass revisits the flagged samples in ascending order (per lane: the order and the arithmetic of a
-  // single pass, so the sums are the same bits) and accumulates costs and partials; its loop runs as many times as
-  // the busiest lane has violations.
-  auto sample_time = [&](int j) -> Real { return (Real)((double)j * prm.delta_t); };  // beta_full row j: t = j * delta_t (:251)
-  auto detect = [&](int chunk0) -> unsigned long long {
-    const int chunk_end = min(iters, chunk0 + 64);
-    unsigned long long viol = 0ull;
-    for (int it0 = chunk0; it0 < chunk_end; it0 += U) {
-      Real sv[U], vel[U][D];
-      typename LookupT::Addr ad[U];
-      typename LookupT::Raw rw[U];
-      bool on[U];
-      // stand-alone kernel: lanes whose piece has run out of samples sit the round out (exec-masked)
-      if constexpr (SAMPLE_IO)
-        if (r + it0 * L >= ns) continue;
-      // only the position is needed to issue the gathers; the velocity is evaluated while they fly
-      constexpr bool kVelLate = SAMPLE_IO && sizeof(Real) == 4;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int j = r + (it0 + u) * L;
-        on[u] = j < ns && it0 + u < chunk_end;
-        const Real s = sample_time(j);
-        sv[u] = s;
-        Real pos[D];
-        if constexpr (kVelLate) {
-#pragma unroll
-          for (int d = 0; d < D; ++d)
-            pos[d] = fmaf(fmaf(fmaf(fmaf(fmaf(c[5][d], s, c[4][d]), s, c[3][d]), s, c[2][d]), s, c[1][d]), s, c[0][d]);
-        } else {
-          piece_pos_vel<Real, D>(c, s, pos, vel[u]);
-        }
-        ad[u] = lk.template prepare<D>(pos, on[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) rw[u] = lk.load(ad[u]);
-      if constexpr (kVelLate) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          Real pos[D];
-          piece_pos_vel<Real, D>(c, sv[u], pos, vel[u]);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        Real v2 = Real(0);
-#pragma unroll
-        for (int d = 0; d < D; ++d) v2 += vel[u][d] * vel[u][d];
-        Real gdrop[D];
-        const Real vd = safe - lk.template finish<D>(ad[u], rw[u], gdrop);
-        if (on[u] && (v2 - vmax2 > Real(0) || vd > Real(0))) viol |= 1ull << (it0 + u - chunk0);
-      }
-    }
-    return viol;
-  };
-  // (the accumulators are defined AFTER the first detect pass, so that they hold no registers during it)
-  unsigned long long viol0 = detect(0);
   Real aC[6][D];
 #pragma unroll
   for (int k = 0; k < 6; ++k)
 #pragma unroll
     for (int d = 0; d < D; ++d) aC[k][d] = Real(0);
   Real aT = Real(0), aF = Real(0), aK = Real(0);
-  // second pass: the flagged samples of a chunk
-  auto accumulate = [&](int chunk0, unsigned long long viol) {
-    while (__any(viol != 0ull)) {
-      const bool has = viol != 0ull;
-      const int k = has ? __builtin_ctzll(viol) : 0;
-      viol &= viol - 1ull;
-      const int j = r + (chunk0 + k) * L;
-      const Real s = sample_time(j);
-      Real pos[D], vel[D], g[D];
-      piece_pos_vel<Real, D>(c, s, pos, vel);
-      const typename LookupT::Addr ad = lk.template prepare<D>(pos, has);
-      const typename LookupT::Raw rw = lk.load(ad);
-      const Real dist = lk.template finish<D>(ad, rw, g);
-      if (!has) continue;
-      Real v2 = Real(0);
+
+  // U samples per lane are prepared together and their gathers issued back to back before any of
+  // them is consumed
+  for (int it0 = 0; it0 < iters; it0 += U) {
+    Real sv[U], vel[U][D];
+    typename LookupT::Addr ad[U];
+    typename LookupT::Raw rw[U];
+    bool on[U];
+    // stand-alone kernel: lanes whose piece has run out of samples sit the round out (exec-masked)
+    if constexpr (SAMPLE_IO)
+      if (r + it0 * L >= ns) continue;
+    // only the position is needed to issue the gathers; the velocity is evaluated while they fly
+    constexpr bool kVelLate = SAMPLE_IO && sizeof(Real) == 4;
 #pragma unroll
-      for (int d = 0; d < D; ++d) v2 += vel[d] * vel[d];
-      const Real vv = v2 - vmax2, vd = safe - dist;
-      const Real omg = (j == 0 || j == ns - 1) ? Real(0.5) : Real(1);
-      const Real s2 = s * s, s3 = s2 * s, s4 = s2 * s2, s5 = s4 * s;
-      // dynamic feasibility
-      if (vv > Real(0)) {
-        const Real vq = vv;
-        aF += omg * dt * vq * vq * vq;
-        Real av = Real(0);
+    for (int u = 0; u < U; ++u) {
+      const int j = r + (it0 + u) * L;
+      on[u] = j < ns;
+      const Real s = (Real)((double)j * prm.delta_t);  // beta_full row j: t = j * delta_t (:251)
+      sv[u] = s;
+      Real pos[D];
+      if constexpr (kVelLate) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const Real acc = Real(2) * c[2][d] + s * (Real(6) * c[3][d] + s * (Real(12) * c[4][d] + s * (Real(20) * c[5][d])));
-          av += acc * vel[d];
-        }
-        const Real dK = Real(3) * dt * omg * vq * vq;
-        const Real b1[6] = {Real(0), Real(1), Real(2) * s, Real(3) * s2, Real(4) * s3, Real(5) * s4};
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const Real uu = w2 * dK * Real(2) * vel[d];
-#pragma unroll
-          for (int kk = 1; kk < 6; ++kk) aC[kk][d] += b1[kk] * uu;
-        }
-        aT += w2 * (omg * vq * vq * vq * inv_ns + dK * Real(2) * av * (Real)j * inv_ns);
+        for (int d = 0; d < D; ++d)
+          pos[d] = fmaf(fmaf(fmaf(fmaf(fmaf(c[5][d], s, c[4][d]), s, c[3][d]), s, c[2][d]), s, c[1][d]), s, c[0][d]);
+      } else {
+        piece_pos_vel<Real, D>(c, s, pos, vel[u]);
       }
-      // collision
-      if (vd > Real(0)) {
-        const Real vq = vd;
-        aK += omg * dt * vq * vq * vq;
-        const Real dK = Real(3) * dt * omg * vq * vq;
-        const Real b0[6] = {Real(1), s, s2, s3, s4, s5};
-        Real gv = Real(0);
+      ad[u] = lk.template prepare<D>(pos, on[u]);
+    }
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-          gv += g[d] * vel[d];
-          const Real uu = -(w3 * dK * g[d]);
+    for (int u = 0; u < U; ++u) rw[u] = lk.load(ad[u]);
+    if constexpr (kVelLate) {
 #pragma unroll
-          for (int kk = 0; kk < 6; ++kk) aC[kk][d] += b0[kk] * uu;
-        }
-        aT += w3 * (omg * vq * vq * vq * inv_ns + dK * (-gv) * (Real)j * inv_ns);
+      for (int u = 0; u < U; ++u) {
+        Real pos[D];
+        piece_pos_vel<Real, D>(c, sv[u], pos, vel[u]);
       }
     }
-  };
-  accumulate(0, viol0);
-  for (int chunk0 = 64; chunk0 < iters; chunk0 += 64) accumulate(chunk0, detect(chunk0));  // (more than 64 rounds: rare)
+    // violations are rare: first only the two penalties' arguments for the U samples, one test for the
+    // whole group, and the per-sample accumulation code only if some lane of the wave needs it
+    Real vv[U], vd[U];
+    bool any_violation = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      Real v2 = Real(0);
+#pragma unroll
+      for (int d = 0; d < D; ++d) v2 += vel[u][d] * vel[u][d];
+      vv[u] = v2 - vmax2;
+      Real gdrop[D];
+      vd[u] = safe - lk.template finish<D>(ad[u], rw[u], gdrop);
+      if (on[u] && (vv[u] > Real(0) || vd[u] > Real(0))) any_violation = true;
+    }
+    if (any_violation) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!on[u]) continue;
+        const int j = r + (it0 + u) * L;
+        const Real s = sv[u];
+        const Real omg = (j == 0 || j == ns - 1) ? Real(0.5) : Real(1);
+        const Real s2 = s * s, s3 = s2 * s, s4 = s2 * s2, s5 = s4 * s;
+        // dynamic feasibility
+        if (vv[u] > Real(0)) {
+          const Real vq = vv[u];
+          aF += omg * dt * vq * vq * vq;
+          Real av = Real(0);
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            const Real acc = Real(2) * c[2][d] + s * (Real(6) * c[3][d] + s * (Real(12) * c[4][d] + s * (Real(20) * c[5][d])));
+            av += acc * vel[u][d];
+          }
+          const Real dK = Real(3) * dt * omg * vq * vq;
+          const Real b1[6] = {Real(0), Real(1), Real(2) * s, Real(3) * s2, Real(4) * s3, Real(5) * s4};
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            const Real uu = w2 * dK * Real(2) * vel[u][d];
+#pragma unroll
+            for (int k = 1; k < 6; ++k) aC[k][d] += b1[k] * uu;
+          }
+          aT += w2 * (omg * vq * vq * vq * inv_ns + dK * Real(2) * av * (Real)j * inv_ns);
+        }
+        // collision
+        if (vd[u] > Real(0)) {
+          Real g[D];
+          (void)lk.template finish<D>(ad[u], rw[u], g);
+          const Real vq = vd[u];
+          aK += omg * dt * vq * vq * vq;
+          const Real dK = Real(3) * dt * omg * vq * vq;
+          const Real b0[6] = {Real(1), s, s2, s3, s4, s5};
+          Real gv = Real(0);
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            gv += g[d] * vel[u][d];
+            const Real uu = -(w3 * dK * g[d]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) aC[k][d] += b0[k] * uu;
+          }
+          aT += w3 * (omg * vq * vq * vq * inv_ns + dK * (-gv) * (Real)j * inv_ns);
+        }
+      }
+    }
+  }
   // fold the L lanes of each piece (fixed order); PIECE-layout callers get lane piece*L moved to lane piece
-  auto fold = [&](Real v) -> Real {
-    const Real f = fold_piece_lanes<Real>(v, L, r);
-    if constexpr (SAMPLE_IO) return f;
-    return __shfl(f, LG::base() + lane * L, kWave);
-  };
+  Real fv[6 * D + 3];
 #pragma unroll
   for (int k = 0; k < 6; ++k)
 #pragma unroll
-    for (int d = 0; d < D; ++d) gC[k][d] = fold(aC[k][d]);
-  gT = fold(aT);
-  const Real pf = fold(aF), pk = fold(aK);
+    for (int d = 0; d < D; ++d) fv[k * D + d] = aC[k][d];
+  fv[6 * D] = aT;
+  fv[6 * D + 1] = aF;
+  fv[6 * D + 2] = aK;
+  if (sl.lmax == 0)
+    fold_piece_lanes<Real, 6 * D + 3>(fv, L, r);
+  else
+    fold_piece_segments<Real, 6 * D + 3>(fv, r, L, sl.lmax);
+  if constexpr (!SAMPLE_IO) {
+#pragma unroll
+    for (int q = 0; q < 6 * D + 3; ++q) fv[q] = __shfl(fv[q], LG::base() + sl.first, kWave);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int d = 0; d < D; ++d) gC[k][d] = fv[k * D + d];
+  gT = fv[6 * D];
+  const Real pf = fv[6 * D + 1], pk = fv[6 * D + 2];
   const bool mine = SAMPLE_IO ? (act && r == 0) : (lane < M);
   cost_feas = LG::sum(mine ? (double)pf : 0.0);
   cost_coll = LG::sum(mine ? (double)pk : 0.0);

