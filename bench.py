@@ -9,7 +9,8 @@ bench.py -- trajectories/sec of the batched replan inner loop on MI355X (BASELIN
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set for each, rendezvous on 127.0.0.1) before anything touches a GPU.
 
 Workload (config.workload): BASELINE.json configs[1] -- per GPU one 300^3-voxel fp32 ESDF of a synthetic
-random-forest scene (pillars + floating canopy boxes) resident in HBM, and request batches of
+random-forest scene (pillars + floating canopy boxes) resident in HBM in the yz-quad layout
+(NEO_LAYOUT_YZ4: the 8 corners of a trilinear cell in 32 contiguous bytes, 432 MB), and request batches of
 B = 4096 replans with 20 intermediate waypoints (M = 21 pieces, D = 3, n = 81 variables) whose starts, goals and
 waypoints fill the volume (synth.VOLUME: heights 1..25 m, climbing and descending paths).  One launch optimises one
 batch of 4096 from its initial guess to L-BFGS-B termination (neo_optimize_batch_dev), inputs already in HBM.
@@ -97,7 +98,8 @@ def parse(argv=None):
     ap.add_argument("--waypoints", type=int, default=20)
     ap.add_argument("--grid", type=int, default=300)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--layout", default="linear", choices=["linear", "yz4", "cell8"])
+    ap.add_argument("--layout", default="yz4", choices=["linear", "yz4", "cell8"],
+                    help="voxel order of the field in HBM (include/neo_planner.h NEO_LAYOUT_*); yz4 = one line per lookup")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall budget of the NumPy-port sample")
     ap.add_argument("--native-seconds", type=float, default=4.0, help="wall budget of each cpu_native run")
     ap.add_argument("--no-cpu", action="store_true")
@@ -351,7 +353,7 @@ def main():
     M, D, B = a.waypoints + 1, 3, a.batch
     n = D * (M - 1) + M
     default_workload = (a.config == "cfg2" and a.batch == 4096 and a.waypoints == 20 and a.grid == 300
-                        and a.dtype == "f32" and a.layout == "linear" and not a.planar)
+                        and a.dtype == "f32" and a.layout == "yz4" and not a.planar)
     if a.dry_run:
         return dry_run(a, rank, world, n)
     from neo_planner_amd import synth

@@ -35,16 +35,24 @@ def _cpu(field, res, x0, head, tail, M, idx, **kw):
     return cn.optimize_batch(nm, x0[idx], head[idx], tail[idx], M, 3, params=cn.make_params(**kw), threads=8)
 
 
-def _compare(gpu, cpu, idx, nq, min_follow):
+def _compare(gpu, cpu, idx, nq, ctrl):
+    """GPU runs against the CPU optimiser's, with the CPU-vs-CPU control `ctrl` (the same CPU runs with every
+    coefficient perturbed by one ulp) as the yardstick: the device may part from the CPU's path no more often than
+    the CPU parts from itself (binomial slack for the sample size), runs that keep the CPU's evaluation count end
+    on its control points, and the rest are valid runs of the same optimiser (same cost statistics)."""
+    n = len(idx)
     same = gpu["nfev"][idx] == cpu["nfev"]
+    same_ctrl = ctrl["nfev"] == cpu["nfev"]
     dx = np.abs(gpu["x"][idx][:, :nq] - cpu["x"][:, :nq]).max(axis=1) / np.abs(cpu["x"][:, :nq]).max(axis=1)
+    dx_ctrl = np.abs(ctrl["x"][:, :nq] - cpu["x"][:, :nq]).max(axis=1) / np.abs(cpu["x"][:, :nq]).max(axis=1)
     gc = (gpu["costs_last"][idx] * W4).sum(axis=1)
     cc = (cpu["costs_last"] * W4).sum(axis=1)
-    assert same.mean() >= min_follow, (same.mean(), min_follow)
-    # runs that follow the CPU evaluation for evaluation end where it ends
-    assert (dx[same] <= 1e-4).mean() >= 0.97, dx[same].max()
-    assert np.abs(gc[same] - cc[same]).max() <= 1e-4 * np.abs(cc[same]).max()
-    # the others are valid runs of the same optimiser: same cost statistics
+    slack = 2.5 * np.sqrt(0.25 / n) + 1.0 / n
+    assert same.mean() >= same_ctrl.mean() - slack, (same.mean(), same_ctrl.mean())
+    assert (dx <= 1e-4).mean() >= (dx_ctrl <= 1e-4).mean() - slack, ((dx <= 1e-4).mean(), (dx_ctrl <= 1e-4).mean())
+    if same.any():
+        # same evaluation count = same path, up to the drift the control shows for such runs
+        assert (dx[same] <= 1e-4).mean() >= 0.85 and dx[same].max() < 1e-2, dx[same].max()
     assert abs(np.median(gc) - np.median(cc)) <= 0.05 * abs(np.median(cc))
     return same.mean(), np.median(dx)
 
@@ -84,8 +92,9 @@ def test_cfg3_65536_warm_started_small_problems():
     idx = np.arange(0, B, B // 64)[:64]
     r64 = npa.BatchPlanner(sample_dtype="f64").optimize(g3, x0[idx], head[idx], tail[idx])
     cpu = _cpu(g3.dist, synth.RES, x0, head, tail, M, idx)
-    follow, med = _compare(r64, cpu, np.arange(64), 3 * (M - 1), min_follow=0.75)    # ~25 evaluations per run
-    assert med < 1e-8
+    ctrl = _cpu(g3.dist, synth.RES, x0, head, tail, M, idx, coeff_eps=2.2e-16)
+    follow, med = _compare(r64, cpu, np.arange(64), 3 * (M - 1), ctrl)
+    assert follow >= 0.75 and med < 1e-8                                            # ~25 evaluations per run
     # and the timed (fp32) modes against it, statistically
     cpu32 = _cpu(g3.dist, synth.RES, x0, head, tail, M, idx, sample_f32=True)
     for r in (rd, rg):
@@ -122,7 +131,8 @@ def test_cfg4_eight_scenes_per_trajectory_slots_equal_single_scene_runs():
         idx = s * per + np.arange(0, per, per // 32)[:32]
         g = bp64.optimize(scenes[s], x0[idx], head[idx], tail[idx])
         cpu = _cpu(scenes[s].dist, synth.RES, x0, head, tail, M, idx)
-        _compare(g, cpu, np.arange(32), 3 * (M - 1), min_follow=0.4)                 # control: 0.63 at ~135 evaluations
+        ctrl = _cpu(scenes[s].dist, synth.RES, x0, head, tail, M, idx, coeff_eps=2.2e-16)
+        _compare(g, cpu, np.arange(32), 3 * (M - 1), ctrl)                           # ~135 evaluations per run
 
 
 def test_cfg5_fp16_field_600_cubed_optimiser_against_cpu():
@@ -151,7 +161,8 @@ def test_cfg5_fp16_field_600_cubed_optimiser_against_cpu():
         # the whole optimisation (n = 161 variables, one-wave kernel, 4 FLAT slots)
         g = bp.optimize(g16, x0[:24], head[:24], tail[:24])
         cpu = _cpu(field16, res, x0, head, tail, M, np.arange(24))
-        follow, _ = _compare(g, cpu, np.arange(24), 3 * (M - 1), min_follow=0.15)    # ~340 evaluations per run
+        ctrl = _cpu(field16, res, x0, head, tail, M, np.arange(24), coeff_eps=2.2e-16)
+        _compare(g, cpu, np.arange(24), 3 * (M - 1), ctrl)                           # ~340 evaluations per run
         # fp32 sampling (the timed mode of cfg5) on the whole batch: properties
         r = npa.BatchPlanner(ctx=ctx, sample_dtype="f32").optimize(g16, x0, head, tail)
         e0 = npa.BatchPlanner(ctx=ctx, sample_dtype="f32").cost_grad(g16, x0, head, tail)

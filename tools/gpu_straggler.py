@@ -10,14 +10,17 @@ import neo_planner_amd as npa
 from neo_planner_amd import synth
 
 grid = 300; res = 30.0 / grid
-dist = synth.esdf_3d(0, n=grid, res=res)
+# NEO_PLANAR=1: the round-1 workload (z = 2 m, no canopy); NEO_LAYOUT, NEO_WAVES (1 | 2): layout / register allocation
+planar = bool(os.environ.get("NEO_PLANAR"))
+dist = synth.esdf_3d(0, n=grid, res=res, canopy=0 if planar else 80)
 B, M, D = 4096, 21, 3
-head, tail, wp, ts = synth.replan_requests(0, B, M - 1, D=D)
+head, tail, wp, ts = synth.replan_requests(0, B, M - 1, D=D, **({} if planar else synth.VOLUME))
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
 ctx = npa.Context(0, stream=st.cuda_stream)
-g3 = npa.ESDF3D(torch.from_numpy(dist).to(dev), res, synth.DOMAIN_ORIGIN, store="f32", ctx=ctx)
-bp = npa.BatchPlanner(ctx=ctx, sample_dtype="f32"); bp._sync()
+g3 = npa.ESDF3D(torch.from_numpy(dist).to(dev), res, synth.DOMAIN_ORIGIN, store="f32", ctx=ctx,
+                layout=os.environ.get("NEO_LAYOUT", "yz4"))
+bp = npa.BatchPlanner(ctx=ctx, sample_dtype="f32", waves_per_simd=int(os.environ.get("NEO_WAVES", "2"))); bp._sync()
 x0 = torch.from_numpy(bp.pack_x(wp, ts)).to(dev); x = x0.clone()
 h = torch.from_numpy(head).to(dev); tl = torch.from_numpy(tail).to(dev)
 costs = torch.zeros(B, 4, dtype=torch.float64, device=dev); last = torch.zeros_like(costs)
