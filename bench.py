@@ -16,8 +16,8 @@ waypoints fill the volume (synth.VOLUME: heights 1..25 m, climbing and descendin
 batch of 4096 from its initial guess to L-BFGS-B termination (neo_optimize_batch_dev), inputs already in HBM.
 One STEP = one pass of the hot path over `--batches-per-step` (default 16) different request batches of the scene,
 i.e. 16 launches of 4096 trajectories: long enough for the timed region to last seconds at the driver's
-`--steps 20`.  Launches are issued round-robin on `--streams` (default 3) HIP streams with separate state and result
-buffers: the end of a launch is a handful of long runs on an otherwise idle chip, and the next batch fills it
+`--steps 20`.  Launches are issued round-robin on `--streams` (default 4) HIP streams with separate state and result
+buffers: the end of a launch is a handful of long runs on an otherwise idle chip, and the next batches fill it
 (`--streams 1 --batches-per-step 1` gives the one-batch-at-a-time latency figure).
 With N > 1 every rank owns its own scene and batches (weak scaling, no data-path collective); the per-rank results
 of every batch are gathered with one RCCL all_gather inside the timed region.
@@ -107,7 +107,7 @@ def parse(argv=None):
     ap.add_argument("--no-order", action="store_true", help="dispatch trajectories in index order")
     ap.add_argument("--lane-groups", action="store_true",
                     help="small problems (cfg3): eight trajectories per wavefront (NEO_FLAG_LANE_GROUPS)")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="launches kept in flight per GPU (HIP streams): the tail of a launch -- a few long runs on an "
                          "otherwise idle chip -- overlaps with the next batch")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
