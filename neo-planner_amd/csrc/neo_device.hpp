@@ -418,6 +418,8 @@ struct Lookup3D {
   }
 };
 
+__host__ __device__ __forceinline__ int sample_lanes_per_piece_fwd(int M);
+
 // ------------------------------------------------------------------ lane groups
 // The per-trajectory functions below are written once for a GROUP of lanes that owns one trajectory:
 //   WaveLanes      the whole 64-lane wavefront (optimize / eval / sample kernels);
@@ -425,9 +427,21 @@ struct Lookup3D {
 //                  run the same instruction stream in lock step.
 // `lane()` is the lane inside the group; cross-lane traffic (sums, neighbour moves, broadcasts) stays inside the
 // group, which for W <= 16 lies inside one 16-lane DPP row.  All lanes of a wavefront call the functions together.
+//   WaveLanesPD<D> the whole wavefront with lane = (piece, dimension): D lanes per piece, ONE dimension's state per lane
+//                  (D * M <= 64: cfg2's M = 21 uses 63 lanes instead of 21 in the PIECE-layout phases).  Everything that
+//                  is per dimension -- boundary states, velocities, coefficients, every right-hand side of the joint
+//                  solves, partials -- shrinks to a third per lane: a third of the registers and of the instructions;
+//                  what depends on the durations only (the factorisation) is computed alike by the D lanes of a piece.
+// `piece()` is the piece (= joint) of the lane, `S` the lanes per piece, `dl(D)` the dimensions held per lane and
+// `dim0()` the first of them; `prev` / `next` / `read` address pieces, not lanes.
 struct WaveLanes {
   static constexpr int W = kWave;
+  static constexpr int S = 1;
+  static constexpr int dl(int D) { return D; }
   static __device__ __forceinline__ int lane() { return lane_id(); }
+  static __device__ __forceinline__ int piece() { return lane_id(); }
+  static __device__ __forceinline__ int dim0() { return 0; }
+  static __device__ __forceinline__ double sum_dims(double v) { return v; }
   static __device__ __forceinline__ int base() { return 0; }
   static __device__ __forceinline__ double read(double v, int src /*wave-uniform*/) { return rdlane(v, src); }
   static __device__ __forceinline__ double prev(double v, double fill) { return from_prev(v, fill); }
@@ -442,6 +456,11 @@ template <int W_>
 struct GroupLanes {
   static_assert(W_ == 16 || W_ == 8, "a group is a DPP row or half of one");
   static constexpr int W = W_;
+  static constexpr int S = 1;
+  static constexpr int dl(int D) { return D; }
+  static __device__ __forceinline__ int piece() { return lane_id() & (W - 1); }
+  static __device__ __forceinline__ int dim0() { return 0; }
+  static __device__ __forceinline__ double sum_dims(double v) { return v; }
   static __device__ __forceinline__ int lane() { return lane_id() & (W - 1); }
   static __device__ __forceinline__ int base() { return lane_id() & ~(W - 1); }
   // sums / maxima over the group, result in every lane.  W = 16: the in-row part of wave_sum (row_shr scan, then the
@@ -497,17 +516,71 @@ struct GroupLanes {
   }
 };
 
+template <int D_>
+struct WaveLanesPD {
+  static constexpr int W = kWave;
+  static constexpr int S = D_;
+  static constexpr int dl(int) { return 1; }
+  static __device__ __forceinline__ int lane() { return lane_id(); }
+  static __device__ __forceinline__ int base() { return 0; }
+  static __device__ __forceinline__ int piece() { return (lane_id() * ((65536 + S - 1) / S)) >> 16; }  // lane / S
+  static __device__ __forceinline__ int dim0() { return lane_id() - S * piece(); }
+  // value held by piece q (any of its lanes: used for quantities that depend on the durations only)
+  static __device__ __forceinline__ double read(double v, int q /*wave-uniform*/) { return rdlane(v, S * q); }
+  // value of the same dimension in the previous / next piece: S single-lane DPP shifts
+  static __device__ __forceinline__ double prev(double v, double fill) {
+#pragma unroll
+    for (int k = 0; k < S; ++k) v = dpp_d<0x138>(v);  // wave_shr:1
+    return lane_id() < S ? fill : v;
+  }
+  static __device__ __forceinline__ double next(double v, double fill) {
+#pragma unroll
+    for (int k = 0; k < S; ++k) v = dpp_d<0x130>(v);  // wave_shl:1
+    return lane_id() >= kWave - S ? fill : v;
+  }
+  static __device__ __forceinline__ double sum(double v) { return wave_sum(v); }
+  static __device__ __forceinline__ int sum(int v) { return wave_sum(v); }
+  static __device__ __forceinline__ int any(int pred) { return __any(pred); }
+  // sum over the S lanes (dimensions) of a piece; valid in the piece's first lane
+  static __device__ __forceinline__ double sum_dims(double v) {
+    double acc = v, t = v;
+#pragma unroll
+    for (int k = 1; k < S; ++k) {
+      t = dpp_d<0x130>(t);
+      acc += t;
+    }
+    return acc;
+  }
+  static __host__ __device__ __forceinline__ int lanes_per_piece(int M) { return sample_lanes_per_piece_fwd(M); }
+};
+
+// element (row k, dimension of this lane's local index dl) of a boundary state [3][D] in global memory: a uniform
+// scalar load when the lane holds all dimensions, a select among the D scalars when it holds one
+template <int D, class LG>
+__device__ __forceinline__ double bstate(const double *p, int k, int dl) {
+  if constexpr (LG::S == 1) {
+    return p[k * D + dl];
+  } else {
+    const int d = LG::dim0();
+    double v = p[k * D];
+#pragma unroll
+    for (int j = 1; j < D; ++j) v = (d == j) ? p[k * D + j] : v;
+    return v;
+  }
+}
+
 // ------------------------------------------------------------------ per-trajectory state
-template <int D>
+// DL = dimensions held per lane: D (PIECE layout: lane = piece) or 1 (lane = (piece, dimension), WaveLanesPD)
+template <int D, int DL = D>
 struct Traj {
   // wave-uniform
   int M, n, nq, L;
-  // PIECE layout (lane p < M)
+  // PIECE layout (lane p < M; with DL = 1 every lane of the piece)
   double T, tau;                  // tau: the decision variable on entry to minco_forward, exp(-tau) after it
   double i1, i2, i3, i4;          // T^-1 .. T^-4
-  double P0[D], P1[D];            // positions at the start / end joint
-  double V0[D], A0[D], V1[D], A1[D];
-  double c[6][D];                 // polynomial coefficients
+  double P0[DL], P1[DL];          // positions at the start / end joint
+  double V0[DL], A0[DL], V1[DL], A1[DL];
+  double c[6][DL];                // polynomial coefficients
   int ns;                         // samples of this piece: int(T / delta_t)
   double N[2][2];                 // pivot-block inverse of the joint system (lane = joint)
   const double *head, *tail;      // boundary states [3][D] in global memory (wave-uniform scalar loads)
@@ -529,7 +602,7 @@ __device__ __forceinline__ void thomas_factor(int M, const double (&Lo)[2][2], c
   // Eh_p = s dl_{p-1} adj(Dh) Up_p,  dl_p = s det(Dh),  s = a power of two that brings dl_p to
   // [0.5, 1) so nothing over/underflows.  Each lane keeps its own Dh and dl_{p-1} and forms
   // N_p = dl_{p-1} adj(Dh)/det(Dh) and E_p = Eh_p/dl_p after the loop, all lanes in parallel.
-  const int lane = LG::lane();
+  const int lane = LG::piece();  // (every lane of a piece computes the same factors)
   double Eh[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, dl = 1.0;  // lane 0: E_0 = 0
   double Dh[2][2] = {{1.0, 0.0}, {0.0, 1.0}}, dprev = 1.0;
   for (int p = 1; p < M; ++p) {
@@ -579,13 +652,13 @@ __device__ __forceinline__ void thomas_factor(int M, const double (&Lo)[2][2], c
 // prefix / suffix scans over the lanes: ceil(log2 M) steps, every lane busy, 10x shorter
 // dependent chain.  |A| < 1 for these diagonally dominant systems, so the products decay
 // (checked against the sequential sweep to 6e-15 over T in [0.5,5]^M, M <= 64).
-template <int D, class LG = WaveLanes>
+template <int DL, class LG = WaveLanes>
 __device__ __forceinline__ void thomas_solve(int M, const double (&Lo)[2][2], const double (&N)[2][2],
-                                             const double (&E)[2][2], const double (&R)[2][D],
-                                             const double (&y0)[2][D], const double (&yM)[2][D],
-                                             double (&y)[2][D]) {
-  const int lane = LG::lane();
-  double A[2][2], b[2][D];
+                                             const double (&E)[2][2], const double (&R)[2][DL],
+                                             const double (&y0)[2][DL], const double (&yM)[2][DL],
+                                             double (&y)[2][DL]) {
+  const int lane = LG::piece();
+  double A[2][2], b[2][DL];
   // ---- forward: lane 0 is the constant map v -> y_0
   {
     const bool in = lane >= 1 && lane < M;
@@ -594,7 +667,7 @@ __device__ __forceinline__ void thomas_solve(int M, const double (&Lo)[2][2], co
     A[1][0] = in ? -(N[1][0] * Lo[0][0] + N[1][1] * Lo[1][0]) : 0.0;
     A[1][1] = in ? -(N[1][0] * Lo[0][1] + N[1][1] * Lo[1][1]) : 0.0;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DL; ++d) {
       const double r0 = N[0][0] * R[0][d] + N[0][1] * R[1][d];
       const double r1 = N[1][0] * R[0][d] + N[1][1] * R[1][d];
       b[0][d] = lane == 0 ? y0[0][d] : (in ? r0 : 0.0);
@@ -602,17 +675,17 @@ __device__ __forceinline__ void thomas_solve(int M, const double (&Lo)[2][2], co
     }
   }
   for (int s = 1; s < M; s <<= 1) {
-    double As[2][2], bs[2][D];
+    double As[2][2], bs[2][DL];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) As[i][j] = __shfl_up(A[i][j], s, kWave);
+      for (int j = 0; j < 2; ++j) As[i][j] = __shfl_up(A[i][j], s * LG::S, kWave);
 #pragma unroll
-      for (int d = 0; d < D; ++d) bs[i][d] = __shfl_up(b[i][d], s, kWave);
+      for (int d = 0; d < DL; ++d) bs[i][d] = __shfl_up(b[i][d], s * LG::S, kWave);
     }
     if (lane >= s && lane < M) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
+      for (int d = 0; d < DL; ++d) {
         const double n0 = A[0][0] * bs[0][d] + A[0][1] * bs[1][d] + b[0][d];
         const double n1 = A[1][0] * bs[0][d] + A[1][1] * bs[1][d] + b[1][d];
         b[0][d] = n0;
@@ -627,7 +700,7 @@ __device__ __forceinline__ void thomas_solve(int M, const double (&Lo)[2][2], co
   {
     const bool in = lane >= 1 && lane < M - 1;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DL; ++d) {
       if (lane == M - 1) {
         b[0][d] -= E[0][0] * yM[0][d] + E[0][1] * yM[1][d];
         b[1][d] -= E[1][0] * yM[0][d] + E[1][1] * yM[1][d];
@@ -639,17 +712,17 @@ __device__ __forceinline__ void thomas_solve(int M, const double (&Lo)[2][2], co
     A[1][1] = in ? -E[1][1] : 0.0;
   }
   for (int s = 1; s < M; s <<= 1) {
-    double As[2][2], bs[2][D];
+    double As[2][2], bs[2][DL];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) As[i][j] = __shfl_down(A[i][j], s, kWave);
+      for (int j = 0; j < 2; ++j) As[i][j] = __shfl_down(A[i][j], s * LG::S, kWave);
 #pragma unroll
-      for (int d = 0; d < D; ++d) bs[i][d] = __shfl_down(b[i][d], s, kWave);
+      for (int d = 0; d < DL; ++d) bs[i][d] = __shfl_down(b[i][d], s * LG::S, kWave);
     }
     if (lane >= 1 && lane + s <= M - 1) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
+      for (int d = 0; d < DL; ++d) {
         const double n0 = A[0][0] * bs[0][d] + A[0][1] * bs[1][d] + b[0][d];
         const double n1 = A[1][0] * bs[0][d] + A[1][1] * bs[1][d] + b[1][d];
         b[0][d] = n0;
@@ -661,7 +734,7 @@ __device__ __forceinline__ void thomas_solve(int M, const double (&Lo)[2][2], co
     }
   }
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < DL; ++d) {
     y[0][d] = b[0][d];
     y[1][d] = b[1][d];
   }
@@ -669,8 +742,8 @@ __device__ __forceinline__ void thomas_solve(int M, const double (&Lo)[2][2], co
 
 // joint-system blocks of lane p (joint p between piece p-1 "a" and piece p "b")
 // (a1..a3 = T^-1..T^-3 of piece p-1, fetched from the neighbour lane by the caller)
-template <int D>
-__device__ __forceinline__ void joint_blocks(const Traj<D> &t, double a1, double a2, double a3,
+template <class TrajT>
+__device__ __forceinline__ void joint_blocks(const TrajT &t, double a1, double a2, double a3,
                                              double (&Lo)[2][2], double (&Di)[2][2], double (&Up)[2][2]) {
   Lo[0][0] = -24.0 * a2;  Lo[0][1] = -3.0 * a1;
   Lo[1][0] = -168.0 * a3; Lo[1][1] = -24.0 * a2;
@@ -683,9 +756,10 @@ __device__ __forceinline__ void joint_blocks(const Traj<D> &t, double a1, double
 // forward pass.  Inputs (PIECE layout): t.tau, t.P0, t.P1 set by the caller, head/tail uniform.
 // Returns 0 or NUMERIC_RANGE (4) when exp(-tau) overflows like math.exp does (:481).
 template <int D, class LG = WaveLanes>
-__device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, double &energy,
+__device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D)> &t, const DevParams &prm, double &energy,
                                              double &time_sum) {
-  const int lane = LG::lane();
+  constexpr int DL = LG::dl(D);
+  const int lane = LG::piece();
   const bool act = lane < t.M;
   int bad = 0;
   // map_tau2T (:477-483)
@@ -704,46 +778,46 @@ __device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, d
   t.ns = act ? (int)(t.T / prm.delta_t) : 0;  // int(T / delta_t) (:401)
 
   if (t.M > 1) {
-    double Lo[2][2], Di[2][2], Up[2][2], E[2][2], R[2][D], y0[2][D], yM[2][D], y[2][D];
+    double Lo[2][2], Di[2][2], Up[2][2], E[2][2], R[2][DL], y0[2][DL], yM[2][DL], y[2][DL];
     const double a1 = LG::prev(t.i1, 1.0), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;
     joint_blocks(t, a1, a2, a3, Lo, Di, Up);
     thomas_factor<LG>((prm.dbg & (2 | 8)) ? 1 : t.M, Lo, Di, Up, t.N, E);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DL; ++d) {
       // displacement of piece p-1 and of piece p
       const double dPb = t.P1[d] - t.P0[d];
       const double dPa = LG::prev(dPb, 0.0);
       R[0][d] = -(60.0 * a3 * dPa - 60.0 * t.i3 * dPb);
       R[1][d] = -(360.0 * a4 * dPa + 360.0 * t.i4 * dPb);
-      y0[0][d] = t.head[1 * D + d];
-      y0[1][d] = t.head[2 * D + d];
-      yM[0][d] = t.tail[1 * D + d];
-      yM[1][d] = t.tail[2 * D + d];
+      y0[0][d] = bstate<D, LG>(t.head, 1, d);
+      y0[1][d] = bstate<D, LG>(t.head, 2, d);
+      yM[0][d] = bstate<D, LG>(t.tail, 1, d);
+      yM[1][d] = bstate<D, LG>(t.tail, 2, d);
     }
-    thomas_solve<D, LG>((prm.dbg & (2 | 16)) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);
+    thomas_solve<DL, LG>((prm.dbg & (2 | 16)) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      t.V0[d] = lane == 0 ? t.head[1 * D + d] : y[0][d];
-      t.A0[d] = lane == 0 ? t.head[2 * D + d] : y[1][d];
+    for (int d = 0; d < DL; ++d) {
+      t.V0[d] = lane == 0 ? bstate<D, LG>(t.head, 1, d) : y[0][d];
+      t.A0[d] = lane == 0 ? bstate<D, LG>(t.head, 2, d) : y[1][d];
     }
   } else {
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      t.V0[d] = t.head[1 * D + d];
-      t.A0[d] = t.head[2 * D + d];
+    for (int d = 0; d < DL; ++d) {
+      t.V0[d] = bstate<D, LG>(t.head, 1, d);
+      t.A0[d] = bstate<D, LG>(t.head, 2, d);
     }
   }
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < DL; ++d) {
     const double v1 = LG::next(t.V0[d], 0.0), a1 = LG::next(t.A0[d], 0.0);
-    t.V1[d] = (lane == t.M - 1) ? t.tail[1 * D + d] : v1;
-    t.A1[d] = (lane == t.M - 1) ? t.tail[2 * D + d] : a1;
+    t.V1[d] = (lane == t.M - 1) ? bstate<D, LG>(t.tail, 1, d) : v1;
+    t.A1[d] = (lane == t.M - 1) ? bstate<D, LG>(t.tail, 2, d) : a1;
   }
   // Hermite form of the quintic
   double e = 0.0;
   const double T = t.T, T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < DL; ++d) {
     const double ep = t.P1[d] - t.P0[d] - T * t.V0[d] - 0.5 * T2 * t.A0[d];
     const double ev = t.V1[d] - t.V0[d] - T * t.A0[d];
     const double ea = t.A1[d] - t.A0[d];
@@ -759,7 +833,7 @@ __device__ __forceinline__ int minco_forward(Traj<D> &t, const DevParams &prm, d
          720.0 * T4 * c4 * c5 + 720.0 * T5 * c5 * c5;
   }
   energy = LG::sum(act ? e : 0.0);
-  time_sum = LG::sum(act ? t.T : 0.0);  // add_time_cost (:386-387)
+  time_sum = LG::sum((act && LG::dim0() == 0) ? t.T : 0.0);  // add_time_cost (:386-387): once per piece
   return 0;
 }
 
@@ -800,6 +874,7 @@ __host__ __device__ __forceinline__ int sample_lanes_per_piece(int M) {
 }
 
 __host__ __device__ __forceinline__ int WaveLanes::lanes_per_piece(int M) { return sample_lanes_per_piece(M); }
+__host__ __device__ __forceinline__ int sample_lanes_per_piece_fwd(int M) { return sample_lanes_per_piece(M); }
 
 template <typename Real, int CTRL>
 __device__ __forceinline__ Real dpp_real(Real v) {
@@ -945,8 +1020,8 @@ __device__ __forceinline__ void fold_piece_segments(Real (&v)[N], int r, int L, 
 //   gC / gT are left in the first lane (r = 0) of each piece.
 // Costs are returned wave-uniform.  U = samples per lane whose gathers are put in flight together.
 template <typename Real, int D, class LookupT, int U, bool SAMPLE_IO = false, class LG = WaveLanes>
-__device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int ns_in, const Real (&cp)[6][D],
-                                             const DevParams &prm, const LookupT &lk, Real (&gC)[6][D], Real &gT,
+__device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int ns_in, const Real (&cp)[6][LG::dl(D)],
+                                             const DevParams &prm, const LookupT &lk, Real (&gC)[6][LG::dl(D)], Real &gT,
                                              double &cost_feas, double &cost_coll) {
 #pragma clang fp contract(on)  // fuse a*b+c only as written: the same arithmetic whatever the unrolling around it
   const int lane = LG::lane();
@@ -961,12 +1036,17 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
       for (int d = 0; d < D; ++d) c[k][d] = cp[k][d];
     ns = act ? ns_in : 0;
   } else {
-    // hand the piece data to its L sample lanes
+    // hand the piece data to its L sample lanes (every sample lane needs all D dimensions of its piece)
 #pragma unroll
     for (int k = 0; k < 6; ++k)
 #pragma unroll
-      for (int d = 0; d < D; ++d) c[k][d] = __shfl(cp[k][d], LG::base() + piece, kWave);
-    const int ns_sh = __shfl(ns_in, LG::base() + piece, kWave);
+      for (int d = 0; d < D; ++d) {
+        if constexpr (LG::S == 1)
+          c[k][d] = __shfl(cp[k][d], LG::base() + piece, kWave);
+        else
+          c[k][d] = __shfl(cp[k][0], LG::S * piece + d, kWave);
+      }
+    const int ns_sh = __shfl(ns_in, LG::base() + LG::S * piece, kWave);
     ns = act ? ns_sh : 0;
   }
   const int iters = (prm.dbg & 1) ? 0 : (sl.rounds >= 0 ? sl.rounds : wave_max_nonneg((ns + L - 1) / L));
@@ -1095,16 +1175,31 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
   else
     fold_piece_segments<Real, 6 * D + 3>(fv, r, L, sl.lmax);
   if constexpr (!SAMPLE_IO) {
+    // back to the lanes of the piece (sl.first is held by lane p for piece p)
+    int src = LG::base() + sl.first;
+    if constexpr (LG::S > 1) src = __shfl(sl.first, LG::piece(), kWave);
 #pragma unroll
-    for (int q = 0; q < 6 * D + 3; ++q) fv[q] = __shfl(fv[q], LG::base() + sl.first, kWave);
+    for (int q = 0; q < 6 * D + 3; ++q) fv[q] = __shfl(fv[q], src, kWave);
   }
+  if constexpr (LG::S == 1) {
 #pragma unroll
-  for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < 6; ++k)
 #pragma unroll
-    for (int d = 0; d < D; ++d) gC[k][d] = fv[k * D + d];
+      for (int d = 0; d < D; ++d) gC[k][d] = fv[k * D + d];
+  } else {
+    // one dimension per lane: keep this lane's column of the partials
+    const int dm = LG::dim0();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      Real v = fv[k * D];
+#pragma unroll
+      for (int j = 1; j < D; ++j) v = (dm == j) ? fv[k * D + j] : v;
+      gC[k][0] = v;
+    }
+  }
   gT = fv[6 * D];
   const Real pf = fv[6 * D + 1], pk = fv[6 * D + 2];
-  const bool mine = SAMPLE_IO ? (act && r == 0) : (lane < M);
+  const bool mine = SAMPLE_IO ? (act && r == 0) : (LG::piece() < M && LG::dim0() == 0);  // every piece once
   cost_feas = LG::sum(mine ? (double)pf : 0.0);
   cost_coll = LG::sum(mine ? (double)pk : 0.0);
 }
@@ -1116,19 +1211,21 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
 // a power in two places, `(np.dot(c, beta3).item())**2` (:382) and `(1+math.exp(-tau))**2` (:490),
 // and Python raises once such a result exceeds the double range instead of returning inf.
 template <int D, class LG = WaveLanes>
-__device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams &prm, double (&gC)[6][D],
-                                              double gT, double (&gq)[D], double &gtau) {
-  const int lane = LG::lane();
+__device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D)> &t, const DevParams &prm,
+                                              double (&gC)[6][LG::dl(D)], double gT, double (&gq)[LG::dl(D)], double &gtau) {
+  constexpr int DL = LG::dl(D);
+  const int lane = LG::piece();
   const int M = t.M;
   int pow_overflow = 0;
   const double a1 = LG::prev(t.i1, 1.0), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;  // piece p-1
   const double T = t.T, T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
   const double w0 = prm.w[0];
-  double jerk_end[D], snap_end[D], crackle[D];
+  double jerk_end[DL], snap_end[DL], crackle[DL];
   // add_energy_grad_CT (:361-384), add_time_grad_CT (:389-390)
-  gT += prm.w[1];
+  // (gT: the sampled partial and the time weight enter once per piece -- in the lane of its first dimension)
+  gT = (LG::dim0() == 0) ? gT + prm.w[1] : 0.0;
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < DL; ++d) {
     const double c3 = t.c[3][d], c4 = t.c[4][d], c5 = t.c[5][d];
     gC[3][d] += 2.0 * w0 * (36.0 * T * c3 + 72.0 * T2 * c4 + 120.0 * T3 * c5);
     gC[4][d] += 2.0 * w0 * (72.0 * T2 * c3 + 192.0 * T3 * c4 + 360.0 * T4 * c5);
@@ -1140,9 +1237,9 @@ __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams 
     gT += w0 * jerk_end[d] * jerk_end[d];
   }
   // gz = H(T)^T gC : sensitivity wrt the end states Z = (p0, v0, a0, p1, v1, a1)
-  double gz[6][D];
+  double gz[6][DL];
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < DL; ++d) {
     const double gep = 10.0 * gC[3][d] * t.i3 - 15.0 * gC[4][d] * t.i4 + 6.0 * gC[5][d] * t.i4 * t.i1;
     const double gev = -4.0 * gC[3][d] * t.i2 + 7.0 * gC[4][d] * t.i3 - 3.0 * gC[5][d] * t.i4;
     const double gea = 0.5 * gC[3][d] * t.i1 - gC[4][d] * t.i2 + 0.5 * gC[5][d] * t.i3;
@@ -1154,18 +1251,18 @@ __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams 
     gz[5][d] = gea;
   }
   // S_p = dW/d(state of joint p) = gz_{p-1}[3:6] + gz_p[0:3]   (lanes 1..M-1)
-  double S[3][D];
+  double S[3][DL];
 #pragma unroll
   for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int d = 0; d < D; ++d) S[k][d] = LG::prev(gz[3 + k][d], 0.0) + gz[k][d];
+    for (int d = 0; d < DL; ++d) S[k][d] = LG::prev(gz[3 + k][d], 0.0) + gz[k][d];
 
-  double lam[2][D];
+  double lam[2][DL];
 #pragma unroll
-  for (int d = 0; d < D; ++d) lam[0][d] = lam[1][d] = 0.0;
+  for (int d = 0; d < DL; ++d) lam[0][d] = lam[1][d] = 0.0;
   if (M > 1) {
     // transposed system: row p of K^T has Up_{p-1}^T, Di_p^T, Lo_{p+1}^T; pivot inverses are N^T
-    double LoT[2][2], NT[2][2], ET[2][2], R[2][D], z0[2][D], y[2][D];
+    double LoT[2][2], NT[2][2], ET[2][2], R[2][DL], z0[2][DL], y[2][DL];
     LoT[0][0] = 24.0 * a2;  LoT[0][1] = -168.0 * a3;   // Up_{p-1}^T (piece p-1 = "a")
     LoT[1][0] = -3.0 * a1;  LoT[1][1] = 24.0 * a2;
     NT[0][0] = t.N[0][0]; NT[0][1] = t.N[1][0]; NT[1][0] = t.N[0][1]; NT[1][1] = t.N[1][1];
@@ -1178,22 +1275,22 @@ __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams 
       ET[1][1] = NT[1][0] * u01 + NT[1][1] * u11;
     }
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DL; ++d) {
       R[0][d] = S[1][d];
       R[1][d] = S[2][d];
       z0[0][d] = z0[1][d] = 0.0;
     }
-    thomas_solve<D, LG>((prm.dbg & (2 | 16)) ? 1 : M, LoT, NT, ET, R, z0, z0, y);
+    thomas_solve<DL, LG>((prm.dbg & (2 | 16)) ? 1 : M, LoT, NT, ET, R, z0, z0, y);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DL; ++d) {
       lam[0][d] = (lane >= 1 && lane < M) ? y[0][d] : 0.0;
       lam[1][d] = (lane >= 1 && lane < M) ? y[1][d] : 0.0;
     }
   }
   // dW/dq: G[6i+3] of the reference (:506-508)
-  double Gt[3][D];  // sensitivity wrt the tail state (lane M-1), = G[-3:] of the reference
+  double Gt[3][DL];  // sensitivity wrt the tail state (lane M-1), = G[-3:] of the reference
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < DL; ++d) {
     const double l1 = lam[0][d], l2 = lam[1][d];
     const double dp_prev = -60.0 * a3 * l1 - 360.0 * a4 * l2;
     const double dp_here = (60.0 * a3 + 60.0 * t.i3) * l1 + (360.0 * a4 - 360.0 * t.i4) * l2;
@@ -1210,7 +1307,7 @@ __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams 
   // dW/dT (:511-533)
   double gTt = gT;
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < DL; ++d) {
     const double v1 = t.V1[d], a1 = t.A1[d], je = jerk_end[d];
     gTt -= gz[3][d] * v1 + gz[4][d] * a1 + gz[5][d] * je;
     // joint p+1 (this piece ends there): rows +je.Z, +se.Z
@@ -1233,7 +1330,7 @@ __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams 
     if (prm.stale_T && M >= 2 && lane == M - 1) {
       const double S2 = Ts * Ts, S3 = S2 * Ts, S4 = S2 * S2;
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
+      for (int d = 0; d < DL; ++d) {
         const double c1 = t.c[1][d], c2 = t.c[2][d], c3 = t.c[3][d], c4 = t.c[4][d], c5 = t.c[5][d];
         const double velL = c1 + 2.0 * T * c2 + 3.0 * T2 * c3 + 4.0 * T3 * c4 + 5.0 * T4 * c5;
         const double velS = c1 + 2.0 * Ts * c2 + 3.0 * S2 * c3 + 4.0 * S3 * c4 + 5.0 * S4 * c5;
@@ -1249,7 +1346,7 @@ __device__ __forceinline__ int minco_backward(const Traj<D> &t, const DevParams 
   const double ex = t.tau;  // exp(-tau), left there by minco_forward
   // `(1 + math.exp(-tau))**2` (:490) is a Python-float power too: OverflowError beyond sqrt(DBL_MAX)
   if (lane < M && (1.0 + ex) > 1.3407807929942596e154) pow_overflow = 1;
-  gtau = gTt * (prm.T_max - prm.T_min) * ex / ((1.0 + ex) * (1.0 + ex));
+  gtau = LG::sum_dims(gTt) * (prm.T_max - prm.T_min) * ex / ((1.0 + ex) * (1.0 + ex));  // (valid in the piece's first lane)
   return LG::any(pow_overflow) ? 4 : 0;
 }
 

@@ -7,14 +7,23 @@ namespace neo {
 template <int D, typename Real, class MapT, class LookupT>
 int launch_eval(neo_ctx *c, const MapT &map, const EvalArgs &a) {
   const dim3 grid(a.B), blk(kWave);
-#define NEO_EVAL(NS)                                                                                         \
-  hipLaunchKernelGGL((eval_kernel<D, NS, Real, MapT, LookupT>), grid, blk, 0, c->stream, a.B, a.M, c->dev, map, \
+#define NEO_EVAL_LG(NS, LG)                                                                                        \
+  hipLaunchKernelGGL((eval_kernel<D, NS, Real, MapT, LookupT, LG>), grid, blk, 0, c->stream, a.B, a.M, c->dev, map, \
                      a.x, a.head, a.tail, a.cost, a.costs4, a.grad, a.coeffs, a.status)
+  const bool pd = D * a.M <= kWave && !(c->params.flags & 512);  // lane = (piece, dimension), as in launch_opt
+#define NEO_EVAL(NS)                      \
+  do {                                    \
+    if (pd)                               \
+      NEO_EVAL_LG(NS, WaveLanesPD<D>);    \
+    else                                  \
+      NEO_EVAL_LG(NS, WaveLanes);         \
+  } while (0)
   switch (slots_for(a.M, D)) {
     case 1: NEO_EVAL(1); break;
     case 2: NEO_EVAL(2); break;
-    default: NEO_EVAL(4); break;
+    default: NEO_EVAL_LG(4, WaveLanes); break;
   }
+#undef NEO_EVAL_LG
 #undef NEO_EVAL
   return NEO_OK;
 }

@@ -28,13 +28,15 @@ namespace neo {
 
 // ------------------------------------------------------------------ device backend of the optimiser
 // SU: samples per lane in flight in the sample loop (minco_sample)
-template <int D, int NS, typename Real, class MapT, class LookupT, int SU = NEO_FUSED_U>
+// LG: lane layout of the PIECE-layout phases -- WaveLanes (lane = piece) or WaveLanesPD<D> (lane = (piece, dimension))
+template <int D, int NS, typename Real, class MapT, class LookupT, int SU = NEO_FUSED_U, class LG = WaveLanes>
 struct DevBackend {
+  static constexpr int DL = LG::dl(D);
   // FLAT layout with NS slots: n <= 64 * NS
   struct Vec {
     double v[NS];
   };
-  Traj<D> t;
+  Traj<D, DL> t;
   const DevParams &prm;
   const MapT &map;
   double *xs;    // LDS [256]: FLAT <-> PIECE staging
@@ -139,24 +141,27 @@ struct DevBackend {
       if (k * kWave + lane < t.n) xs[k * kWave + lane] = x.v[k];
     __syncthreads();
     const int M = t.M;
-    const bool act = lane < M;
-    t.tau = act ? xs[t.nq + lane] : 0.0;
+    const int p = LG::piece();
+    const bool act = p < M;
+    t.tau = act ? xs[t.nq + p] : 0.0;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      t.P0[d] = (lane == 0 || !act) ? t.head[d] : xs[d * (M - 1) + (lane > 0 ? lane - 1 : 0)];
-      t.P1[d] = (lane >= M - 1) ? t.tail[d] : xs[d * (M - 1) + lane];
+    for (int d = 0; d < DL; ++d) {
+      const int dg = LG::dim0() + d;  // the dimension: compile-time when the lane holds all of them
+      t.P0[d] = (p == 0 || !act) ? bstate<D, LG>(t.head, 0, d) : xs[dg * (M - 1) + (p > 0 ? p - 1 : 0)];
+      t.P1[d] = (p >= M - 1) ? bstate<D, LG>(t.tail, 0, d) : xs[dg * (M - 1) + p];
     }
   }
 
   // one evaluation of cost and gradient (get_cost + get_grad, :539-585)
   __device__ __forceinline__ int eval(const Vec &x, double &f, Vec &g, double *costs) {
     const int lane = lane_id();
+    const int p = LG::piece();
 #ifdef NEO_STAMPS
     const long long s0 = wall_clock64();
 #endif
     scatter_x(x);
     double energy, tsum;
-    const int st = minco_forward<D>(t, prm, energy, tsum);
+    const int st = minco_forward<D, LG>(t, prm, energy, tsum);
 #ifdef NEO_STAMPS
     const long long s1 = wall_clock64();
 #endif
@@ -166,29 +171,32 @@ struct DevBackend {
       for (int k = 0; k < 4; ++k) costs[k] = 0.0;
       return st;
     }
-    last_ns = wave_sum(lane < t.M ? t.ns : 0);
+    last_ns = wave_sum((p < t.M && LG::dim0() == 0) ? t.ns : 0);
     samples += (long long)last_ns;
-    if (coeff_out != nullptr && lane < t.M) {
+    if (coeff_out != nullptr && p < t.M) {
 #pragma unroll
       for (int k = 0; k < 6; ++k)
 #pragma unroll
-        for (int d = 0; d < D; ++d) coeff_out[(size_t)(6 * lane + k) * D + d] = t.c[k][d];
+        for (int d = 0; d < DL; ++d) coeff_out[(size_t)(6 * p + k) * D + LG::dim0() + d] = t.c[k][d];
     }
-    double gC[6][D], gT = 0.0, cf, ck;
+    double gC[6][DL], gT = 0.0, cf, ck;
     {
-      Real cr[6][D], gCr[6][D], gTr;
+      Real cr[6][DL], gCr[6][DL], gTr;
 #pragma unroll
       for (int k = 0; k < 6; ++k)
 #pragma unroll
-        for (int d = 0; d < D; ++d) cr[k][d] = (Real)t.c[k][d];
+        for (int d = 0; d < DL; ++d) cr[k][d] = (Real)t.c[k][d];
       LookupT lk(map);
-      // lanes in proportion to the pieces' sample counts (xs is free between scatter_x and the gradient gather)
-      const SampleLanes sl = balanced_sample_lanes(t.M, t.ns, reinterpret_cast<int *>(xs));
-      minco_sample<Real, D, LookupT, SU>(t.M, sl, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
+      // lanes in proportion to the pieces' sample counts (xs is free between scatter_x and the gradient gather);
+      // the assignment wants the sample count of piece l in lane l
+      int ns_by_piece = t.ns;
+      if constexpr (LG::S > 1) ns_by_piece = __shfl(t.ns, min(LG::S * lane, kWave - 1), kWave);
+      const SampleLanes sl = balanced_sample_lanes(t.M, ns_by_piece, reinterpret_cast<int *>(xs));
+      minco_sample<Real, D, LookupT, SU, false, LG>(t.M, sl, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
 #pragma unroll
       for (int k = 0; k < 6; ++k)
 #pragma unroll
-        for (int d = 0; d < D; ++d) gC[k][d] = (double)gCr[k][d];
+        for (int d = 0; d < DL; ++d) gC[k][d] = (double)gCr[k][d];
       gT = (double)gTr;
     }
 #ifdef NEO_STAMPS
@@ -199,16 +207,16 @@ struct DevBackend {
     costs[2] = uniform(cf);
     costs[3] = uniform(ck);
     f = costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3];
-    double gq[D], gtau;
-    const int bst = minco_backward<D>(t, prm, gC, gT, gq, gtau);
+    double gq[DL], gtau;
+    const int bst = minco_backward<D, LG>(t, prm, gC, gT, gq, gtau);
     if (bst != 0) return bst;
     // PIECE -> FLAT
     __syncthreads();
-    if (lane >= 1 && lane < t.M) {
+    if (p >= 1 && p < t.M) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) xs[d * (t.M - 1) + lane - 1] = gq[d];
+      for (int d = 0; d < DL; ++d) xs[(LG::dim0() + d) * (t.M - 1) + p - 1] = gq[d];
     }
-    if (lane < t.M) xs[t.nq + lane] = gtau;
+    if (p < t.M && LG::dim0() == 0) xs[t.nq + p] = gtau;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NS; ++k) g.v[k] = (k * kWave + lane < t.n) ? xs[k * kWave + lane] : 0.0;
@@ -223,8 +231,8 @@ struct DevBackend {
   }
 };
 
-template <int D>
-__device__ __forceinline__ void load_boundary(Traj<D> &t, const double *head, const double *tail, int M) {
+template <int D, int DL>
+__device__ __forceinline__ void load_boundary(Traj<D, DL> &t, const double *head, const double *tail, int M) {
   t.M = M;
   t.nq = D * (M - 1);
   t.n = t.nq + M;
@@ -238,7 +246,7 @@ struct MapTable {
 };
 
 // ------------------------------------------------------------------ kernels
-template <int D, int NS, typename Real, class MapT, class LookupT>
+template <int D, int NS, typename Real, class MapT, class LookupT, class LG = WaveLanes>
 __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm, MapT map,
                                                       const double *__restrict__ x,
                                                       const double *__restrict__ head,
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
   __shared__ double cst[12];
   const int b = blockIdx.x;
   if (b >= B) return;
-  using BE = DevBackend<D, NS, Real, MapT, LookupT>;
+  using BE = DevBackend<D, NS, Real, MapT, LookupT, NEO_FUSED_U, LG>;
   BE be(prm, map);
   be.xs = xs;
   be.sc = sc;
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
   be.cst = cst;
   be.hist = nullptr;
   be.m = NEO_LBFGS_M;
-  load_boundary<D>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
+  load_boundary(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
   const int n = be.t.n;
   be.npad = NS * kWave;
   be.coeff_out = coeffs ? coeffs + (size_t)b * 6 * M * D : nullptr;
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
 // spilled to scratch -- each evaluation is slower, but two trajectories share a SIMD's issue slots, which wins
 // once the batch queues for the 1024 SIMDs anyway (cfg2 with several batches in flight: +10 %).  Same
 // source, same arithmetic, bit-identical results.
-template <int D, int NS, typename Real, class MapT, class LookupT, int WAVES>
+template <int D, int NS, typename Real, class MapT, class LookupT, int WAVES, class LG = WaveLanes>
 __global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
                                                           const int *__restrict__ scene_slot, int nmaps,
                                                           double *__restrict__ x,
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, De
   const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
   // the two-waves variant has half the registers: two samples per lane in flight instead of four (with the lean
   // Horner form, cfg2 with three batches in flight: 414 k -> 541 k traj/s; scratch 640 -> 336 B per lane)
-  using BE = DevBackend<D, NS, Real, MapT, LookupT, (WAVES == 2 ? NEO_W2_U : NEO_FUSED_U)>;
+  using BE = DevBackend<D, NS, Real, MapT, LookupT, (WAVES == 2 ? NEO_W2_U : NEO_FUSED_U), LG>;
   // a slot outside the table (a stale or foreign slot array): the trajectory is left untouched and flagged
   const int slot = scene_slot ? scene_slot[b] : 0;
   if (slot < 0 || slot >= nmaps) {
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, De
   be.coeff_out = nullptr;
   be.trace = trace ? trace + (size_t)b * trace_cap * 4 : nullptr;
   be.trace_cap = trace_cap;
-  load_boundary<D>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
+  load_boundary(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
   const int n = be.t.n;
   be.npad = NS * kWave;
   extern __shared__ double dyn_lds[];  // 2 * maxcor * n doubles (launch parameter)

@@ -9,18 +9,30 @@ template <int D, typename Real, class MapT, class LookupT, int WAVES = 1>
 int launch_opt(neo_ctx *c, const OptArgs &a) {
   const dim3 grid(a.B), blk(kWave);
   const size_t dyn = (size_t)2 * NEO_LBFGS_M * (D * (a.M - 1) + a.M) * sizeof(double);  // L-BFGS pairs in LDS
-#define NEO_OPT(NS)                                                                                           \
-  hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES>), grid, blk, dyn, c->stream, a.B, a.M, c->dev, \
+#define NEO_OPT_LG(NS, LG)                                                                                    \
+  hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES, LG>), grid, blk, dyn, c->stream, a.B, a.M, c->dev, \
                      static_cast<const MapT *>(a.table), a.slots, a.nmaps, a.x, a.head, a.tail, a.costs4,      \
                      a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter,                                \
                      (c->order_B == a.B ? c->dispatch_order : nullptr), c->trace, c->trace_cap)
+  // lane = (piece, dimension) whenever D * M fits the wavefront (cfg2: 63 lanes busy in the PIECE-layout phases
+  // instead of 21, a third of the per-dimension state per lane); lane = piece otherwise.  flags bit 512 forces the
+  // latter (comparison runs).
+  const bool pd = D * a.M <= kWave && !(c->params.flags & 512);
+#define NEO_OPT(NS)                      \
+  do {                                   \
+    if (pd)                              \
+      NEO_OPT_LG(NS, WaveLanesPD<D>);    \
+    else                                 \
+      NEO_OPT_LG(NS, WaveLanes);         \
+  } while (0)
   switch (slots_for(a.M, D)) {
     case 1: NEO_OPT(1); break;
     case 2: NEO_OPT(2); break;
     default:
-      if constexpr (WAVES == 1 || NEO_W2_MAX_SLOTS >= 4) NEO_OPT(4);  // (two waves only up to NEO_W2_MAX_SLOTS)
+      if constexpr (WAVES == 1 || NEO_W2_MAX_SLOTS >= 4) NEO_OPT_LG(4, WaveLanes);  // (two waves only up to NEO_W2_MAX_SLOTS)
       break;
   }
+#undef NEO_OPT_LG
 #undef NEO_OPT
   return NEO_OK;
 }
