@@ -87,6 +87,7 @@ struct GroupBackend {
   __device__ __forceinline__ double sget(int i) const { return sc[i]; }
   __device__ __forceinline__ LineSearch &ls() { return *lsp; }
   __device__ __forceinline__ double *cost_store() { return cst; }
+  __device__ __forceinline__ void note_eval(int, int, double, double) {}  // (no trace in the lane-group kernel)
 
   // one evaluation (get_cost + get_grad, :539-585); costs into registers, nsamp = samples visited
   __device__ __forceinline__ int eval(const Vec &x, double &f, Vec &g, double (&costs)[4], int &nsamp) {

@@ -23,6 +23,7 @@
 #endif
 #include "neo_device.hpp"
 #include "neo_lbfgs.hpp"
+#include "neo_lbfgs_sm.hpp"
 
 namespace neo {
 
@@ -353,7 +354,23 @@ __global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, De
 #ifdef NEO_STAMPS
   const long long k0 = wall_clock64();
 #endif
+#ifdef NEO_OPT_SM
+  // the run as "evaluate, then advance" (neo_lbfgs_sm.hpp: the same arithmetic and decisions, bit for bit): ONE inlined
+  // copy of the evaluation instead of two
+  {
+    LbfgsMachine<BE> mach(be, o);
+    mach.x = xv;
+    mach.begin();
+    while (mach.need_eval()) {
+      const int est = be.eval(mach.x, mach.f, mach.g, mach.costs());
+      mach.advance(est);
+    }
+    mach.result(res);
+    xv = mach.x;
+  }
+#else
   lbfgs_minimize(be, xv, o, res);
+#endif
 #ifdef NEO_STAMPS
   if (lane == 0 && nsamples) {  // the counter buffer is [B][8] in this build
     long long *o8 = nsamples + (size_t)b * 8;

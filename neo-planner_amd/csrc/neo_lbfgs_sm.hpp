@@ -69,6 +69,7 @@ struct LbfgsMachine {
     int next;
     if (phase == PH_FIRST) {
       nfev++;
+      be.note_eval(nfev, 0, 0.0, f);
       for (int k = 0; k < 4; ++k) cur()[k] = costs()[k];
       if (est != 0) return finish(est);
       if (!(f - f == 0.0)) return finish(TERM_NONFINITE);
@@ -78,6 +79,7 @@ struct LbfgsMachine {
     } else {
       // an evaluation inside the line search
       nfev++;
+      be.note_eval(nfev, iter, stp, f);
       if (est != 0) {
         for (int k = 0; k < 4; ++k) cur()[k] = costs()[k];
         return finish(est);
