@@ -354,7 +354,7 @@ __global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, De
 #ifdef NEO_STAMPS
   const long long k0 = wall_clock64();
 #endif
-#ifdef NEO_OPT_SM
+#ifndef NEO_OPT_LOOP  // (-DNEO_OPT_LOOP: the straight-line form lbfgs_minimize, two inlined copies of the evaluation)
   // the run as "evaluate, then advance" (neo_lbfgs_sm.hpp: the same arithmetic and decisions, bit for bit): ONE inlined
   // copy of the evaluation instead of two
   {
