@@ -16,7 +16,10 @@
 #define NEO_FUSED_U (sizeof(Real) == 4 ? 4 : 2)
 #endif
 #ifndef NEO_W2_U
-#define NEO_W2_U 2
+#define NEO_W2_U 1  // (one sample per lane in flight: the two-waves variant then has no VGPR spills; 2 -> 7 % slower)
+#endif
+#ifndef NEO_W2_OCC
+#define NEO_W2_OCC 2  // wavefronts per SIMD the throughput variant is allocated for (experiments: 3)
 #endif
 #ifndef NEO_W2_MAX_SLOTS
 #define NEO_W2_MAX_SLOTS 2  // two waves per SIMD only up to n = 128 variables (M = 41: +5 % on an fp32 field, -2 % at cfg5)
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
 // once the batch queues for the 1024 SIMDs anyway (cfg2 with several batches in flight: +10 %).  Same
 // source, same arithmetic, bit-identical results.
 template <int D, int NS, typename Real, class MapT, class LookupT, int WAVES, class LG = WaveLanes>
-__global__ __launch_bounds__(kWave, WAVES) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
+__global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
                                                           const int *__restrict__ scene_slot, int nmaps,
                                                           double *__restrict__ x,
                                                           const double *__restrict__ head,

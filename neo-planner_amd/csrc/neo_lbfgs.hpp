@@ -65,7 +65,7 @@ NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpt
   using Vec = typename Backend::Vec;
   const double epsmch = 2.220446049250313e-16;
   const double big = 1.0e10;
-  Vec g, t, r, d, tmp;
+  Vec g, t, r, d, tmp, tmp2;
   double f = 0.0;
   double *costs = be.cost_store(), *cur = costs + 4, *old = costs + 8;
   int nfev = 0, nit = 0;
@@ -101,18 +101,18 @@ NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpt
       for (int k = col - 1; k >= 0; --k) {
         const int slot = (head + k) % o.m;
         be.hist_get_s(slot, tmp);
+        be.hist_get_y(slot, tmp2);  // (issued with the read of s: its latency hides behind the reduction)
         const double a = be.sget(slot) * be.dot(tmp, d);  // rho * s'q
         be.sput(o.m + slot, a);
-        be.hist_get_y(slot, tmp);
-        be.axpy(-a, tmp, d);
+        be.axpy(-a, tmp2, d);
       }
       be.scale(d, 1.0 / theta);
       for (int k = 0; k < col; ++k) {
         const int slot = (head + k) % o.m;
         be.hist_get_y(slot, tmp);
+        be.hist_get_s(slot, tmp2);
         const double b = be.sget(slot) * be.dot(tmp, d);
-        be.hist_get_s(slot, tmp);
-        be.axpy(be.sget(o.m + slot) - b, tmp, d);
+        be.axpy(be.sget(o.m + slot) - b, tmp2, d);
       }
       be.scale(d, -1.0);
     }

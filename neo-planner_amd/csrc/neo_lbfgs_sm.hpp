@@ -27,7 +27,7 @@ struct LbfgsMachine {
 
   Backend &be;
   LbfgsOpts o;
-  Vec x, g, t, r, d, tmp;
+  Vec x, g, t, r, d, tmp, tmp2;
   double f = 0.0, fold = 0.0, stp = 0.0, gd = 0.0, gdold = 0.0, theta = 1.0, stp_evaluated = -1.0;
   int nfev = 0, nit = 0, iter = 0, col = 0, head = 0, task = LS_START, ifun = 0;
   int phase = PH_FIRST, status = -1;
@@ -103,18 +103,18 @@ struct LbfgsMachine {
           for (int k = col - 1; k >= 0; --k) {
             const int slot = (head + k) % o.m;
             be.hist_get_s(slot, tmp);
+            be.hist_get_y(slot, tmp2);  // (issued with the read of s: its latency hides behind the reduction)
             const double a = be.sget(slot) * be.dot(tmp, d);  // rho * s'q
             be.sput(o.m + slot, a);
-            be.hist_get_y(slot, tmp);
-            be.axpy(-a, tmp, d);
+            be.axpy(-a, tmp2, d);
           }
           be.scale(d, 1.0 / theta);
           for (int k = 0; k < col; ++k) {
             const int slot = (head + k) % o.m;
             be.hist_get_y(slot, tmp);
+            be.hist_get_s(slot, tmp2);
             const double b = be.sget(slot) * be.dot(tmp, d);
-            be.hist_get_s(slot, tmp);
-            be.axpy(be.sget(o.m + slot) - b, tmp, d);
+            be.axpy(be.sget(o.m + slot) - b, tmp2, d);
           }
           be.scale(d, -1.0);
         }

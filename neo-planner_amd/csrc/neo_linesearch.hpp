@@ -175,21 +175,36 @@ NEO_HD int dcsrch(LineSearch &L, double f, double g, double &stp, int task) {
   if (f <= ftest && fabs(g) <= L.gtol * (-L.ginit)) out = LS_CONVERGENCE;
   if (out != LS_FG) return out;
 
-  if (L.stage == 1 && f <= L.fx && f > ftest) {
-    // modified function while the sufficient-decrease condition is not yet met
-    double fm = f - stp * L.gtest;
-    double fxm = L.fx - L.stx * L.gtest;
-    double fym = L.fy - L.sty * L.gtest;
-    double gm = g - L.gtest;
-    double gxm = L.gx - L.gtest;
-    double gym = L.gy - L.gtest;
-    dcstep(L.stx, fxm, gxm, L.sty, fym, gym, stp, fm, gm, L.brackt, L.stmin, L.stmax);
-    L.fx = fxm + L.stx * L.gtest;
-    L.fy = fym + L.sty * L.gtest;
-    L.gx = gxm + L.gtest;
-    L.gy = gym + L.gtest;
-  } else {
-    dcstep(L.stx, L.fx, L.gx, L.sty, L.fy, L.gy, stp, f, g, L.brackt, L.stmin, L.stmax);
+  // One call of dcstep on local copies (the two call sites of MINPACK-2 -- on the modified function while the
+  // sufficient-decrease condition is not yet met, on the function itself otherwise -- made the device compiler keep
+  // the interval in a private-memory array selected by pointer); the arithmetic of each case is unchanged.
+  {
+    const bool modified = L.stage == 1 && f <= L.fx && f > ftest;
+    double stx = L.stx, sty = L.sty, fx = L.fx, fy = L.fy, gx = L.gx, gy = L.gy;
+    double fp = f, gp = g;
+    int brackt = L.brackt;
+    if (modified) {
+      fp = f - stp * L.gtest;
+      fx = L.fx - L.stx * L.gtest;
+      fy = L.fy - L.sty * L.gtest;
+      gp = g - L.gtest;
+      gx = L.gx - L.gtest;
+      gy = L.gy - L.gtest;
+    }
+    dcstep(stx, fx, gx, sty, fy, gy, stp, fp, gp, brackt, L.stmin, L.stmax);
+    if (modified) {
+      fx = fx + stx * L.gtest;
+      fy = fy + sty * L.gtest;
+      gx = gx + L.gtest;
+      gy = gy + L.gtest;
+    }
+    L.stx = stx;
+    L.sty = sty;
+    L.fx = fx;
+    L.fy = fy;
+    L.gx = gx;
+    L.gy = gy;
+    L.brackt = brackt;
   }
   if (L.brackt) {
     if (fabs(L.sty - L.stx) >= 0.66 * L.width1) stp = L.stx + 0.5 * (L.sty - L.stx);
