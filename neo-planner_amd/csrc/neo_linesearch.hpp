@@ -35,8 +35,16 @@ struct LineSearch {
 NEO_HD double ls_max3(double a, double b, double c) { return fmax(fmax(a, b), c); }
 
 // safeguarded cubic/quadratic step; updates the interval [stx, sty] and stp
-NEO_HD void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy,
-                   double &stp, double fp, double dp, int &brackt, double stpmin, double stpmax) {
+struct StepInterval {
+  double stx, fx, dx, sty, fy, dy, stp;
+  int brackt;
+};
+
+// (the interval goes in and out BY VALUE: with reference parameters the device compiler kept it in a private-memory
+//  array -- the only scratch use of the optimiser kernels)
+NEO_HD StepInterval dcstep(const StepInterval in, double fp, double dp, double stpmin, double stpmax) {
+  double stx = in.stx, fx = in.fx, dx = in.dx, sty = in.sty, fy = in.fy, dy = in.dy, stp = in.stp;
+  int brackt = in.brackt;
   double gamma, p, q, r, s, stpc, stpf, stpq, theta;
   const double sgnd = dp * (dx / fabs(dx));
   if (fp > fx) {
@@ -138,6 +146,16 @@ NEO_HD void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy,
     dx = dp;
   }
   stp = stpf;
+  StepInterval out;
+  out.stx = stx;
+  out.fx = fx;
+  out.dx = dx;
+  out.sty = sty;
+  out.fy = fy;
+  out.dy = dy;
+  out.stp = stp;
+  out.brackt = brackt;
+  return out;
 }
 
 // one reverse-communication call.  task in: LS_START or LS_FG (f, g evaluated at stp);
@@ -191,7 +209,10 @@ NEO_HD int dcsrch(LineSearch &L, double f, double g, double &stp, int task) {
       gx = L.gx - L.gtest;
       gy = L.gy - L.gtest;
     }
-    dcstep(stx, fx, gx, sty, fy, gy, stp, fp, gp, brackt, L.stmin, L.stmax);
+    StepInterval iv;
+    iv.stx = stx; iv.fx = fx; iv.dx = gx; iv.sty = sty; iv.fy = fy; iv.dy = gy; iv.stp = stp; iv.brackt = brackt;
+    iv = dcstep(iv, fp, gp, L.stmin, L.stmax);
+    stx = iv.stx; fx = iv.fx; gx = iv.dx; sty = iv.sty; fy = iv.fy; gy = iv.dy; stp = iv.stp; brackt = iv.brackt;
     if (modified) {
       fx = fx + stx * L.gtest;
       fy = fy + sty * L.gtest;
