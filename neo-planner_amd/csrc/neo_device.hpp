@@ -59,6 +59,15 @@ struct Map3D {
 // ------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
 
+// Ordering of LDS traffic inside ONE wavefront (every workgroup of these kernels is a single wavefront): the LDS
+// executes a wavefront's DS instructions in issue order, so a read issued after a write sees it -- whichever lanes
+// wrote and read.  All that is needed is that the compiler keeps the order: a wavefront-scope fence and a scheduling
+// barrier, no s_barrier and no wait for every outstanding LDS operation as __syncthreads() would add.
+__device__ __forceinline__ void lds_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ double rdlane(double v, int src /*wave-uniform*/) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -614,16 +623,27 @@ __device__ __forceinline__ void thomas_factor(int M, const double (&Lo)[2][2], c
     const double h10 = dp * Di[1][0] - (Lo[1][0] * e00 + Lo[1][1] * e10);
     const double h11 = dp * Di[1][1] - (Lo[1][0] * e01 + Lo[1][1] * e11);
     const double det = h00 * h11 - h01 * h10;
-    const int ex = -__builtin_amdgcn_frexp_exp(det);
-    // adj(Dh) Up, scaled by dl_{p-1} and the power of two
-    const double g00 = dp * (h11 * Up[0][0] - h01 * Up[1][0]), g01 = dp * (h11 * Up[0][1] - h01 * Up[1][1]);
-    const double g10 = dp * (h00 * Up[1][0] - h10 * Up[0][0]), g11 = dp * (h00 * Up[1][1] - h10 * Up[0][1]);
+    // adj(Dh) Up, scaled by dl_{p-1} (and, every second joint, by the power of two: dl_p = dl_{p-1}^2 det(D_p) at most
+    // squares-and-multiplies by ~1e20 in one unscaled step even for durations of 10 ms, far inside the double range, and
+    // a power of two changes no bit of the quotients E = Eh / dl and N -- the loop-carried chain of every other step is
+    // 5 ldexp + 1 frexp shorter)
+    double g00 = dp * (h11 * Up[0][0] - h01 * Up[1][0]), g01 = dp * (h11 * Up[0][1] - h01 * Up[1][1]);
+    double g10 = dp * (h00 * Up[1][0] - h10 * Up[0][0]), g11 = dp * (h00 * Up[1][1] - h10 * Up[0][1]);
+    double dn = det;
+    if ((p & 1) == 0) {
+      const int ex = -__builtin_amdgcn_frexp_exp(det);
+      g00 = ldexp(g00, ex);
+      g01 = ldexp(g01, ex);
+      g10 = ldexp(g10, ex);
+      g11 = ldexp(g11, ex);
+      dn = ldexp(det, ex);
+    }
     if (lane == p) {
-      Eh[0][0] = ldexp(g00, ex);
-      Eh[0][1] = ldexp(g01, ex);
-      Eh[1][0] = ldexp(g10, ex);
-      Eh[1][1] = ldexp(g11, ex);
-      dl = ldexp(det, ex);
+      Eh[0][0] = g00;
+      Eh[0][1] = g01;
+      Eh[1][0] = g10;
+      Eh[1][1] = g11;
+      dl = dn;
       Dh[0][0] = h00; Dh[0][1] = h01; Dh[1][0] = h10; Dh[1][1] = h11;
       dprev = dp;
     }
@@ -984,11 +1004,11 @@ __device__ __forceinline__ SampleLanes balanced_sample_lanes(int M, int ns_piece
   const int incl = wave_scan_add(Lp);
   const int start = incl - Lp;
   seg[lane] = 0;
-  __syncthreads();
+  lds_wave_sync();
   if (Lp > 0) seg[start] = ((lane + 1) << 16) | (Lp << 8) | start;
-  __syncthreads();
+  lds_wave_sync();
   const int key = wave_scan_max_nonneg(seg[lane]);  // the segment this lane falls in: the last start at or before it
-  __syncthreads();                                  // (seg is the caller's staging buffer again after this)
+  lds_wave_sync();                                  // (seg is the caller's staging buffer again after this)
   SampleLanes sl;
   sl.piece = max((key >> 16) - 1, 0);
   sl.L = max((key >> 8) & 0xff, 1);

@@ -71,7 +71,7 @@ struct GroupBackend {
         hist[slot * t.n + k * W + gl] = s.v[k];
         hist[(m + slot) * t.n + k * W + gl] = y.v[k];
       }
-    __syncthreads();
+    lds_wave_sync();
   }
   __device__ __forceinline__ void hist_get(int row, Vec &v) const {
     const int gl = GroupLanes<W>::lane();
@@ -82,22 +82,23 @@ struct GroupBackend {
   __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
   __device__ __forceinline__ void sput(int i, double v) {
     sc[i] = v;
-    __syncthreads();
+    lds_wave_sync();
   }
   __device__ __forceinline__ double sget(int i) const { return sc[i]; }
   __device__ __forceinline__ LineSearch &ls() { return *lsp; }
   __device__ __forceinline__ double *cost_store() { return cst; }
   __device__ __forceinline__ void note_eval(int, int, double, double) {}  // (no trace in the lane-group kernel)
+  __device__ __forceinline__ void sm_stamp(int) {}
 
   // one evaluation (get_cost + get_grad, :539-585); costs into registers, nsamp = samples visited
   __device__ __forceinline__ int eval(const Vec &x, double &f, Vec &g, double (&costs)[4], int &nsamp) {
     const int lane = GroupLanes<W>::lane();
     const int M = t.M;
-    __syncthreads();
+    lds_wave_sync();
 #pragma unroll
     for (int k = 0; k < NS; ++k)
       if (k * W + lane < t.n) xs[k * W + lane] = x.v[k];
-    __syncthreads();
+    lds_wave_sync();
     const bool act = lane < M;
     t.tau = act ? xs[t.nq + lane] : 0.0;
 #pragma unroll
@@ -134,13 +135,13 @@ struct GroupBackend {
     f = costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3];
     double gq[D], gtau;
     const int bst = minco_backward<D, GroupLanes<W>>(t, prm, gC, gT, gq, gtau);
-    __syncthreads();
+    lds_wave_sync();
     if (lane >= 1 && lane < M) {
 #pragma unroll
       for (int d = 0; d < D; ++d) xs[d * (M - 1) + lane - 1] = gq[d];
     }
     if (lane < M) xs[t.nq + lane] = gtau;
-    __syncthreads();
+    lds_wave_sync();
 #pragma unroll
     for (int k = 0; k < NS; ++k) g.v[k] = (k * W + lane < t.n) ? xs[k * W + lane] : 0.0;
     if (st != 0) {

@@ -26,6 +26,9 @@
 #endif
 #include "neo_device.hpp"
 #include "neo_lbfgs.hpp"
+#ifdef NEO_STAMPS
+#define NEO_SM_STAMP(i) be.sm_stamp(i)
+#endif
 #include "neo_lbfgs_sm.hpp"
 
 namespace neo {
@@ -56,6 +59,10 @@ struct DevBackend {
   int trace_cap = 0;
 #ifdef NEO_STAMPS  // timing experiments (tools/gpu_straggler.py): 100 MHz wall-clock ticks per phase
   long long tk[4] = {0, 0, 0, 0};  // forward, sample, backward, evaluations
+  long long tl = 0, tl0 = 0;       // two-loop recursion (direction) time
+  __device__ __forceinline__ void sm_stamp(int i) {
+    if (i == 0) tl0 = wall_clock64(); else tl += wall_clock64() - tl0;
+  }
 #endif
 
   __device__ DevBackend(const DevParams &p, const MapT &mp) : prm(p), map(mp) {}
@@ -100,7 +107,7 @@ struct DevBackend {
         hist[slot * t.n + k * kWave + lane] = s.v[k];
         hist[(m + slot) * t.n + k * kWave + lane] = y.v[k];
       }
-    __syncthreads();
+    lds_wave_sync();
   }
   __device__ __forceinline__ void hist_get(int row, Vec &v) const {
     const int lane = lane_id();
@@ -109,11 +116,11 @@ struct DevBackend {
   }
   __device__ __forceinline__ void hist_get_s(int slot, Vec &v) const { hist_get(slot, v); }
   __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
-  __device__ __forceinline__ void sput(int i, double v) {
-    sc[i] = v;
-    __syncthreads();
-  }
-  __device__ __forceinline__ double sget(int i) const { return sc[i]; }
+  // the 2m wave-uniform scalars of the two-loop recursion (rho, alpha): entry i lives in lane i of one register
+  // pair, written with a select and read back with v_readlane -- no LDS round trip on the recursion's dependent chain
+  double sreg = 0.0;
+  __device__ __forceinline__ void sput(int i, double v) { sreg = (lane_id() == i) ? v : sreg; }
+  __device__ __forceinline__ double sget(int i) const { return rdlane(sreg, i); }
 #ifndef NEO_LS_IN_REGS  // measured: LDS is faster (registers spill: 14.0 vs 15.5 ms at cfg2)
   __device__ __forceinline__ LineSearch &ls() { return *lsp; }
   __device__ __forceinline__ double *cost_store() { return cst; }
@@ -139,11 +146,11 @@ struct DevBackend {
   // FLAT x -> PIECE inputs
   __device__ __forceinline__ void scatter_x(const Vec &x) {
     const int lane = lane_id();
-    __syncthreads();
+    lds_wave_sync();
 #pragma unroll
     for (int k = 0; k < NS; ++k)
       if (k * kWave + lane < t.n) xs[k * kWave + lane] = x.v[k];
-    __syncthreads();
+    lds_wave_sync();
     const int M = t.M;
     const int p = LG::piece();
     const bool act = p < M;
@@ -215,13 +222,13 @@ struct DevBackend {
     const int bst = minco_backward<D, LG>(t, prm, gC, gT, gq, gtau);
     if (bst != 0) return bst;
     // PIECE -> FLAT
-    __syncthreads();
+    lds_wave_sync();
     if (p >= 1 && p < t.M) {
 #pragma unroll
       for (int d = 0; d < DL; ++d) xs[(LG::dim0() + d) * (t.M - 1) + p - 1] = gq[d];
     }
     if (p < t.M && LG::dim0() == 0) xs[t.nq + p] = gtau;
-    __syncthreads();
+    lds_wave_sync();
 #pragma unroll
     for (int k = 0; k < NS; ++k) g.v[k] = (k * kWave + lane < t.n) ? xs[k * kWave + lane] : 0.0;
 #ifdef NEO_STAMPS
@@ -357,10 +364,11 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
 #ifdef NEO_STAMPS
   const long long k0 = wall_clock64();
 #endif
-#ifndef NEO_OPT_LOOP  // (-DNEO_OPT_LOOP: the straight-line form lbfgs_minimize, two inlined copies of the evaluation)
-  // the run as "evaluate, then advance" (neo_lbfgs_sm.hpp: the same arithmetic and decisions, bit for bit): ONE inlined
-  // copy of the evaluation instead of two
-  {
+  // n <= 128: the run as "evaluate, then advance" (neo_lbfgs_sm.hpp: the same arithmetic and decisions as
+  // lbfgs_minimize) -- ONE inlined copy of the evaluation instead of two: 36 % less code and no spills in the cfg2
+  // two-waves kernel.  Four FLAT slots (n > 128, cfg5): the compiler keeps the machine's vectors in private memory
+  // (1 KB of scratch, 3x slower), so those instantiations run the straight-line form.
+  if constexpr (NS <= 2) {
     LbfgsMachine<BE> mach(be, o);
     mach.x = xv;
     mach.begin();
@@ -370,15 +378,14 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
     }
     mach.result(res);
     xv = mach.x;
+  } else {
+    lbfgs_minimize(be, xv, o, res);
   }
-#else
-  lbfgs_minimize(be, xv, o, res);
-#endif
 #ifdef NEO_STAMPS
   if (lane == 0 && nsamples) {  // the counter buffer is [B][8] in this build
     long long *o8 = nsamples + (size_t)b * 8;
     o8[1] = be.tk[3]; o8[2] = be.tk[0]; o8[3] = be.tk[1]; o8[4] = be.tk[2];
-    o8[5] = wall_clock64() - k0; o8[6] = k0; o8[7] = blockIdx.x;
+    o8[5] = wall_clock64() - k0; o8[6] = k0; o8[7] = be.tl;  // (7: two-loop time; was the dispatch slot)
     o8[0] = be.samples;
   }
   nsamples = nullptr;

@@ -16,6 +16,9 @@
 // every round is "evaluate, then advance" for all of them.
 #pragma once
 #include "neo_lbfgs.hpp"
+#ifndef NEO_SM_STAMP  // timing experiments only (NEO_STAMPS builds of the device kernels define it)
+#define NEO_SM_STAMP(i)
+#endif
 
 namespace neo {
 
@@ -96,6 +99,7 @@ struct LbfgsMachine {
     while (next != DO_RETURN) {
       if (next == DO_START_ITER) {
         // ---- search direction
+        NEO_SM_STAMP(0);
         if (col == 0) {
           be.neg(d, g);
         } else {
@@ -118,6 +122,7 @@ struct LbfgsMachine {
           }
           be.scale(d, -1.0);
         }
+        NEO_SM_STAMP(1);
         // ---- line search set-up (lnsrlb)
         be.copy(t, x);
         be.copy(r, g);

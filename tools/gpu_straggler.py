@@ -42,7 +42,8 @@ def row(sel, name):
     e = ev[sel].sum()
     f, s_, b_ = c[sel, 2].sum() * tick / e, c[sel, 3].sum() * tick / e, c[sel, 4].sum() * tick / e
     t = tot[sel].sum() / e
-    print(f"{name:<28} n={sel.sum():5d}  per evaluation: total {t:6.2f} us = forward {f:5.2f} + sample {s_:5.2f} + backward {b_:5.2f} + optimiser {t - f - s_ - b_:5.2f};"
+    tl_ = c[sel, 7].sum() * tick / e
+    print(f"{name:<28} n={sel.sum():5d}  per evaluation: total {t:6.2f} us = forward {f:5.2f} + sample {s_:5.2f} + backward {b_:5.2f} + optimiser {t - f - s_ - b_:5.2f} (of which two-loop {tl_:5.2f});"
           f"  samples/eval {c[sel, 0].sum() / e:6.1f}")
 row(np.ones(B, bool), "all runs")
 idx = np.argsort(-tot)
@@ -51,7 +52,7 @@ for k in (1, 8, 64):
     row(sel, f"longest {k}")
     if k == 8:
         for i in idx[:8]:
-            print(f"    traj {i}: dispatch slot {int(c[i, 7])}, start {start[i]:7.0f} us, duration {tot[i]:7.0f} us, {int(ev[i])} evaluations, status {int(status[i]) & 0xff}")
+            print(f"    traj {i}: start {start[i]:7.0f} us, duration {tot[i]:7.0f} us, {int(ev[i])} evaluations, status {int(status[i]) & 0xff}")
 late = start + tot
 sel = np.zeros(B, bool); sel[np.argsort(-late)[:8]] = True
 row(sel, "last 8 to finish")
