@@ -197,7 +197,17 @@ struct DevBackend {
       for (int k = 0; k < 6; ++k)
 #pragma unroll
         for (int d = 0; d < DL; ++d) cr[k][d] = (Real)t.c[k][d];
+#ifdef NEO_STAMPS
+      // timing experiment (flags bit 1024): a buffer descriptor with zero records -- the range check drops every gather
+      // (it returns 0 without touching memory) while the instruction stream stays: what the sample loop costs without
+      // its memory latency
+      MapT map_t = map;
+      if constexpr (sizeof(MapT) == sizeof(Map3D))
+        if (prm.dbg & 1024) map_t.bytes = 0;
+      LookupT lk(map_t);
+#else
       LookupT lk(map);
+#endif
       // lanes in proportion to the pieces' sample counts (xs is free between scatter_x and the gradient gather);
       // the assignment wants the sample count of piece l in lane l
       int ns_by_piece = t.ns;
