@@ -116,6 +116,78 @@ struct DevBackend {
   }
   __device__ __forceinline__ void hist_get_s(int slot, Vec &v) const { hist_get(slot, v); }
   __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
+  // ---- compact-representation direction (neo_lbfgs_dir.hpp, fp32-sampling kernels): vectors with one entry per
+  // history slot live in lane `slot` of a register pair; S'Y and Y'Y (m x m each) in LDS
+  struct SVec {
+    double v;
+  };
+  double *mats = nullptr;  // LDS [2][m][m]
+  __device__ __forceinline__ double sv_get(const SVec &a, int k) const { return rdlane(a.v, k); }
+  __device__ __forceinline__ void sv_set(SVec &a, int k, double x) const { a.v = (lane_id() == k) ? x : a.v; }
+  __device__ __forceinline__ void sv_scale(SVec &a, double s_) const { a.v *= s_; }
+  // ps[k] = s_k . v, py[k] = y_k . v for all m slots: 2m INDEPENDENT dot products (slots that hold no pair yet give
+  // garbage in their lanes, which every consumer masks by the chronological index)
+  __device__ __forceinline__ void hist_dots(const Vec &v, SVec &ps, SVec &py) const {
+    const int lane = lane_id();
+    ps.v = 0.0;
+    py.v = 0.0;
+#pragma unroll
+    for (int k = 0; k < NEO_LBFGS_M; ++k) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const bool in = q * kWave + lane < t.n;
+        const double sv = in ? hist[k * t.n + q * kWave + lane] : 0.0;
+        const double yv = in ? hist[(m + k) * t.n + q * kWave + lane] : 0.0;
+        a += sv * v.v[q];
+        b += yv * v.v[q];
+      }
+      const double ta = wave_sum(a), tb = wave_sum(b);
+      ps.v = (lane == k) ? ta : ps.v;
+      py.v = (lane == k) ? tb : py.v;
+    }
+  }
+  __device__ __forceinline__ void mat_put_col(int slot, const SVec &sy, const SVec &yy) {
+    const int lane = lane_id();
+    if (lane < NEO_LBFGS_M) {
+      mats[lane * NEO_LBFGS_M + slot] = sy.v;
+      mats[NEO_LBFGS_M * NEO_LBFGS_M + lane * NEO_LBFGS_M + slot] = yy.v;
+      mats[NEO_LBFGS_M * NEO_LBFGS_M + slot * NEO_LBFGS_M + lane] = yy.v;
+    }
+    lds_wave_sync();
+  }
+  __device__ __forceinline__ void sv_init_w(SVec &w, const SVec &u, const SVec &b, double gamma) const {
+    const int lane = lane_id();
+    const double dii = lane < NEO_LBFGS_M ? mats[lane * NEO_LBFGS_M + lane] : 0.0;
+    w.v = dii * u.v - gamma * b.v;
+  }
+  __device__ __forceinline__ void sv_axpy_mat(SVec &u, double coef, int which, int j, int lo, int hi, int head) const {
+    const int lane = lane_id();
+    const int i = lane < NEO_LBFGS_M ? lane : 0;
+    int li = i - head;
+    li += li < 0 ? NEO_LBFGS_M : 0;  // chronological index of slot i
+    const bool on = lane < NEO_LBFGS_M && li >= lo && li < hi;
+    const int idx = which == 0 ? i * NEO_LBFGS_M + j
+                               : (which == 1 ? j * NEO_LBFGS_M + i : NEO_LBFGS_M * NEO_LBFGS_M + i * NEO_LBFGS_M + j);
+    const double mv = mats[idx];
+    u.v = on ? u.v + coef * mv : u.v;
+  }
+  __device__ __forceinline__ void hist_combine(Vec &d, const SVec &cs, const SVec &cy, int col, int head) const {
+    const int lane = lane_id();
+    for (int kk = 0; kk < col; ++kk) {
+      int k = head + kk;
+      k -= k >= m ? m : 0;
+      const double a = rdlane(cs.v, k), b = rdlane(cy.v, k);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const bool in = q * kWave + lane < t.n;
+        const double sv = in ? hist[k * t.n + q * kWave + lane] : 0.0;
+        const double yv = in ? hist[(m + k) * t.n + q * kWave + lane] : 0.0;
+        d.v[q] += a * sv + b * yv;
+      }
+    }
+  }
+
   // the 2m wave-uniform scalars of the two-loop recursion (rho, alpha): entry i lives in lane i of one register
   // pair, written with a select and read back with v_readlane -- no LDS round trip on the recursion's dependent chain
   double sreg = 0.0;
@@ -329,10 +401,14 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
                                                           long long *__restrict__ nsamples,
                                                           const int *__restrict__ order, double *__restrict__ trace,
                                                           int trace_cap) {
+  // fp32 sampling (the throughput mode): compact-representation direction, its two m x m matrices in LDS;
+  // fp64 sampling (the parity mode): the two-loop recursion that is pinned to SciPy's iterates (neo_lbfgs_dir.hpp)
+  constexpr bool kCompact = sizeof(Real) == 4;
   __shared__ double xs[NS * kWave];
   __shared__ double sc[2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm;
   __shared__ double cst[12];
+  __shared__ double mats[kCompact ? 2 * NEO_LBFGS_M * NEO_LBFGS_M : 1];
   if ((int)blockIdx.x >= B) return;
   // workgroups are dispatched in index order: `order` lets the caller start the runs it expects to
   // be long first (list scheduling: a long run that starts last sets the duration of the launch)
@@ -357,6 +433,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
   be.lsp = &lsm;
   be.cst = cst;
   be.m = NEO_LBFGS_M;
+  be.mats = mats;
   be.coeff_out = nullptr;
   be.trace = trace ? trace + (size_t)b * trace_cap * 4 : nullptr;
   be.trace_cap = trace_cap;
@@ -379,7 +456,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
   // two-waves kernel.  Four FLAT slots (n > 128, cfg5): the compiler keeps the machine's vectors in private memory
   // (1 KB of scratch, 3x slower), so those instantiations run the straight-line form.
   if constexpr (NS <= 2) {
-    LbfgsMachine<BE> mach(be, o);
+    LbfgsMachine<BE, kCompact> mach(be, o);
     mach.x = xv;
     mach.begin();
     while (mach.need_eval()) {
@@ -389,7 +466,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
     mach.result(res);
     xv = mach.x;
   } else {
-    lbfgs_minimize(be, xv, o, res);
+    lbfgs_minimize<BE, kCompact>(be, xv, o, res);
   }
 #ifdef NEO_STAMPS
   if (lane == 0 && nsamples) {  // the counter buffer is [B][8] in this build

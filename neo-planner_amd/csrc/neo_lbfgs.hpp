@@ -20,6 +20,7 @@
 // wavefront-cooperative vectors (neo_kernels.hpp), the host test harness plain arrays.
 #pragma once
 #include "neo_linesearch.hpp"
+#include "neo_lbfgs_dir.hpp"
 
 namespace neo {
 
@@ -59,7 +60,7 @@ struct LbfgsResult {
 //   int  eval(const Vec& x, double& f, Vec& g, double* costs4);   0 = ok
 //   void note_eval(int nfev, int iter, double stp, double f);     diagnostics hook after every counted evaluation
 //       (a no-op in the product unless a trace buffer was given: neo_optimize_trace)
-template <class Backend>
+template <class Backend, bool COMPACT = false>
 NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpts &o,
                            LbfgsResult &res) {
   using Vec = typename Backend::Vec;
@@ -94,28 +95,7 @@ NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpt
 
   for (;;) {
     // ---- search direction
-    if (col == 0) {
-      be.neg(d, g);
-    } else {
-      be.copy(d, g);  // d plays q of the two-loop recursion
-      for (int k = col - 1; k >= 0; --k) {
-        const int slot = (head + k) % o.m;
-        be.hist_get_s(slot, tmp);
-        be.hist_get_y(slot, tmp2);  // (issued with the read of s: its latency hides behind the reduction)
-        const double a = be.sget(slot) * be.dot(tmp, d);  // rho * s'q
-        be.sput(o.m + slot, a);
-        be.axpy(-a, tmp2, d);
-      }
-      be.scale(d, 1.0 / theta);
-      for (int k = 0; k < col; ++k) {
-        const int slot = (head + k) % o.m;
-        be.hist_get_y(slot, tmp);
-        be.hist_get_s(slot, tmp2);
-        const double b = be.sget(slot) * be.dot(tmp, d);
-        be.axpy(be.sget(o.m + slot) - b, tmp2, d);
-      }
-      be.scale(d, -1.0);
-    }
+    lbfgs_direction<COMPACT>(be, g, d, tmp, tmp2, col, head, o.m, theta);
 
     // ---- line search (lnsrlb)
     be.copy(t, x);
@@ -224,6 +204,7 @@ NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpt
     be.hist_put(slot, d, r);
     be.sput(slot, 1.0 / dr);
     theta = rr / dr;
+    lbfgs_pair_stored<COMPACT>(be, slot, r);
   }
 }
 

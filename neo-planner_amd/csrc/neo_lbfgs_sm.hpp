@@ -22,7 +22,7 @@
 
 namespace neo {
 
-template <class Backend>
+template <class Backend, bool COMPACT = false>
 struct LbfgsMachine {
   using Vec = typename Backend::Vec;
   enum : int { PH_FIRST = 0, PH_LS = 1, PH_DONE = 2 };
@@ -100,28 +100,7 @@ struct LbfgsMachine {
       if (next == DO_START_ITER) {
         // ---- search direction
         NEO_SM_STAMP(0);
-        if (col == 0) {
-          be.neg(d, g);
-        } else {
-          be.copy(d, g);  // d plays q of the two-loop recursion
-          for (int k = col - 1; k >= 0; --k) {
-            const int slot = (head + k) % o.m;
-            be.hist_get_s(slot, tmp);
-            be.hist_get_y(slot, tmp2);  // (issued with the read of s: its latency hides behind the reduction)
-            const double a = be.sget(slot) * be.dot(tmp, d);  // rho * s'q
-            be.sput(o.m + slot, a);
-            be.axpy(-a, tmp2, d);
-          }
-          be.scale(d, 1.0 / theta);
-          for (int k = 0; k < col; ++k) {
-            const int slot = (head + k) % o.m;
-            be.hist_get_y(slot, tmp);
-            be.hist_get_s(slot, tmp2);
-            const double b = be.sget(slot) * be.dot(tmp, d);
-            be.axpy(be.sget(o.m + slot) - b, tmp2, d);
-          }
-          be.scale(d, -1.0);
-        }
+        lbfgs_direction<COMPACT>(be, g, d, tmp, tmp2, col, head, o.m, theta);
         NEO_SM_STAMP(1);
         // ---- line search set-up (lnsrlb)
         be.copy(t, x);
@@ -214,6 +193,7 @@ struct LbfgsMachine {
         be.hist_put(slot, d, r);
         be.sput(slot, 1.0 / dr);
         theta = rr / dr;
+        lbfgs_pair_stored<COMPACT>(be, slot, r);
       }
     }
   }

@@ -193,3 +193,30 @@ def test_state_machine_form_is_the_same_run(lib):
             assert all(np.array_equal(p[0], q[0]) for p, q in zip(a["evals"], b["evals"]))
             n_runs += 1
     assert n_runs >= 30
+
+
+def test_compact_direction_is_the_same_optimiser(lib):
+    """csrc/neo_lbfgs_dir.hpp: the compact-representation direction (what the fp32-sampling kernels run) against the
+    two-loop recursion on every recorded objective: the trial points agree to round-off for as long as the run is not
+    steered by it -- most runs are identical to the end (same nit / nfev / status, x to 1e-7), every run ends at a
+    point of the same quality; its state-machine form is the same run bit for bit."""
+    n_runs = n_same = 0
+    for path in golden("g3_trace_*.npz"):
+        d = load(path)
+        for r in range(int(d["n_runs"])):
+            x0 = d[f"r{r}_x0"]
+            M = (len(x0) + 2) // 3
+            _, fgc = _oracle_objective(d, x0[:2 * (M - 1)].reshape(2, M - 1), np.zeros(M))
+            a = host_minimize(lib, x0, fgc)
+            b = host_minimize(lib, x0, fgc, entry="lbfgs_host_minimize_compact")
+            c = host_minimize(lib, x0, fgc, entry="lbfgs_host_minimize_sm_compact")
+            assert (b["nit"], b["nfev"], b["status"]) == (c["nit"], c["nfev"], c["status"]) and np.array_equal(b["x"], c["x"])
+            k = min(len(a["evals"]), len(b["evals"]), 12)
+            for i in range(k):      # the first trial points: round-off apart
+                assert np.abs(a["evals"][i][0] - b["evals"][i][0]).max() <= 1e-10 * max(np.abs(a["evals"][i][0]).max(), 1.0)
+            same = (a["nit"], a["nfev"], a["status"]) == (b["nit"], b["nfev"], b["status"])
+            if same:
+                assert rel_err(b["x"], a["x"]) < 1e-7
+            n_runs += 1
+            n_same += same
+    assert n_runs >= 30 and n_same >= 0.85 * n_runs, (n_same, n_runs)
