@@ -80,10 +80,15 @@ __device__ __forceinline__ double uniform(double v) {
 }
 // ---- DPP cross-lane moves (no LDS round trip).  ctrl: 0x110+n = row_shr:n (lane i <- lane i-n inside
 // its row of 16), 0x142 / 0x143 = row_bcast:15 / row_bcast:31, 0x130 / 0x138 = wave_shl:1 / wave_shr:1.
-// Lanes without a valid source (or masked off by row_mask) receive 0.
+// Lanes without a valid source (or masked off by row_mask) receive 0.  With every row enabled that is the
+// instruction's own bound_ctrl zero fill: no register has to be preset to 0 ahead of each move (two v_mov_b32 per
+// fp64 step, 8 of the 34 instructions of a wave_sum); with a row mask the masked rows keep `old`, which must be the 0.
+#ifndef NEO_DPP_ZERO_FILL
+#define NEO_DPP_ZERO_FILL 1
+#endif
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ int dpp_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf && NEO_DPP_ZERO_FILL);
 }
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp_f(float v) {
@@ -124,6 +129,41 @@ __device__ __forceinline__ int wave_sum(int v) {
   v += dpp_i<0x143, 0xc>(v);
   return __builtin_amdgcn_readlane(v, 63);
 }
+// Four wave-wide sums for little more than the price of one: the four per-lane values are first folded onto one
+// register -- v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-waves and odd/even rows of two registers, so
+// two adds leave the 64 partials of value k on the 16 lanes of row k -- then ONE row-wise DPP scan finishes all four
+// (lane 15 of row k holds the total of value k).  One dependent chain of 7 additions instead of four of 6, 37
+// instructions instead of 80; fixed association order.
+__device__ __forceinline__ void swap_half_waves(double &x, double &y) {  // lanes 32..63 of x <-> lanes 0..31 of y
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  x = __hiloint2double((int)hi[0], (int)lo[0]);
+  y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void swap_odd_even_rows(double &x, double &y) {  // odd rows of x <-> even rows of y
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  x = __hiloint2double((int)hi[0], (int)lo[0]);
+  y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void wave_sum4(double a, double b, double c, double d, double &ta, double &tb, double &tc,
+                                          double &td) {
+  swap_half_waves(a, c);
+  double x = a + c;  // lanes 0..31: a folded to 32 values, lanes 32..63: c
+  swap_half_waves(b, d);
+  double y = b + d;
+  swap_odd_even_rows(x, y);
+  double z = x + y;  // row 0: a, row 1: b, row 2: c, row 3: d (16 partials each)
+  z += dpp_d<0x111>(z);
+  z += dpp_d<0x112>(z);
+  z += dpp_d<0x114>(z);
+  z += dpp_d<0x118>(z);
+  ta = rdlane(z, 15);
+  tb = rdlane(z, 31);
+  tc = rdlane(z, 47);
+  td = rdlane(z, 63);
+}
+
 // inclusive prefix sum / prefix maximum over the lanes of the wavefront (non-negative ints; the same DPP sequence as
 // wave_sum, which is that scan read at lane 63)
 __device__ __forceinline__ int wave_scan_add(int v) {
@@ -606,52 +646,39 @@ struct Traj {
 template <class LG = WaveLanes>
 __device__ __forceinline__ void thomas_factor(int M, const double (&Lo)[2][2], const double (&Di)[2][2],
                                               const double (&Up)[2][2], double (&N)[2][2], double (&E)[2][2]) {
-  // The recurrence E_p = (Di_p - Lo_p E_{p-1})^-1 Up_p is carried as a fraction E = Eh / dl so that the
-  // loop-carried chain holds no division:  Dh = dl_{p-1} Di_p - Lo_p Eh_{p-1} (= dl_{p-1} D_p),
-  // Eh_p = s dl_{p-1} adj(Dh) Up_p,  dl_p = s det(Dh),  s = a power of two that brings dl_p to
-  // [0.5, 1) so nothing over/underflows.  Each lane keeps its own Dh and dl_{p-1} and forms
-  // N_p = dl_{p-1} adj(Dh)/det(Dh) and E_p = Eh_p/dl_p after the loop, all lanes in parallel.
+  // One step per joint: lane p forms D_p = Di_p - Lo_p E_{p-1}, inverts it and keeps N_p = D_p^-1, E_p = N_p Up_p.
+  // The optimiser kernels run two wavefronts per SIMD and are bound by instruction issue more than by the length of
+  // this chain, so the step is written for the fewest instructions: the reciprocal of the determinant is v_rcp_f64
+  // with two Newton steps (5 instructions, relative error below 2^-52; a correctly rounded division is 12), everything
+  // is computed by lane p under its own exec mask straight into N and E, and only E travels to the next lane (8
+  // v_readlane).  35 instructions a joint; carrying E as a fraction to keep the division out of the chain (the
+  // round-1 form) cost 52 and two divisions after the loop.
   const int lane = LG::piece();  // (every lane of a piece computes the same factors)
-  double Eh[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, dl = 1.0;  // lane 0: E_0 = 0
-  double Dh[2][2] = {{1.0, 0.0}, {0.0, 1.0}}, dprev = 1.0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) N[i][j] = E[i][j] = 0.0;  // lane 0: E_0 = 0; lanes outside 1..M-1 stay 0
   for (int p = 1; p < M; ++p) {
-    const double e00 = LG::read(Eh[0][0], p - 1), e01 = LG::read(Eh[0][1], p - 1);
-    const double e10 = LG::read(Eh[1][0], p - 1), e11 = LG::read(Eh[1][1], p - 1);
-    const double dp = LG::read(dl, p - 1);
-    const double h00 = dp * Di[0][0] - (Lo[0][0] * e00 + Lo[0][1] * e10);
-    const double h01 = dp * Di[0][1] - (Lo[0][0] * e01 + Lo[0][1] * e11);
-    const double h10 = dp * Di[1][0] - (Lo[1][0] * e00 + Lo[1][1] * e10);
-    const double h11 = dp * Di[1][1] - (Lo[1][0] * e01 + Lo[1][1] * e11);
-    const double det = h00 * h11 - h01 * h10;
-    const int ex = -__builtin_amdgcn_frexp_exp(det);
-    // adj(Dh) Up, scaled by dl_{p-1} and the power of two
-    // (rescaling only every second joint -- exact, a power of two changes no bit of the quotients -- was measured: the
-    //  uniform branch in this sequential loop costs more than the five ldexp it saves, 6.7 -> 7.6 us per forward pass)
-    const double g00 = dp * (h11 * Up[0][0] - h01 * Up[1][0]), g01 = dp * (h11 * Up[0][1] - h01 * Up[1][1]);
-    const double g10 = dp * (h00 * Up[1][0] - h10 * Up[0][0]), g11 = dp * (h00 * Up[1][1] - h10 * Up[0][1]);
+    const double e00 = LG::read(E[0][0], p - 1), e01 = LG::read(E[0][1], p - 1);
+    const double e10 = LG::read(E[1][0], p - 1), e11 = LG::read(E[1][1], p - 1);
     if (lane == p) {
-      Eh[0][0] = ldexp(g00, ex);
-      Eh[0][1] = ldexp(g01, ex);
-      Eh[1][0] = ldexp(g10, ex);
-      Eh[1][1] = ldexp(g11, ex);
-      dl = ldexp(det, ex);
-      Dh[0][0] = h00; Dh[0][1] = h01; Dh[1][0] = h10; Dh[1][1] = h11;
-      dprev = dp;
+      const double h00 = fma(-Lo[0][1], e10, fma(-Lo[0][0], e00, Di[0][0]));
+      const double h01 = fma(-Lo[0][1], e11, fma(-Lo[0][0], e01, Di[0][1]));
+      const double h10 = fma(-Lo[1][1], e10, fma(-Lo[1][0], e00, Di[1][0]));
+      const double h11 = fma(-Lo[1][1], e11, fma(-Lo[1][0], e01, Di[1][1]));
+      const double det = fma(h00, h11, -(h01 * h10));
+      double r = __builtin_amdgcn_rcp(det);
+      r = fma(fma(-det, r, 1.0), r, r);
+      r = fma(fma(-det, r, 1.0), r, r);
+      N[0][0] = h11 * r;
+      N[0][1] = -h01 * r;
+      N[1][0] = -h10 * r;
+      N[1][1] = h00 * r;
+      E[0][0] = fma(N[0][0], Up[0][0], N[0][1] * Up[1][0]);
+      E[0][1] = fma(N[0][0], Up[0][1], N[0][1] * Up[1][1]);
+      E[1][0] = fma(N[1][0], Up[0][0], N[1][1] * Up[1][0]);
+      E[1][1] = fma(N[1][0], Up[0][1], N[1][1] * Up[1][1]);
     }
-  }
-  {
-    const double det = Dh[0][0] * Dh[1][1] - Dh[0][1] * Dh[1][0];
-    const double sc = dprev / det;
-    const bool in = lane >= 1 && lane < M;
-    N[0][0] = in ? Dh[1][1] * sc : 0.0;
-    N[0][1] = in ? -Dh[0][1] * sc : 0.0;
-    N[1][0] = in ? -Dh[1][0] * sc : 0.0;
-    N[1][1] = in ? Dh[0][0] * sc : 0.0;
-    const double idl = 1.0 / dl;
-    E[0][0] = in ? Eh[0][0] * idl : 0.0;
-    E[0][1] = in ? Eh[0][1] * idl : 0.0;
-    E[1][0] = in ? Eh[1][0] * idl : 0.0;
-    E[1][1] = in ? Eh[1][1] * idl : 0.0;
   }
 }
 

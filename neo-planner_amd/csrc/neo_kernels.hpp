@@ -15,6 +15,9 @@
 #ifndef NEO_FUSED_U
 #define NEO_FUSED_U (sizeof(Real) == 4 ? 4 : 2)
 #endif
+#ifndef NEO_COMPACT_DIRECTION
+#define NEO_COMPACT_DIRECTION 0
+#endif
 #ifndef NEO_W2_U
 #define NEO_W2_U 1  // (one sample per lane in flight: the two-waves variant then has no VGPR spills; 2 -> 7 % slower)
 #endif
@@ -131,20 +134,32 @@ struct DevBackend {
     const int lane = lane_id();
     ps.v = 0.0;
     py.v = 0.0;
+    // the 2m history rows (s_0..s_{m-1}, y_0..y_{m-1}) four at a time: per-lane partial products, then wave_sum4
+    static_assert((2 * NEO_LBFGS_M) % 4 == 0, "rows are reduced in groups of four");
 #pragma unroll
-    for (int k = 0; k < NEO_LBFGS_M; ++k) {
-      double a = 0.0, b = 0.0;
+    for (int g = 0; g < 2 * NEO_LBFGS_M / 4; ++g) {
+      double part[4], tot[4];
 #pragma unroll
-      for (int q = 0; q < NS; ++q) {
-        const bool in = q * kWave + lane < t.n;
-        const double sv = in ? hist[k * t.n + q * kWave + lane] : 0.0;
-        const double yv = in ? hist[(m + k) * t.n + q * kWave + lane] : 0.0;
-        a += sv * v.v[q];
-        b += yv * v.v[q];
+      for (int e = 0; e < 4; ++e) {
+        const int row = 4 * g + e;  // row of `hist`: s_row for row < m, y_{row-m} beyond
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const bool in = q * kWave + lane < t.n;
+          const double hv = in ? hist[row * t.n + q * kWave + lane] : 0.0;
+          a += hv * v.v[q];
+        }
+        part[e] = a;
       }
-      const double ta = wave_sum(a), tb = wave_sum(b);
-      ps.v = (lane == k) ? ta : ps.v;
-      py.v = (lane == k) ? tb : py.v;
+      wave_sum4(part[0], part[1], part[2], part[3], tot[0], tot[1], tot[2], tot[3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = 4 * g + e;
+        if (row < NEO_LBFGS_M)
+          ps.v = (lane == row) ? tot[e] : ps.v;
+        else
+          py.v = (lane == row - NEO_LBFGS_M) ? tot[e] : py.v;
+      }
     }
   }
   __device__ __forceinline__ void mat_put_col(int slot, const SVec &sy, const SVec &yy) {
@@ -401,9 +416,13 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
                                                           long long *__restrict__ nsamples,
                                                           const int *__restrict__ order, double *__restrict__ trace,
                                                           int trace_cap) {
-  // fp32 sampling (the throughput mode): compact-representation direction, its two m x m matrices in LDS;
-  // fp64 sampling (the parity mode): the two-loop recursion that is pinned to SciPy's iterates (neo_lbfgs_dir.hpp)
-  constexpr bool kCompact = sizeof(Real) == 4;
+  // The direction d = -H g is the two-loop recursion, the form pinned to SciPy's iterates (neo_lbfgs_dir.hpp).
+  // -DNEO_COMPACT_DIRECTION=1 builds the fp32-sampling kernels with the compact representation instead (its two m x m
+  // matrices in LDS).  Measured on MI355X at cfg2 (two waves per SIMD, per evaluation): 28.4 us with one reduction per
+  // history row, 24.3 us with the rows reduced four at a time (wave_sum4), against 21.7 us for the two-loop recursion
+  // -- with two waves sharing a SIMD the 2*col extra dot products of the pair update and the 3*col steps of the
+  // triangular solves cost more issue slots than the shorter dependence chain gives back; 690 k -> 551 k traj/s.
+  constexpr bool kCompact = NEO_COMPACT_DIRECTION && sizeof(Real) == 4;
   __shared__ double xs[NS * kWave];
   __shared__ double sc[2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm;

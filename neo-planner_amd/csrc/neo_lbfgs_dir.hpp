@@ -8,9 +8,9 @@
 //     2*col dependent LDS reads + wavefront reductions per iteration (470 cycles a step, 3.8 us of a 21.7 us evaluation
 //     at cfg2).  This is the form pinned to SciPy: it follows 37 of the 39 recorded reference runs evaluation by
 //     evaluation, and every kernel with fp64 sampling (the parity mode, the reference-shaped MinJerkPlanner) uses it.
-//   * true: the compact representation (Byrd, Nocedal, Schnabel 1994, eq. 3.1), used by the fp32-sampling kernels (the
-//     throughput mode, whose runs are compared with the CPU's statistically anyway -- DESIGN.md section 3; on the host
-//     it follows 36 of the 39 recorded runs, the round-off difference tips one more of them):
+//   * true: the compact representation (Byrd, Nocedal, Schnabel 1994, eq. 3.1); a build option for the fp32-sampling
+//     kernels (-DNEO_COMPACT_DIRECTION=1, off by default: measured slower on MI355X, neo_kernels.hpp optimize_kernel)
+//     and exercised on the host (it follows 36 of the 39 recorded runs, the round-off difference tips one more):
 //         H = gamma I + [S  gamma Y] [ R^-T (D + gamma Y'Y) R^-1    -R^-T ] [ S'       ]
 //                                    [ -R^-1                          0    ] [ gamma Y' ]
 //     with R = upper triangle of S'Y (pairs in chronological order), D = its diagonal, gamma = 1 / theta.
