@@ -982,6 +982,7 @@ struct SampleLanes {
   int rounds;  // wave-uniform: rounds of the sample loop
   int lmax;    // wave-uniform: largest L (fold depth); 0 = every piece has the same L (fast DPP folds)
   int first;   // PIECE layout (lane p < M): first sample lane of piece p
+  int Lp;      // PIECE layout (lane p < M): number of sample lanes of piece p
 };
 
 // the same L = sample_lanes_per_piece(M) lanes for every piece (lane groups; pieces with equal sample counts)
@@ -997,6 +998,7 @@ __device__ __forceinline__ SampleLanes fixed_sample_lanes(int M, int L, int ns_o
   sl.rounds = -1;  // from the sample counts, in minco_sample
   sl.lmax = 0;
   sl.first = lane * L;
+  sl.Lp = L;
   return sl;
 }
 
@@ -1035,6 +1037,7 @@ __device__ __forceinline__ SampleLanes balanced_sample_lanes(int M, int ns_piece
   sl.rounds = R;
   sl.lmax = wave_max_nonneg(Lp);
   sl.first = start;
+  sl.Lp = Lp;
   return sl;
 }
 
@@ -1060,7 +1063,7 @@ __device__ __forceinline__ void fold_piece_segments(Real (&v)[N], int r, int L, 
 template <typename Real, int D, class LookupT, int U, bool SAMPLE_IO = false, class LG = WaveLanes>
 __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int ns_in, const Real (&cp)[6][LG::dl(D)],
                                              const DevParams &prm, const LookupT &lk, Real (&gC)[6][LG::dl(D)], Real &gT,
-                                             double &cost_feas, double &cost_coll) {
+                                             double &cost_feas, double &cost_coll, Real *fold_rows = nullptr) {
 #pragma clang fp contract(on)  // fuse a*b+c only as written: the same arithmetic whatever the unrolling around it
   const int lane = LG::lane();
   const int piece = sl.piece, r = sl.r, L = sl.L;  // (L: per lane when the pieces have different numbers of lanes)
@@ -1197,6 +1200,55 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
           aT += w3 * (omg * vq * vq * vq * inv_ns + dK * (-gv) * (Real)j * inv_ns);
         }
       }
+    }
+  }
+  // (fp32 sampling only: the fp64 parity mode keeps the summation order below, the one its runs were pinned to the
+  //  reference's recorded iterates with)
+  if constexpr (!SAMPLE_IO && sizeof(Real) == 4) {
+    if (fold_rows != nullptr && sl.lmax != 0) {
+      // Pieces with different numbers of sample lanes, partials wanted in the lanes of the piece: through LDS.  Every
+      // sample lane writes its row [d][8] = (aC[0..5][d], aT, 0) (two 16-byte stores a dimension); the lane of (piece,
+      // dimension) then adds up the rows first .. first + Lp - 1 of its piece, one 32-byte block a row, in that order.
+      // lmax * (2 reads + 7 adds) instructions, against log2(lmax) * 21 * (shuffle + select + add) and 21 more
+      // shuffles to bring the result home for the in-register fold below; the two costs need no fold at all.
+      typedef Real Quad __attribute__((ext_vector_type(4)));
+      constexpr int DL = LG::dl(D);
+      Quad *row = reinterpret_cast<Quad *>(fold_rows + (size_t)lane * (8 * D));
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        row[2 * d] = Quad{aC[0][d], aC[1][d], aC[2][d], aC[3][d]};
+        row[2 * d + 1] = Quad{aC[4][d], aC[5][d], aT, Real(0)};
+      }
+      lds_wave_sync();
+      int first = sl.first, Lp = sl.Lp;
+      if constexpr (LG::S > 1) {
+        first = __shfl(sl.first, LG::piece(), kWave);
+        Lp = __shfl(sl.Lp, LG::piece(), kWave);
+      }
+      if (LG::piece() >= M) Lp = 0;
+      Quad lo[DL], hi[DL];
+#pragma unroll
+      for (int dd = 0; dd < DL; ++dd) lo[dd] = hi[dd] = Quad{Real(0), Real(0), Real(0), Real(0)};
+      const Quad *src = reinterpret_cast<const Quad *>(fold_rows + (size_t)first * (8 * D)) + 2 * LG::dim0();
+      for (int i = 0; i < sl.lmax; ++i) {
+        if (i < Lp) {
+#pragma unroll
+          for (int dd = 0; dd < DL; ++dd) {
+            lo[dd] += src[i * 2 * D + 2 * dd];
+            hi[dd] += src[i * 2 * D + 2 * dd + 1];
+          }
+        }
+      }
+      lds_wave_sync();  // (the rows are the caller's staging buffer again)
+#pragma unroll
+      for (int dd = 0; dd < DL; ++dd) {
+        gC[0][dd] = lo[dd].x; gC[1][dd] = lo[dd].y; gC[2][dd] = lo[dd].z; gC[3][dd] = lo[dd].w;
+        gC[4][dd] = hi[dd].x; gC[5][dd] = hi[dd].y;
+      }
+      gT = hi[0].z;
+      cost_feas = LG::sum(act ? (double)aF : 0.0);
+      cost_coll = LG::sum(act ? (double)aK : 0.0);
+      return;
     }
   }
   // fold the L lanes of each piece (fixed order); PIECE-layout callers get lane piece*L moved to lane piece

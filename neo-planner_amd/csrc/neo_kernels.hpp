@@ -36,6 +36,14 @@
 
 namespace neo {
 
+// doubles of LDS staging a wavefront needs: NS * 64 for the FLAT <-> PIECE exchange, 64 rows of [D][8] Reals for the
+// per-piece fold of the sampled partials (the two uses never overlap)
+template <int D, int NS, typename Real>
+__host__ __device__ constexpr int stage_doubles() {
+  constexpr int fold = sizeof(Real) == 4 ? kWave * 8 * D * (int)sizeof(Real) : 0;  // (fp32 sampling only)
+  return (NS * kWave * 8 > fold ? NS * kWave * 8 : fold) / 8;
+}
+
 // ------------------------------------------------------------------ device backend of the optimiser
 // SU: samples per lane in flight in the sample loop (minco_sample)
 // LG: lane layout of the PIECE-layout phases -- WaveLanes (lane = piece) or WaveLanesPD<D> (lane = (piece, dimension))
@@ -49,7 +57,9 @@ struct DevBackend {
   Traj<D, DL> t;
   const DevParams &prm;
   const MapT &map;
-  double *xs;    // LDS [256]: FLAT <-> PIECE staging
+  double *xs;    // LDS [kStage]: FLAT <-> PIECE staging; between scatter_x and the gradient gather the same memory
+                 // holds the lane assignment's segment table and the rows of the per-piece fold (minco_sample)
+  static constexpr int kStage = stage_doubles<D, NS, Real>();
   double *sc;    // LDS [2m]: rho / alpha of the two-loop recursion
   LineSearch *lsp;  // LDS: line-search state (wave-uniform)
   double *cst;      // LDS [12]: cost terms of the last evaluation / current x / previous x
@@ -300,7 +310,8 @@ struct DevBackend {
       int ns_by_piece = t.ns;
       if constexpr (LG::S > 1) ns_by_piece = __shfl(t.ns, min(LG::S * lane, kWave - 1), kWave);
       const SampleLanes sl = balanced_sample_lanes(t.M, ns_by_piece, reinterpret_cast<int *>(xs));
-      minco_sample<Real, D, LookupT, SU, false, LG>(t.M, sl, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
+      minco_sample<Real, D, LookupT, SU, false, LG>(t.M, sl, t.ns, cr, prm, lk, gCr, gTr, cf, ck,
+                                                    reinterpret_cast<Real *>(xs));
 #pragma unroll
       for (int k = 0; k < 6; ++k)
 #pragma unroll
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
                                                       double *__restrict__ cost, double *__restrict__ costs4,
                                                       double *__restrict__ grad, double *__restrict__ coeffs,
                                                       int *__restrict__ status) {
-  __shared__ double xs[NS * kWave];
+  __shared__ __attribute__((aligned(16))) double xs[stage_doubles<D, NS, Real>()];
   __shared__ double sc[2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm;
   __shared__ double cst[12];
@@ -423,7 +434,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
   // -- with two waves sharing a SIMD the 2*col extra dot products of the pair update and the 3*col steps of the
   // triangular solves cost more issue slots than the shorter dependence chain gives back; 690 k -> 551 k traj/s.
   constexpr bool kCompact = NEO_COMPACT_DIRECTION && sizeof(Real) == 4;
-  __shared__ double xs[NS * kWave];
+  __shared__ __attribute__((aligned(16))) double xs[stage_doubles<D, NS, Real>()];
   __shared__ double sc[2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm;
   __shared__ double cst[12];
