@@ -112,11 +112,14 @@ struct DevBackend {
 #pragma unroll
     for (int k = 0; k < NS; ++k) v.v[k] *= s;
   }
+  // element k * 64 + lane of a FLAT vector exists.  The kernel with NS slots is launched for (NS / 2) * 64 < n <=
+  // NS * 64 (slots_for), so the first NS / 2 slots are full in every lane: no exec masking around their LDS accesses.
+  __device__ __forceinline__ bool in_range(int k, int lane) const { return k < NS / 2 || k * kWave + lane < t.n; }
   __device__ __forceinline__ void hist_put(int slot, const Vec &s, const Vec &y) {
     const int lane = lane_id();
 #pragma unroll
     for (int k = 0; k < NS; ++k)
-      if (k * kWave + lane < t.n) {
+      if (in_range(k, lane)) {
         hist[slot * t.n + k * kWave + lane] = s.v[k];
         hist[(m + slot) * t.n + k * kWave + lane] = y.v[k];
       }
@@ -125,7 +128,7 @@ struct DevBackend {
   __device__ __forceinline__ void hist_get(int row, Vec &v) const {
     const int lane = lane_id();
 #pragma unroll
-    for (int k = 0; k < NS; ++k) v.v[k] = (k * kWave + lane < t.n) ? hist[row * t.n + k * kWave + lane] : 0.0;
+    for (int k = 0; k < NS; ++k) v.v[k] = in_range(k, lane) ? hist[row * t.n + k * kWave + lane] : 0.0;
   }
   __device__ __forceinline__ void hist_get_s(int slot, Vec &v) const { hist_get(slot, v); }
   __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
@@ -246,7 +249,7 @@ struct DevBackend {
     lds_wave_sync();
 #pragma unroll
     for (int k = 0; k < NS; ++k)
-      if (k * kWave + lane < t.n) xs[k * kWave + lane] = x.v[k];
+      if (in_range(k, lane)) xs[k * kWave + lane] = x.v[k];
     lds_wave_sync();
     const int M = t.M;
     const int p = LG::piece();
@@ -338,7 +341,7 @@ struct DevBackend {
     if (p < t.M && LG::dim0() == 0) xs[t.nq + p] = gtau;
     lds_wave_sync();
 #pragma unroll
-    for (int k = 0; k < NS; ++k) g.v[k] = (k * kWave + lane < t.n) ? xs[k * kWave + lane] : 0.0;
+    for (int k = 0; k < NS; ++k) g.v[k] = in_range(k, lane) ? xs[k * kWave + lane] : 0.0;
 #ifdef NEO_STAMPS
     const long long s3 = wall_clock64();
     tk[0] += s1 - s0;

@@ -102,8 +102,9 @@ NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpt
     be.copy(r, g);
     const double fold = f;
     for (int k = 0; k < 4; ++k) old[k] = cur[k];
-    const double dnorm = sqrt(be.dot(d, d));
-    double stp = (iter == 0) ? fmin(1.0 / dnorm, big) : 1.0;
+    // (lnsrlb forms |d| every iteration but, without bounds, uses it only for the first step)
+    double stp = 1.0;
+    if (iter == 0) stp = fmin(1.0 / sqrt(be.dot(d, d)), big);
     double gd = be.dot(g, d);
     const double gdold = gd;
     bool failed = false;

@@ -45,7 +45,7 @@ NEO_HD void lbfgs_direction(Backend &be, const typename Backend::Vec &g, typenam
   if constexpr (!COMPACT) {
   be.copy(d, g);  // d plays q of the two-loop recursion
   for (int k = col - 1; k >= 0; --k) {
-    const int slot = (head + k) % m;
+    const int slot = head + k < m ? head + k : head + k - m;  // (head + k) % m without the division
     be.hist_get_s(slot, tmp);
     be.hist_get_y(slot, tmp2);  // (issued with the read of s: its latency hides behind the reduction)
     const double a = be.sget(slot) * be.dot(tmp, d);  // rho * s'q
@@ -54,7 +54,7 @@ NEO_HD void lbfgs_direction(Backend &be, const typename Backend::Vec &g, typenam
   }
   be.scale(d, 1.0 / theta);
   for (int k = 0; k < col; ++k) {
-    const int slot = (head + k) % m;
+    const int slot = head + k < m ? head + k : head + k - m;
     be.hist_get_y(slot, tmp);
     be.hist_get_s(slot, tmp2);
     const double b = be.sget(slot) * be.dot(tmp, d);

@@ -107,8 +107,9 @@ struct LbfgsMachine {
         be.copy(r, g);
         fold = f;
         for (int k = 0; k < 4; ++k) old()[k] = cur()[k];
-        const double dnorm = sqrt(be.dot(d, d));
-        stp = (iter == 0) ? fmin(1.0 / dnorm, big) : 1.0;
+        // (lnsrlb forms |d| every iteration but, without bounds, uses it only for the first step)
+        stp = 1.0;
+        if (iter == 0) stp = fmin(1.0 / sqrt(be.dot(d, d)), big);
         gd = be.dot(g, d);
         gdold = gd;
         if (gd >= 0.0) {
