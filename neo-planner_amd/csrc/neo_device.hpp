@@ -100,6 +100,19 @@ __device__ __forceinline__ double dpp_d(double v) {
   const int hi = dpp_i<CTRL, ROW_MASK>(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+// The two row broadcasts of a reduction that is read at lane 63 only: rows masked off by row_mask are left UNDEFINED
+// (no preset register, v_mov_dpp with an undefined `old`).  Lane 63 depends only on written rows: row_bcast:15 (rows 1,
+// 3) gives lane 31 = S1 + S0 and lane 63 = S3 + S2, row_bcast:31 (rows 2, 3) adds lane 31 to lane 63.  Not for scans.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_any_i(int v) {
+  return __builtin_amdgcn_mov_dpp(v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_any_d(double v) {
+  const int lo = dpp_any_i<CTRL, ROW_MASK>(__double2loint(v));
+  const int hi = dpp_any_i<CTRL, ROW_MASK>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
 // wave-wide sum / max with a fixed association order; the result is returned wave-uniform
 // (taken from lane 63 through v_readlane).  Inclusive scan inside rows, then the two row broadcasts.
 __device__ __forceinline__ double wave_sum(double v) {
@@ -107,8 +120,8 @@ __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_d<0x112>(v);
   v += dpp_d<0x114>(v);
   v += dpp_d<0x118>(v);
-  v += dpp_d<0x142, 0xa>(v);
-  v += dpp_d<0x143, 0xc>(v);
+  v += dpp_any_d<0x142, 0xa>(v);
+  v += dpp_any_d<0x143, 0xc>(v);
   return rdlane(v, 63);
 }
 __device__ __forceinline__ float wave_sum(float v) {
@@ -116,8 +129,8 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_f<0x112>(v);
   v += dpp_f<0x114>(v);
   v += dpp_f<0x118>(v);
-  v += dpp_f<0x142, 0xa>(v);
-  v += dpp_f<0x143, 0xc>(v);
+  v += __int_as_float(dpp_any_i<0x142, 0xa>(__float_as_int(v)));
+  v += __int_as_float(dpp_any_i<0x143, 0xc>(__float_as_int(v)));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ int wave_sum(int v) {
@@ -125,8 +138,8 @@ __device__ __forceinline__ int wave_sum(int v) {
   v += dpp_i<0x112>(v);
   v += dpp_i<0x114>(v);
   v += dpp_i<0x118>(v);
-  v += dpp_i<0x142, 0xa>(v);
-  v += dpp_i<0x143, 0xc>(v);
+  v += dpp_any_i<0x142, 0xa>(v);
+  v += dpp_any_i<0x143, 0xc>(v);
   return __builtin_amdgcn_readlane(v, 63);
 }
 // Four wave-wide sums for little more than the price of one: the four per-lane values are first folded onto one
@@ -190,8 +203,8 @@ __device__ __forceinline__ double wave_max_nonneg(double v) {
   v = fmax(v, dpp_d<0x112>(v));
   v = fmax(v, dpp_d<0x114>(v));
   v = fmax(v, dpp_d<0x118>(v));
-  v = fmax(v, dpp_d<0x142, 0xa>(v));
-  v = fmax(v, dpp_d<0x143, 0xc>(v));
+  v = fmax(v, dpp_any_d<0x142, 0xa>(v));
+  v = fmax(v, dpp_any_d<0x143, 0xc>(v));
   return rdlane(v, 63);
 }
 __device__ __forceinline__ int wave_max_nonneg(int v) {
@@ -199,8 +212,8 @@ __device__ __forceinline__ int wave_max_nonneg(int v) {
   v = max(v, dpp_i<0x112>(v));
   v = max(v, dpp_i<0x114>(v));
   v = max(v, dpp_i<0x118>(v));
-  v = max(v, dpp_i<0x142, 0xa>(v));
-  v = max(v, dpp_i<0x143, 0xc>(v));
+  v = max(v, dpp_any_i<0x142, 0xa>(v));
+  v = max(v, dpp_any_i<0x143, 0xc>(v));
   return __builtin_amdgcn_readlane(v, 63);
 }
 // value of lane (l-1) / (l+1); lanes without such a neighbour get `fill`
