@@ -1217,15 +1217,16 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
   }
   // (fp32 sampling only: the fp64 parity mode keeps the summation order below, the one its runs were pinned to the
   //  reference's recorded iterates with)
-  if constexpr (!SAMPLE_IO && sizeof(Real) == 4) {
+  if constexpr (sizeof(Real) == 4) {
     if (fold_rows != nullptr && sl.lmax != 0) {
-      // Pieces with different numbers of sample lanes, partials wanted in the lanes of the piece: through LDS.  Every
-      // sample lane writes its row [d][8] = (aC[0..5][d], aT, 0) (two 16-byte stores a dimension); the lane of (piece,
-      // dimension) then adds up the rows first .. first + Lp - 1 of its piece, one 32-byte block a row, in that order.
-      // lmax * (2 reads + 7 adds) instructions, against log2(lmax) * 21 * (shuffle + select + add) and 21 more
-      // shuffles to bring the result home for the in-register fold below; the two costs need no fold at all.
+      // Pieces with different numbers of sample lanes: the per-piece sums go through LDS.  Every sample lane writes its
+      // row [d][8] = (aC[0..5][d], aT, 0) (two 16-byte stores a dimension); the receiving lane -- the lane of (piece,
+      // dimension) in the fused kernels, the first sample lane of the piece in the stand-alone kernel -- then adds up
+      // the rows first .. first + Lp - 1 of its piece, one 32-byte block a row and dimension, in that order.
+      // lmax * (2 reads + 7 adds) instructions a dimension, against log2(lmax) * 21 * (shuffle + select + add) and 21
+      // more shuffles to bring the result home for the in-register fold below; the two costs need no fold at all.
       typedef Real Quad __attribute__((ext_vector_type(4)));
-      constexpr int DL = LG::dl(D);
+      constexpr int DR = LG::dl(D);  // dimensions the receiving lane keeps (SAMPLE_IO: LG = WaveLanes, all D)
       Quad *row = reinterpret_cast<Quad *>(fold_rows + (size_t)lane * (8 * D));
 #pragma unroll
       for (int d = 0; d < D; ++d) {
@@ -1233,20 +1234,28 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
         row[2 * d + 1] = Quad{aC[4][d], aC[5][d], aT, Real(0)};
       }
       lds_wave_sync();
-      int first = sl.first, Lp = sl.Lp;
-      if constexpr (LG::S > 1) {
-        first = __shfl(sl.first, LG::piece(), kWave);
-        Lp = __shfl(sl.Lp, LG::piece(), kWave);
+      int first, Lp, dim_base = 0;
+      if constexpr (SAMPLE_IO) {
+        first = lane;
+        Lp = (act && r == 0) ? L : 0;
+      } else {
+        first = sl.first;
+        Lp = sl.Lp;
+        if constexpr (LG::S > 1) {
+          first = __shfl(sl.first, LG::piece(), kWave);
+          Lp = __shfl(sl.Lp, LG::piece(), kWave);
+        }
+        if (LG::piece() >= M) Lp = 0;
+        dim_base = LG::dim0();
       }
-      if (LG::piece() >= M) Lp = 0;
-      Quad lo[DL], hi[DL];
+      Quad lo[DR], hi[DR];
 #pragma unroll
-      for (int dd = 0; dd < DL; ++dd) lo[dd] = hi[dd] = Quad{Real(0), Real(0), Real(0), Real(0)};
-      const Quad *src = reinterpret_cast<const Quad *>(fold_rows + (size_t)first * (8 * D)) + 2 * LG::dim0();
+      for (int dd = 0; dd < DR; ++dd) lo[dd] = hi[dd] = Quad{Real(0), Real(0), Real(0), Real(0)};
+      const Quad *src = reinterpret_cast<const Quad *>(fold_rows + (size_t)first * (8 * D)) + 2 * dim_base;
       for (int i = 0; i < sl.lmax; ++i) {
         if (i < Lp) {
 #pragma unroll
-          for (int dd = 0; dd < DL; ++dd) {
+          for (int dd = 0; dd < DR; ++dd) {
             lo[dd] += src[i * 2 * D + 2 * dd];
             hi[dd] += src[i * 2 * D + 2 * dd + 1];
           }
@@ -1254,7 +1263,7 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
       }
       lds_wave_sync();  // (the rows are the caller's staging buffer again)
 #pragma unroll
-      for (int dd = 0; dd < DL; ++dd) {
+      for (int dd = 0; dd < DR; ++dd) {
         gC[0][dd] = lo[dd].x; gC[1][dd] = lo[dd].y; gC[2][dd] = lo[dd].z; gC[3][dd] = lo[dd].w;
         gC[4][dd] = hi[dd].x; gC[5][dd] = hi[dd].y;
       }

@@ -551,6 +551,8 @@ __global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? NEO_SAMPLE_OCC : 2) void
   const int b = blockIdx.x;
   if (b >= B) return;
   __shared__ int seg[kWave];
+  // rows of the per-piece fold (fp32 sampling, minco_sample)
+  __shared__ __attribute__((aligned(16))) Real rows[sizeof(Real) == 4 ? kWave * 8 * D : 4];
   const int lane = lane_id();
   // lanes in proportion to the pieces' sample counts, as in the fused kernels (same sums, bit for bit)
   const double Tp = lane < M ? ts[(size_t)b * M + lane] : 1.0;
@@ -573,7 +575,8 @@ __global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? NEO_SAMPLE_OCC : 2) void
   }
   double cf, ck;
   LookupT lk(map);
-  minco_sample<Real, D, LookupT, NEO_SAMPLE_U, true>(M, sl, ns, c, prm, lk, gC, gT, cf, ck);
+  minco_sample<Real, D, LookupT, NEO_SAMPLE_U, true>(M, sl, ns, c, prm, lk, gC, gT, cf, ck,
+                                                     sizeof(Real) == 4 ? rows : nullptr);
   if (act && r == 0) {
     double2 *dst = reinterpret_cast<double2 *>(grad_C + ((size_t)b * 6 * M + 6 * piece) * D);
 #pragma unroll
