@@ -60,6 +60,7 @@ struct DevBackend {
   double *xs;    // LDS [kStage]: FLAT <-> PIECE staging; between scatter_x and the gradient gather the same memory
                  // holds the lane assignment's segment table and the rows of the per-piece fold (minco_sample)
   static constexpr int kStage = stage_doubles<D, NS, Real>();
+  bool fold_rows = true;  // xs has all kStage doubles (false: only NS * 64, the fold stays in registers)
   double *sc;    // LDS [2m]: rho / alpha of the two-loop recursion
   LineSearch *lsp;  // LDS: line-search state (wave-uniform)
   double *cst;      // LDS [12]: cost terms of the last evaluation / current x / previous x
@@ -314,7 +315,7 @@ struct DevBackend {
       if constexpr (LG::S > 1) ns_by_piece = __shfl(t.ns, min(LG::S * lane, kWave - 1), kWave);
       const SampleLanes sl = balanced_sample_lanes(t.M, ns_by_piece, reinterpret_cast<int *>(xs));
       minco_sample<Real, D, LookupT, SU, false, LG>(t.M, sl, t.ns, cr, prm, lk, gCr, gTr, cf, ck,
-                                                    reinterpret_cast<Real *>(xs));
+                                                    fold_rows ? reinterpret_cast<Real *>(xs) : nullptr);
 #pragma unroll
       for (int k = 0; k < 6; ++k)
 #pragma unroll
@@ -413,10 +414,13 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
 }
 
 // WAVES = wavefronts per SIMD the register allocation aims at.  1: the whole file (256 VGPRs + AGPRs) for one
-// trajectory -- the shortest evaluation, for batches that leave SIMDs to spare.  2: half the file, some state
-// spilled to scratch -- each evaluation is slower, but two trajectories share a SIMD's issue slots, which wins
-// once the batch queues for the 1024 SIMDs anyway (cfg2 with several batches in flight: +10 %).  Same
-// source, same arithmetic, bit-identical results.
+// trajectory -- the shortest evaluation, for batches that leave SIMDs to spare.  2: half the file (the cfg2
+// instantiation fits it without spills) -- each evaluation is slower, but two trajectories share a SIMD's issue
+// slots, which wins once the batch queues for the 1024 SIMDs anyway.  Same source, same arithmetic, bit-identical
+// results.
+// Dynamic LDS (launch parameter): `stage` doubles of staging (DevBackend::xs) followed by the 2 * maxcor * n doubles of
+// the L-BFGS pairs.  The launcher gives the staging its full size (room for the rows of the per-piece fold) unless that
+// would cost a wavefront of occupancy -- then NS * 64 doubles, and the fold runs in registers.
 template <int D, int NS, typename Real, class MapT, class LookupT, int WAVES, class LG = WaveLanes>
 __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
                                                           const int *__restrict__ scene_slot, int nmaps,
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
                                                           int *__restrict__ status,
                                                           long long *__restrict__ nsamples,
                                                           const int *__restrict__ order, double *__restrict__ trace,
-                                                          int trace_cap) {
+                                                          int trace_cap, int stage) {
   // The direction d = -H g is the two-loop recursion, the form pinned to SciPy's iterates (neo_lbfgs_dir.hpp).
   // -DNEO_COMPACT_DIRECTION=1 builds the fp32-sampling kernels with the compact representation instead (its two m x m
   // matrices in LDS).  Measured on MI355X at cfg2 (two waves per SIMD, per evaluation): 28.4 us with one reduction per
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
   // -- with two waves sharing a SIMD the 2*col extra dot products of the pair update and the 3*col steps of the
   // triangular solves cost more issue slots than the shorter dependence chain gives back; 690 k -> 551 k traj/s.
   constexpr bool kCompact = NEO_COMPACT_DIRECTION && sizeof(Real) == 4;
-  __shared__ __attribute__((aligned(16))) double xs[stage_doubles<D, NS, Real>()];
+  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
   __shared__ double sc[2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm;
   __shared__ double cst[12];
@@ -461,7 +465,8 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
   }
   const MapT map = maps[slot];
   BE be(prm, map);
-  be.xs = xs;
+  be.xs = dyn_lds;
+  be.fold_rows = stage >= stage_doubles<D, NS, Real>();
   be.sc = sc;
   be.lsp = &lsm;
   be.cst = cst;
@@ -473,8 +478,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
   load_boundary(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
   const int n = be.t.n;
   be.npad = NS * kWave;
-  extern __shared__ double dyn_lds[];  // 2 * maxcor * n doubles (launch parameter)
-  be.hist = dyn_lds;
+  be.hist = dyn_lds + stage;
   const int lane = lane_id();
   typename BE::Vec xv;
 #pragma unroll

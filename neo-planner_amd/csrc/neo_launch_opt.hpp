@@ -8,12 +8,20 @@ namespace neo {
 template <int D, typename Real, class MapT, class LookupT, int WAVES = 1>
 int launch_opt(neo_ctx *c, const OptArgs &a) {
   const dim3 grid(a.B), blk(kWave);
-  const size_t dyn = (size_t)2 * NEO_LBFGS_M * (D * (a.M - 1) + a.M) * sizeof(double);  // L-BFGS pairs in LDS
+  const size_t pairs = (size_t)2 * NEO_LBFGS_M * (D * (a.M - 1) + a.M) * sizeof(double);  // L-BFGS pairs in LDS
+  // staging in front of the pairs: the full size (with the rows of the per-piece fold) unless that costs occupancy
+  // -- WAVES wavefronts per SIMD want 160 KB / (4 * WAVES) each, less ~0.5 KB of static LDS
+  const size_t lds_share = (size_t)160 * 1024 / (4 * WAVES) - 512;
 #define NEO_OPT_LG(NS, LG)                                                                                    \
-  hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES, LG>), grid, blk, dyn, c->stream, a.B, a.M, c->dev, \
-                     static_cast<const MapT *>(a.table), a.slots, a.nmaps, a.x, a.head, a.tail, a.costs4,      \
-                     a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter,                                \
-                     (c->order_B == a.B ? c->dispatch_order : nullptr), c->trace, c->trace_cap)
+  do {                                                                                                        \
+    const int full = stage_doubles<D, NS, Real>(), small = NS * kWave;                                        \
+    const int stage = pairs + (size_t)full * 8 <= lds_share ? full : small;                                   \
+    hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES, LG>), grid, blk,                   \
+                       pairs + (size_t)stage * 8, c->stream, a.B, a.M, c->dev,                                \
+                       static_cast<const MapT *>(a.table), a.slots, a.nmaps, a.x, a.head, a.tail, a.costs4,   \
+                       a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter,                             \
+                       (c->order_B == a.B ? c->dispatch_order : nullptr), c->trace, c->trace_cap, stage);     \
+  } while (0)
   // lane = (piece, dimension) whenever D * M fits the wavefront (cfg2: 63 lanes busy in the PIECE-layout phases
   // instead of 21, a third of the per-dimension state per lane); lane = piece otherwise.  flags bit 512 forces the
   // latter (comparison runs).
