@@ -595,6 +595,39 @@ def main():
                 "lookups_per_s": n_samples / (us * 1e-6),
                 "esdf_footprint_bytes": footprint, "esdf_bytes": a.grid ** 3 * esz,
                 "traffic": hbm_traffic(pm_s), "l2_hit_rate": l2_hit(pm_s), "traffic_source": src_s}
+        # the same kernel over ALL request batches of a step in one launch (n_sets * B trajectories): with more
+        # wavefronts than the chip holds at once the launch is bound by throughput, not by the run time of one wavefront
+        if n_sets > 1 and init is None:
+            Ba = B * n_sets
+            coeffs_a = torch.zeros(Ba, 6 * M, D, dtype=torch.float64, device=dev)
+            for r_, bt in enumerate(batches):
+                ctx.check(ctx.lib.neo_cost_grad_batch_dev(ctx.h, g3.scene_id, B, M, D, pp(bt["x0"]), pp(bt["head"]),
+                                                          pp(bt["tail"]), pp(cost1), pp(c4), pp(grad1),
+                                                          pp(coeffs_a[r_ * B:(r_ + 1) * B]), pp(st1)))
+            ts_a = np.ascontiguousarray(np.concatenate([st_[3] for st_ in sets], axis=0))
+            d_ts_a = torch.from_numpy(ts_a).to(dev)
+            c2a = torch.zeros(Ba, 2, dtype=torch.float64, device=dev)
+            gCa = torch.zeros_like(coeffs_a)
+            gTa = torch.zeros(Ba, M, dtype=torch.float64, device=dev)
+            run_a = lambda: ctx.check(ctx.lib.neo_sampled_terms_batch_dev(ctx.h, g3.scene_id, Ba, M, D, pp(coeffs_a),
+                                                                          pp(d_ts_a), pp(c2a), pp(gCa), pp(gTa)))
+            for _ in range(3):
+                run_a()
+            torch.cuda.synchronize()
+            ctx.check(ctx.lib.neo_profile_reset(ctx.h))
+            ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
+            for _ in range(20):
+                run_a()
+            torch.cuda.synchronize()
+            ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
+            ctx.check(ctx.lib.neo_profile_read(ctx.h, _lib.NEO_KERNEL_ESDF_SAMPLE, ctypes.byref(l2), ctypes.byref(m2)))
+            us_a = 1e3 * m2.value / max(l2.value, 1)
+            ns_a = int(np.floor(ts_a / bp.cfg.delta_t).astype(np.int64).sum())
+            by_a = ns_a * 8.0 * esz + Ba * (2 * n * 4 + 20)
+            esdf["whole_step_launch"] = {"trajectories": Ba, "kernel_us": us_a, "launches": int(l2.value),
+                                         "samples_per_launch": ns_a, "algorithmic_bytes_per_launch": by_a,
+                                         "achieved": by_a / (us_a * 1e-6) / 1e9,
+                                         "frac_8d2": by_a / (us_a * 1e-6) / 1e9 / HBM_PEAK_GBPS}
     nfev_all = torch.stack([bt["nfev"] for bt in batches]).cpu().numpy().astype(np.int64)
     nsamp_all = torch.stack([bt["nsamp"] for bt in batches]).cpu().numpy()
     status_h = b0["status"].cpu().numpy()
