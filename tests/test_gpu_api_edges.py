@@ -261,7 +261,9 @@ def test_one_and_two_waves_per_simd_agree_bit_for_bit():
     optimiser kernel: every output must be identical"""
     dist = synth.esdf_3d(2, n=100, res=0.3)
     g3 = npa.ESDF3D(dist, 0.3, synth.DOMAIN_ORIGIN, store="f32")
-    for M, B in ((5, 300), (21, 200)):
+    # M = 31 (n = 121): the L-BFGS pairs leave no room in LDS for the rows of the per-piece fold at eight wavefronts per
+    # CU, both variants then fold in registers (neo_launch_opt.hpp)
+    for M, B in ((5, 300), (21, 200), (31, 96)):
         head, tail, wp, ts = synth.replan_requests(2, B, M - 1, D=3)
         out = []
         for waves in (1, 2):
