@@ -83,12 +83,9 @@ __device__ __forceinline__ double uniform(double v) {
 // Lanes without a valid source (or masked off by row_mask) receive 0.  With every row enabled that is the
 // instruction's own bound_ctrl zero fill: no register has to be preset to 0 ahead of each move (two v_mov_b32 per
 // fp64 step, 8 of the 34 instructions of a wave_sum); with a row mask the masked rows keep `old`, which must be the 0.
-#ifndef NEO_DPP_ZERO_FILL
-#define NEO_DPP_ZERO_FILL 1
-#endif
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ int dpp_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf && NEO_DPP_ZERO_FILL);
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
 }
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp_f(float v) {
