@@ -80,6 +80,10 @@ struct GroupBackend {
   }
   __device__ __forceinline__ void hist_get_s(int slot, Vec &v) const { hist_get(slot, v); }
   __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
+  __device__ __forceinline__ void hist_get_sy(int slot, Vec &s, Vec &y) const {
+    hist_get(slot, s);
+    hist_get(m + slot, y);
+  }
   __device__ __forceinline__ void sput(int i, double v) {
     sc[i] = v;
     lds_wave_sync();

@@ -133,6 +133,20 @@ struct DevBackend {
   }
   __device__ __forceinline__ void hist_get_s(int slot, Vec &v) const { hist_get(slot, v); }
   __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
+  // s and y of one pair together: the partly filled last slot of both under ONE exec mask
+  __device__ __forceinline__ void hist_get_sy(int slot, Vec &s, Vec &y) const {
+    const int lane = lane_id();
+    const double *ps = hist + slot * t.n + lane, *py = hist + (m + slot) * t.n + lane;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      s.v[k] = 0.0;
+      y.v[k] = 0.0;
+      if (in_range(k, lane)) {
+        s.v[k] = ps[k * kWave];
+        y.v[k] = py[k * kWave];
+      }
+    }
+  }
   // ---- compact-representation direction (neo_lbfgs_dir.hpp, fp32-sampling kernels): vectors with one entry per
   // history slot live in lane `slot` of a register pair; S'Y and Y'Y (m x m each) in LDS
   struct SVec {

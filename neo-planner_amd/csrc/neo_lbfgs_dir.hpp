@@ -21,6 +21,7 @@
 // Backend concept (on top of neo_lbfgs.hpp's):
 //   using SVec;                                  a vector with one entry per history slot (m entries)
 //   double sv_get(const SVec&, int slot);  void sv_set(SVec&, int slot, double v);
+//   void hist_get_sy(int slot, Vec& s, Vec& y);          the pair of a slot in one call
 //   void hist_dots(const Vec& v, SVec& ps, SVec& py);     ps[k] = s_k . v, py[k] = y_k . v for every slot k
 //   void mat_put_col(int slot, const SVec& sy, const SVec& yy);   SY[i][slot] = sy[i]; YY[i][slot] = YY[slot][i] = yy[i]
 //   void sv_init_w(SVec& w, const SVec& u, const SVec& b, double gamma);      w_i = SY[i][i] u_i - gamma b_i
@@ -46,8 +47,7 @@ NEO_HD void lbfgs_direction(Backend &be, const typename Backend::Vec &g, typenam
   be.copy(d, g);  // d plays q of the two-loop recursion
   for (int k = col - 1; k >= 0; --k) {
     const int slot = head + k < m ? head + k : head + k - m;  // (head + k) % m without the division
-    be.hist_get_s(slot, tmp);
-    be.hist_get_y(slot, tmp2);  // (issued with the read of s: its latency hides behind the reduction)
+    be.hist_get_sy(slot, tmp, tmp2);  // (y issued with the read of s: its latency hides behind the reduction)
     const double a = be.sget(slot) * be.dot(tmp, d);  // rho * s'q
     be.sput(m + slot, a);
     be.axpy(-a, tmp2, d);
@@ -55,8 +55,7 @@ NEO_HD void lbfgs_direction(Backend &be, const typename Backend::Vec &g, typenam
   be.scale(d, 1.0 / theta);
   for (int k = 0; k < col; ++k) {
     const int slot = head + k < m ? head + k : head + k - m;
-    be.hist_get_y(slot, tmp);
-    be.hist_get_s(slot, tmp2);
+    be.hist_get_sy(slot, tmp2, tmp);
     const double b = be.sget(slot) * be.dot(tmp, d);
     be.axpy(be.sget(m + slot) - b, tmp2, d);
   }

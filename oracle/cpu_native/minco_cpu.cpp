@@ -540,6 +540,10 @@ struct HostBackend {
   }
   void hist_get_s(int slot, Vec &v) const { v.assign(&S[(size_t)slot * n], &S[(size_t)slot * n] + n); }
   void hist_get_y(int slot, Vec &v) const { v.assign(&Y[(size_t)slot * n], &Y[(size_t)slot * n] + n); }
+  void hist_get_sy(int slot, Vec &s, Vec &y) const {
+    hist_get_s(slot, s);
+    hist_get_y(slot, y);
+  }
 
   // ---- compact-form direction (csrc/neo_lbfgs_dir.hpp): one entry per history slot, S'Y and Y'Y as m x m arrays
   struct SVec {
