@@ -659,7 +659,8 @@ __device__ __forceinline__ void thomas_factor(int M, const double (&Lo)[2][2], c
   // One step per joint: lane p forms D_p = Di_p - Lo_p E_{p-1}, inverts it and keeps N_p = D_p^-1, E_p = N_p Up_p.
   // The optimiser kernels run two wavefronts per SIMD and are bound by instruction issue more than by the length of
   // this chain, so the step is written for the fewest instructions: the reciprocal of the determinant is v_rcp_f64
-  // with two Newton steps (5 instructions, relative error below 2^-52; a correctly rounded division is 12), everything
+  // with two Newton steps (5 instructions; measured on gfx950, tools/probe/rcp_precision.hip: 4.6e-8 raw, 2.2e-15 after
+  // one step, 1.1e-16 after two; a correctly rounded division is 12 instructions), everything
   // is computed by lane p under its own exec mask straight into N and E, and only E travels to the next lane (8
   // v_readlane).  35 instructions a joint; carrying E as a fraction to keep the division out of the chain (the
   // round-1 form) cost 52 and two divisions after the loop.
