@@ -658,7 +658,10 @@ def main():
                        "launches_in_flight_per_gpu": n_lanes, "lane_groups": bool(a.lane_groups)},
             "rccl_ranks": rccl_ranks, "per_rank_traj_per_s": per_rank,
             "scaling_efficiency_vs_rank_mean": (value / (world * float(np.mean(per_rank)))) if per_rank else None,
-            "roofline": {"bound": "hbm", "kernel": "optimize_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm",
+                         "kernel": "optimize_group_kernel" if (a.lane_groups and M <= 16 and n <= 32 and a.layout != "cell8"
+                                                               and a.dtype == "f32") else "optimize_kernel",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": hbm_traffic(pm_o), "traffic_source": src_o,
                          "kernel_ms": kernel_ms, "launches": int(launches.value),
                          # `achieved` follows the contract: bytes of one launch / its average duration (HIP events).

@@ -477,8 +477,9 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
   if (kind == 0) return launch_opt_2d(c, D, f32, a);
   if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
   const int fl = c->params.flags;
-  if ((fl & NEO_FLAG_LANE_GROUPS) && f32 && layout == 0 && !a.slots && a.M <= 16 && D * (a.M - 1) + a.M <= 32)
-    return launch_opt_groups(c, elem, a);
+  if ((fl & NEO_FLAG_LANE_GROUPS) && f32 && (layout == NEO_LAYOUT_LINEAR || layout == NEO_LAYOUT_YZ4) && !a.slots &&
+      a.M <= 16 && D * (a.M - 1) + a.M <= 32)
+    return launch_opt_groups(c, elem, layout, a);
   // two trajectories per SIMD for calls that queue for the SIMDs anyway (3-D fields, fp32 sampling, the
   // n <= 128: beyond that the spills cost more than the sharing gains)
   const bool two = f32 && slots_for(a.M, D) <= NEO_W2_MAX_SLOTS &&

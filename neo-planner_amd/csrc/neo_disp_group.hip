@@ -35,7 +35,11 @@ int launch_group(neo_ctx *c, const OptArgs &a) {
   return launch_group_w<Real, LookupT, 16, 1>(c, a);
 }
 
-int launch_opt_groups(neo_ctx *c, int elem, const OptArgs &a) {
+int launch_opt_groups(neo_ctx *c, int elem, int layout, const OptArgs &a) {
+  if (layout == NEO_LAYOUT_YZ4) {
+    if (elem == NEO_F32) return launch_group<float, Lookup3D<float, float, 1>>(c, a);
+    return launch_group<float, Lookup3D<float, __half, 1>>(c, a);
+  }
   if (elem == NEO_F32) return launch_group<float, Lookup3D<float, float, 0>>(c, a);
   return launch_group<float, Lookup3D<float, __half, 0>>(c, a);
 }

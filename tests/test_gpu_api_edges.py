@@ -280,8 +280,10 @@ def test_lane_group_kernel_small_problems():
     from it the way any two fp32 evaluations of this objective do; the batch as a whole ends at the same costs.
     Results do not depend on which group of which wavefront picks a trajectory up."""
     dist = synth.esdf_3d(2, n=100, res=0.3)
-    g3 = npa.ESDF3D(dist, 0.3, synth.DOMAIN_ORIGIN, store="f32")
-    for M, B in ((3, 1001), (4, 130), (2, 64), (3, 1), (6, 200), (8, 65)):
+    g_lin = npa.ESDF3D(dist, 0.3, synth.DOMAIN_ORIGIN, store="f32")
+    g_yz4 = npa.ESDF3D(dist, 0.3, synth.DOMAIN_ORIGIN, store="f32", layout="yz4")
+    for M, B, g3 in ((3, 1001, g_lin), (3, 1001, g_yz4), (4, 130, g_lin), (2, 64, g_yz4), (3, 1, g_lin), (6, 200, g_yz4),
+                     (8, 65, g_lin)):
         head, tail, wp, ts = synth.replan_requests(4, B, M - 1, D=3, length_range=(4.0, 6.0))
         ref = npa.BatchPlanner(sample_dtype="f32")
         x0 = ref.pack_x(wp, ts)
@@ -308,8 +310,14 @@ def test_lane_group_kernel_small_problems():
     head, tail, wp, ts = synth.replan_requests(4, 40, 20, D=3)
     ref = npa.BatchPlanner(sample_dtype="f32")
     x0 = ref.pack_x(wp, ts)
-    a = ref.optimize(g3, x0, head, tail)
-    b = npa.BatchPlanner(sample_dtype="f32", lane_groups=True).optimize(g3, x0, head, tail)
+    a = ref.optimize(g_lin, x0, head, tail)
+    b = npa.BatchPlanner(sample_dtype="f32", lane_groups=True).optimize(g_lin, x0, head, tail)
+    assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["nfev"], b["nfev"])
+    # the two layouts hold the same numbers: the same sums in the same order
+    la = npa.BatchPlanner(sample_dtype="f32", lane_groups=True)
+    head, tail, wp, ts = synth.replan_requests(4, 256, 2, D=3, length_range=(4.0, 6.0))
+    x0 = la.pack_x(wp, ts)
+    a, b = la.optimize(g_lin, x0, head, tail, order=False), la.optimize(g_yz4, x0, head, tail, order=False)
     assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["nfev"], b["nfev"])
 
 
