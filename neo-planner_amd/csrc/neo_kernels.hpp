@@ -8,6 +8,7 @@
 // One 64-lane workgroup (= one wavefront) per trajectory: the optimiser never leaves the chip,
 // finished trajectories free their slot for the next ones, no host round trips.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
@@ -17,6 +18,9 @@
 #endif
 #ifndef NEO_COMPACT_DIRECTION
 #define NEO_COMPACT_DIRECTION 0
+#endif
+#ifndef NEO_PAIRS_F32
+#define NEO_PAIRS_F32 0
 #endif
 #ifndef NEO_W2_U
 #define NEO_W2_U 1  // (one sample per lane in flight: the two-waves variant then has no VGPR spills; 2 -> 7 % slower)
@@ -64,7 +68,10 @@ struct DevBackend {
   double *sc;    // LDS [2m]: rho / alpha of the two-loop recursion
   LineSearch *lsp;  // LDS: line-search state (wave-uniform)
   double *cst;      // LDS [12]: cost terms of the last evaluation / current x / previous x
-  double *hist;  // LDS [2][m][n]: the stored (s, y) pairs of this trajectory
+  // LDS [2][m][n]: the stored (s, y) pairs of this trajectory.  -DNEO_PAIRS_F32=1 (experiment): stored in fp32 by the
+  // fp32-sampling kernels (half the LDS: what a third wavefront per SIMD would need)
+  using Hist = std::conditional_t<(NEO_PAIRS_F32 != 0) && sizeof(Real) == 4, float, double>;
+  Hist *hist;
   int npad, m;
   double *coeff_out;  // optional [6M][D] (eval kernel)
   long long samples = 0;  // quadrature samples visited so far (lane-uniform), for the bench's byte count
@@ -121,29 +128,29 @@ struct DevBackend {
 #pragma unroll
     for (int k = 0; k < NS; ++k)
       if (in_range(k, lane)) {
-        hist[slot * t.n + k * kWave + lane] = s.v[k];
-        hist[(m + slot) * t.n + k * kWave + lane] = y.v[k];
+        hist[slot * t.n + k * kWave + lane] = (Hist)s.v[k];
+        hist[(m + slot) * t.n + k * kWave + lane] = (Hist)y.v[k];
       }
     lds_wave_sync();
   }
   __device__ __forceinline__ void hist_get(int row, Vec &v) const {
     const int lane = lane_id();
 #pragma unroll
-    for (int k = 0; k < NS; ++k) v.v[k] = in_range(k, lane) ? hist[row * t.n + k * kWave + lane] : 0.0;
+    for (int k = 0; k < NS; ++k) v.v[k] = in_range(k, lane) ? (double)hist[row * t.n + k * kWave + lane] : 0.0;
   }
   __device__ __forceinline__ void hist_get_s(int slot, Vec &v) const { hist_get(slot, v); }
   __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
   // s and y of one pair together: the partly filled last slot of both under ONE exec mask
   __device__ __forceinline__ void hist_get_sy(int slot, Vec &s, Vec &y) const {
     const int lane = lane_id();
-    const double *ps = hist + slot * t.n + lane, *py = hist + (m + slot) * t.n + lane;
+    const Hist *ps = hist + slot * t.n + lane, *py = hist + (m + slot) * t.n + lane;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       s.v[k] = 0.0;
       y.v[k] = 0.0;
       if (in_range(k, lane)) {
-        s.v[k] = ps[k * kWave];
-        y.v[k] = py[k * kWave];
+        s.v[k] = (double)ps[k * kWave];
+        y.v[k] = (double)py[k * kWave];
       }
     }
   }
@@ -174,7 +181,7 @@ struct DevBackend {
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
           const bool in = q * kWave + lane < t.n;
-          const double hv = in ? hist[row * t.n + q * kWave + lane] : 0.0;
+          const double hv = in ? (double)hist[row * t.n + q * kWave + lane] : 0.0;
           a += hv * v.v[q];
         }
         part[e] = a;
@@ -224,8 +231,8 @@ struct DevBackend {
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         const bool in = q * kWave + lane < t.n;
-        const double sv = in ? hist[k * t.n + q * kWave + lane] : 0.0;
-        const double yv = in ? hist[(m + k) * t.n + q * kWave + lane] : 0.0;
+        const double sv = in ? (double)hist[k * t.n + q * kWave + lane] : 0.0;
+        const double yv = in ? (double)hist[(m + k) * t.n + q * kWave + lane] : 0.0;
         d.v[q] += a * sv + b * yv;
       }
     }
@@ -492,7 +499,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
   load_boundary(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
   const int n = be.t.n;
   be.npad = NS * kWave;
-  be.hist = dyn_lds + stage;
+  be.hist = reinterpret_cast<typename BE::Hist *>(dyn_lds + stage);
   const int lane = lane_id();
   typename BE::Vec xv;
 #pragma unroll

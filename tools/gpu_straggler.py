@@ -13,7 +13,7 @@ grid = 300; res = 30.0 / grid
 # NEO_PLANAR=1: the round-1 workload (z = 2 m, no canopy); NEO_LAYOUT, NEO_WAVES (1 | 2): layout / register allocation
 planar = bool(os.environ.get("NEO_PLANAR"))
 dist = synth.esdf_3d(0, n=grid, res=res, canopy=0 if planar else 80)
-B, M, D = 4096, 21, 3
+B, M, D = 4096, int(os.environ.get("NEO_M", "21")), 3     # NEO_M: pieces (41 = cfg5's shape)
 head, tail, wp, ts = synth.replan_requests(0, B, M - 1, D=D, **({} if planar else synth.VOLUME))
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
