@@ -29,7 +29,7 @@
 #define NEO_W2_OCC 2  // wavefronts per SIMD the throughput variant is allocated for (experiments: 3)
 #endif
 #ifndef NEO_W2_MAX_SLOTS
-#define NEO_W2_MAX_SLOTS 2  // two waves per SIMD only up to n = 128 variables (M = 41: +5 % on an fp32 field, -2 % at cfg5)
+#define NEO_W2_MAX_SLOTS 4  // two waves per SIMD for every n <= 256 (four FLAT slots: with fp32 pairs, pairs_in_f32)
 #endif
 #include "neo_device.hpp"
 #include "neo_lbfgs.hpp"
@@ -51,7 +51,19 @@ __host__ __device__ constexpr int stage_doubles() {
 // ------------------------------------------------------------------ device backend of the optimiser
 // SU: samples per lane in flight in the sample loop (minco_sample)
 // LG: lane layout of the PIECE-layout phases -- WaveLanes (lane = piece) or WaveLanesPD<D> (lane = (piece, dimension))
-template <int D, int NS, typename Real, class MapT, class LookupT, int SU = NEO_FUSED_U, class LG = WaveLanes>
+// Storage of the L-BFGS pairs.  fp64, except in the two-waves fp32-sampling kernels with four FLAT slots (n > 128,
+// cfg5): their 2 * 10 * n doubles (25.8 KB at n = 161) leave room for six wavefronts per CU, in fp32 for eight -- measured
+// at cfg5: 119 k traj/s with one wavefront per SIMD, 105 k with two and fp64 pairs, 155 k with two and fp32 pairs,
+// mean nfev 336.7 against 337.5 and the same status histogram (the rounding of the pairs is well below what the fp32
+// gradient already carries).  -DNEO_PAIRS_F32=1 stores them in fp32 in every fp32-sampling kernel (experiment: the LDS
+// half of a third wavefront per SIMD).
+template <typename Real, int NS, int WAVES>
+__host__ __device__ constexpr bool pairs_in_f32() {
+  return sizeof(Real) == 4 && ((NEO_PAIRS_F32 != 0) || (WAVES == 2 && NS > 2));
+}
+// PAIRS32: the L-BFGS pairs are stored in fp32
+template <int D, int NS, typename Real, class MapT, class LookupT, int SU = NEO_FUSED_U, class LG = WaveLanes,
+          bool PAIRS32 = false>
 struct DevBackend {
   static constexpr int DL = LG::dl(D);
   // FLAT layout with NS slots: n <= 64 * NS
@@ -68,9 +80,8 @@ struct DevBackend {
   double *sc;    // LDS [2m]: rho / alpha of the two-loop recursion
   LineSearch *lsp;  // LDS: line-search state (wave-uniform)
   double *cst;      // LDS [12]: cost terms of the last evaluation / current x / previous x
-  // LDS [2][m][n]: the stored (s, y) pairs of this trajectory.  -DNEO_PAIRS_F32=1 (experiment): stored in fp32 by the
-  // fp32-sampling kernels (half the LDS: what a third wavefront per SIMD would need)
-  using Hist = std::conditional_t<(NEO_PAIRS_F32 != 0) && sizeof(Real) == 4, float, double>;
+  // LDS [2][m][n]: the stored (s, y) pairs of this trajectory
+  using Hist = std::conditional_t<PAIRS32, float, double>;
   Hist *hist;
   int npad, m;
   double *coeff_out;  // optional [6M][D] (eval kernel)
@@ -473,7 +484,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
   const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
   // the two-waves variant has half the registers: two samples per lane in flight instead of four (with the lean
   // Horner form, cfg2 with three batches in flight: 414 k -> 541 k traj/s; scratch 640 -> 336 B per lane)
-  using BE = DevBackend<D, NS, Real, MapT, LookupT, (WAVES == 2 ? NEO_W2_U : NEO_FUSED_U), LG>;
+  using BE = DevBackend<D, NS, Real, MapT, LookupT, (WAVES == 2 ? NEO_W2_U : NEO_FUSED_U), LG, pairs_in_f32<Real, NS, WAVES>()>;
   // a slot outside the table (a stale or foreign slot array): the trajectory is left untouched and flagged
   const int slot = scene_slot ? scene_slot[b] : 0;
   if (slot < 0 || slot >= nmaps) {

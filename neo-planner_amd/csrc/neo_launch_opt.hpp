@@ -8,14 +8,14 @@ namespace neo {
 template <int D, typename Real, class MapT, class LookupT, int WAVES = 1>
 int launch_opt(neo_ctx *c, const OptArgs &a) {
   const dim3 grid(a.B), blk(kWave);
-  const size_t pairs = (size_t)2 * NEO_LBFGS_M * (D * (a.M - 1) + a.M) *
-                       ((NEO_PAIRS_F32 != 0) && sizeof(Real) == 4 ? sizeof(float) : sizeof(double));  // L-BFGS pairs in LDS
+  const size_t pair_elems = (size_t)2 * NEO_LBFGS_M * (D * (a.M - 1) + a.M);  // L-BFGS pairs in LDS
   // staging in front of the pairs: the full size (with the rows of the per-piece fold) unless that costs the two-waves
   // variant occupancy -- eight wavefronts per CU want 160 KB / 8 each, less ~0.5 KB of static LDS.  The one-wave
   // variant follows the same rule so that both sum the partials in the same order (bit-identical results).
   const size_t lds_share = (size_t)160 * 1024 / 8 - 512;
 #define NEO_OPT_LG(NS, LG)                                                                                    \
   do {                                                                                                        \
+    const size_t pairs = pair_elems * (pairs_in_f32<Real, NS, WAVES>() ? sizeof(float) : sizeof(double));    \
     const int full = stage_doubles<D, NS, Real>(), small = NS * kWave;                                        \
     const int stage = pairs + (size_t)full * 8 <= lds_share ? full : small;                                   \
     hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES, LG>), grid, blk,                   \
