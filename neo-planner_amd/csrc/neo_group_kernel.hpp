@@ -160,7 +160,7 @@ struct GroupBackend {
 
 // grid = any number of wavefronts (the host sizes it to the chip); groups pull trajectories off *ticket
 #ifndef NEO_GRP_OCC
-#define NEO_GRP_OCC 2
+#define NEO_GRP_OCC 1  // (measured at cfg3: 12.2 M traj/s with the whole register file and no spills, 10.8 M at two per SIMD with ~110 spilled)
 #endif
 #ifndef NEO_GRP_U
 #define NEO_GRP_U 2
