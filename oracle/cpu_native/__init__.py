@@ -36,7 +36,7 @@ class Params(ctypes.Structure):
                 ("coll_tol", ctypes.c_double), ("ftol", ctypes.c_double), ("gtol", ctypes.c_double),
                 ("maxls", ctypes.c_int32), ("maxiter", ctypes.c_int32), ("maxfun", ctypes.c_int32),
                 ("stale_T", ctypes.c_int32), ("sample_f32", ctypes.c_int32), ("pad_", ctypes.c_int32),
-                ("coeff_eps", ctypes.c_double)]
+                ("coeff_eps", ctypes.c_double), ("grad_eps", ctypes.c_double)]
 
 
 class Map(ctypes.Structure):
@@ -78,7 +78,7 @@ def load():
     return _lib
 
 
-def make_params(cfg=None, stale_T=True, sample_f32=False, coeff_eps=0.0):
+def make_params(cfg=None, stale_T=True, sample_f32=False, coeff_eps=0.0, grad_eps=0.0):
     """cfg: anything with the PlannerConfig attribute names (oracle.minco_np.PlannerParams by default)"""
     if cfg is None:
         from oracle import minco_np
@@ -93,6 +93,7 @@ def make_params(cfg=None, stale_T=True, sample_f32=False, coeff_eps=0.0):
     p.stale_T = int(bool(stale_T))
     p.sample_f32 = int(bool(sample_f32))
     p.coeff_eps = float(coeff_eps)
+    p.grad_eps = float(grad_eps)
     return p
 
 

@@ -46,6 +46,7 @@ struct mc_params {
   int32_t sample_f32;   // control: sampled terms evaluated in fp32 arithmetic on fp32-rounded coefficients
   int32_t pad_;
   double coeff_eps;     // control: coefficients multiplied by (1 + coeff_eps * u), u in [-1, 1) hashed per entry/eval
+  double grad_eps;      // control: gradient entries multiplied by (1 + grad_eps * u) (what a low-precision adjoint does)
 };
 
 struct mc_map {
@@ -617,6 +618,8 @@ struct HostBackend {
     if (st) return st;
     for (int k = 0; k < 4; ++k) costs4[k] = pl.costs[k];
     st = pl.grad(x.data(), g.data());
+    if (pl.p.grad_eps != 0.0)
+      for (size_t i = 0; i < g.size(); ++i) g[i] *= 1.0 + pl.p.grad_eps * hash_unit(pl.evals * 7000003ull + i);
     return st;
   }
 };
