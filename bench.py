@@ -97,7 +97,8 @@ def parse(argv=None):
                     help="request batches (launches) per step; default 16 for cfg2, 4 for cfg5, 1 otherwise")
     ap.add_argument("--waypoints", type=int, default=20)
     ap.add_argument("--grid", type=int, default=300)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64", "f32x"],
+                    help="f32: fp32 sampled terms, fp64 solve and optimiser; f64: the parity mode; f32x: everything in fp32")
     ap.add_argument("--layout", default="yz4", choices=["linear", "yz4", "cell8"],
                     help="voxel order of the field in HBM (include/neo_planner.h NEO_LAYOUT_*); yz4 = one line per lookup")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall budget of the NumPy-port sample")
@@ -643,7 +644,7 @@ def main():
             "metric": "trajectories/sec (batched replan)", "value": value, "unit": "traj/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": a.dtype, "data": "synthetic",
+            "dtype": "f32" if a.dtype == "f32x" else a.dtype, "data": "synthetic",
             "config": {"workload": f"{a.config}: request batches of B={B} trajectories x {M - 1} waypoints (M={M} pieces, D=3, "
                                    f"n={n}), {n_sets} batch(es) per step per GPU, {n_scenes} x {a.grid}^3 {store} ESDF per GPU "
                                    f"(trilinear, layout {a.layout}; " +
@@ -653,14 +654,15 @@ def main():
                                    + ("; x0 from the initializer net (random weights) each launch" if init is not None else ""),
                        "batch_per_launch": B, "batches_per_step": n_sets, "trajectories_per_step_per_gpu": B * n_sets,
                        "pieces": M, "dims": D, "esdf_voxels": a.grid ** 3,
-                       "sampling_arithmetic": a.dtype, "solve_and_optimiser_arithmetic": "f64",
+                       "sampling_arithmetic": "f32" if a.dtype == "f32x" else a.dtype,
+                       "solve_and_optimiser_arithmetic": "f32" if a.dtype == "f32x" else "f64",
                        "parallelism": f"scene-sharded x{world}",
                        "launches_in_flight_per_gpu": n_lanes, "lane_groups": bool(a.lane_groups)},
             "rccl_ranks": rccl_ranks, "per_rank_traj_per_s": per_rank,
             "scaling_efficiency_vs_rank_mean": (value / (world * float(np.mean(per_rank)))) if per_rank else None,
             "roofline": {"bound": "hbm",
                          "kernel": "optimize_group_kernel" if (a.lane_groups and M <= 16 and n <= 32 and a.layout != "cell8"
-                                                               and a.dtype == "f32") else "optimize_kernel",
+                                                               and a.dtype in ("f32", "f32x")) else "optimize_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": hbm_traffic(pm_o), "traffic_source": src_o,
                          "kernel_ms": kernel_ms, "launches": int(launches.value),

@@ -112,6 +112,11 @@ typedef struct neo_params {
  * lanes each, for n <= 16; four of 16 lanes beyond.  Opt-in: a piece's samples are strided over fewer lanes, so sums associate differently
  * and results agree with the default kernel to fp32 rounding, not bit for bit. */
 #define NEO_FLAG_LANE_GROUPS 128
+/* all-fp32 evaluation (3-D fields, fp32 sampling): the coefficient solve, the adjoint pass and the optimiser's vectors
+ * and stored pairs in fp32 too, two wavefronts per SIMD.  Per evaluation the cost and gradient then agree with the
+ * fp64 solve to ~1e-5 instead of 2e-6; the optimiser's statistics (evaluations, final costs) are those of the default
+ * mode.  Opt-in throughput mode. */
+#define NEO_FLAG_F32_SOLVE 2048
 /* bits 1..16 switch phases off for timing experiments (tools/): leave them 0 */
 
 /* ---- lifetime ------------------------------------------------------------- */

@@ -480,6 +480,7 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
   if ((fl & NEO_FLAG_LANE_GROUPS) && f32 && (layout == NEO_LAYOUT_LINEAR || layout == NEO_LAYOUT_YZ4) && !a.slots &&
       a.M <= 16 && D * (a.M - 1) + a.M <= 32)
     return launch_opt_groups(c, elem, layout, a);
+  if ((fl & NEO_FLAG_F32_SOLVE) && f32) return launch_opt_3d_x(c, elem, layout, a);  // all-fp32 mode
   // two trajectories per SIMD for calls that queue for the SIMDs anyway (3-D fields, fp32 sampling; beyond n = 128 with
   // the pairs stored in fp32 so that eight wavefronts still fit a CU's LDS, neo_kernels.hpp pairs_in_f32)
   const bool two = f32 && slots_for(a.M, D) <= NEO_W2_MAX_SLOTS &&

@@ -73,6 +73,17 @@ __device__ __forceinline__ double rdlane(double v, int src /*wave-uniform*/) {
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float rdlane(float v, int src /*wave-uniform*/) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+// reciprocal to working precision: v_rcp_f64 (4.6e-8 raw on gfx950) with two Newton steps, v_rcp_f32 (1 ulp) as it is
+__device__ __forceinline__ double precise_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float precise_rcp(float d) { return __builtin_amdgcn_rcpf(d); }
 __device__ __forceinline__ double uniform(double v) {
   int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
   int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
@@ -204,6 +215,15 @@ __device__ __forceinline__ double wave_max_nonneg(double v) {
   v = fmax(v, dpp_any_d<0x143, 0xc>(v));
   return rdlane(v, 63);
 }
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  v = fmaxf(v, dpp_f<0x111>(v));
+  v = fmaxf(v, dpp_f<0x112>(v));
+  v = fmaxf(v, dpp_f<0x114>(v));
+  v = fmaxf(v, dpp_f<0x118>(v));
+  v = fmaxf(v, __int_as_float(dpp_any_i<0x142, 0xa>(__float_as_int(v))));
+  v = fmaxf(v, __int_as_float(dpp_any_i<0x143, 0xc>(__float_as_int(v))));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ int wave_max_nonneg(int v) {
   v = max(v, dpp_i<0x111>(v));
   v = max(v, dpp_i<0x112>(v));
@@ -220,6 +240,14 @@ __device__ __forceinline__ double from_prev(double v, double fill) {
 }
 __device__ __forceinline__ double from_next(double v, double fill) {
   const double o = dpp_d<0x130>(v);  // wave_shl:1
+  return lane_id() == kWave - 1 ? fill : o;
+}
+__device__ __forceinline__ float from_prev(float v, float fill) {
+  const float o = dpp_f<0x138>(v);
+  return lane_id() == 0 ? fill : o;
+}
+__device__ __forceinline__ float from_next(float v, float fill) {
+  const float o = dpp_f<0x130>(v);
   return lane_id() == kWave - 1 ? fill : o;
 }
 
@@ -508,6 +536,11 @@ struct WaveLanes {
   static __device__ __forceinline__ double sum(double v) { return wave_sum(v); }
   static __device__ __forceinline__ int sum(int v) { return wave_sum(v); }
   static __device__ __forceinline__ int any(int pred) { return __any(pred); }
+  static __device__ __forceinline__ float sum_dims(float v) { return v; }
+  static __device__ __forceinline__ float read(float v, int src) { return rdlane(v, src); }
+  static __device__ __forceinline__ float prev(float v, float fill) { return from_prev(v, fill); }
+  static __device__ __forceinline__ float next(float v, float fill) { return from_next(v, fill); }
+  static __device__ __forceinline__ float sum(float v) { return wave_sum(v); }
   static __host__ __device__ __forceinline__ int lanes_per_piece(int M);
 };
 
@@ -600,6 +633,27 @@ struct WaveLanesPD {
   static __device__ __forceinline__ double sum(double v) { return wave_sum(v); }
   static __device__ __forceinline__ int sum(int v) { return wave_sum(v); }
   static __device__ __forceinline__ int any(int pred) { return __any(pred); }
+  static __device__ __forceinline__ float read(float v, int q) { return rdlane(v, S * q); }
+  static __device__ __forceinline__ float prev(float v, float fill) {
+#pragma unroll
+    for (int k = 0; k < S; ++k) v = dpp_f<0x138>(v);
+    return lane_id() < S ? fill : v;
+  }
+  static __device__ __forceinline__ float next(float v, float fill) {
+#pragma unroll
+    for (int k = 0; k < S; ++k) v = dpp_f<0x130>(v);
+    return lane_id() >= kWave - S ? fill : v;
+  }
+  static __device__ __forceinline__ float sum(float v) { return wave_sum(v); }
+  static __device__ __forceinline__ float sum_dims(float v) {
+    float acc = v, t = v;
+#pragma unroll
+    for (int k = 1; k < S; ++k) {
+      t = dpp_f<0x130>(t);
+      acc += t;
+    }
+    return acc;
+  }
   // sum over the S lanes (dimensions) of a piece; valid in the piece's first lane
   static __device__ __forceinline__ double sum_dims(double v) {
     double acc = v, t = v;
@@ -630,18 +684,18 @@ __device__ __forceinline__ double bstate(const double *p, int k, int dl) {
 
 // ------------------------------------------------------------------ per-trajectory state
 // DL = dimensions held per lane: D (PIECE layout: lane = piece) or 1 (lane = (piece, dimension), WaveLanesPD)
-template <int D, int DL = D>
+template <int D, int DL = D, typename Num = double>
 struct Traj {
   // wave-uniform
   int M, n, nq, L;
   // PIECE layout (lane p < M; with DL = 1 every lane of the piece)
-  double T, tau;                  // tau: the decision variable on entry to minco_forward, exp(-tau) after it
-  double i1, i2, i3, i4;          // T^-1 .. T^-4
-  double P0[DL], P1[DL];          // positions at the start / end joint
-  double V0[DL], A0[DL], V1[DL], A1[DL];
-  double c[6][DL];                // polynomial coefficients
+  Num T, tau;                  // tau: the decision variable on entry to minco_forward, exp(-tau) after it
+  Num i1, i2, i3, i4;          // T^-1 .. T^-4
+  Num P0[DL], P1[DL];          // positions at the start / end joint
+  Num V0[DL], A0[DL], V1[DL], A1[DL];
+  Num c[6][DL];                // polynomial coefficients
   int ns;                         // samples of this piece: int(T / delta_t)
-  double N[2][2];                 // pivot-block inverse of the joint system (lane = joint)
+  Num N[2][2];                 // pivot-block inverse of the joint system (lane = joint)
   const double *head, *tail;      // boundary states [3][D] in global memory (wave-uniform scalar loads)
 };
 
@@ -653,9 +707,9 @@ struct Traj {
 // The transposed system of the adjoint pass reuses the same pivot inverses: the Schur complements of
 // K^T are the transposes of those of K, so its N is N^T and its E is N^T Lo_{p+1}^T -- no second
 // factorisation, no second set of divisions.
-template <class LG = WaveLanes>
-__device__ __forceinline__ void thomas_factor(int M, const double (&Lo)[2][2], const double (&Di)[2][2],
-                                              const double (&Up)[2][2], double (&N)[2][2], double (&E)[2][2]) {
+template <class LG = WaveLanes, typename Num = double>
+__device__ __forceinline__ void thomas_factor(int M, const Num (&Lo)[2][2], const Num (&Di)[2][2],
+                                              const Num (&Up)[2][2], Num (&N)[2][2], Num (&E)[2][2]) {
   // One step per joint: lane p forms D_p = Di_p - Lo_p E_{p-1}, inverts it and keeps N_p = D_p^-1, E_p = N_p Up_p.
   // The optimiser kernels run two wavefronts per SIMD and are bound by instruction issue more than by the length of
   // this chain, so the step is written for the fewest instructions: the reciprocal of the determinant is v_rcp_f64
@@ -668,19 +722,17 @@ __device__ __forceinline__ void thomas_factor(int M, const double (&Lo)[2][2], c
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) N[i][j] = E[i][j] = 0.0;  // lane 0: E_0 = 0; lanes outside 1..M-1 stay 0
+    for (int j = 0; j < 2; ++j) N[i][j] = E[i][j] = Num(0.0);  // lane 0: E_0 = 0; lanes outside 1..M-1 stay 0
   for (int p = 1; p < M; ++p) {
-    const double e00 = LG::read(E[0][0], p - 1), e01 = LG::read(E[0][1], p - 1);
-    const double e10 = LG::read(E[1][0], p - 1), e11 = LG::read(E[1][1], p - 1);
+    const Num e00 = LG::read(E[0][0], p - 1), e01 = LG::read(E[0][1], p - 1);
+    const Num e10 = LG::read(E[1][0], p - 1), e11 = LG::read(E[1][1], p - 1);
     if (lane == p) {
-      const double h00 = fma(-Lo[0][1], e10, fma(-Lo[0][0], e00, Di[0][0]));
-      const double h01 = fma(-Lo[0][1], e11, fma(-Lo[0][0], e01, Di[0][1]));
-      const double h10 = fma(-Lo[1][1], e10, fma(-Lo[1][0], e00, Di[1][0]));
-      const double h11 = fma(-Lo[1][1], e11, fma(-Lo[1][0], e01, Di[1][1]));
-      const double det = fma(h00, h11, -(h01 * h10));
-      double r = __builtin_amdgcn_rcp(det);
-      r = fma(fma(-det, r, 1.0), r, r);
-      r = fma(fma(-det, r, 1.0), r, r);
+      const Num h00 = fma(-Lo[0][1], e10, fma(-Lo[0][0], e00, Di[0][0]));
+      const Num h01 = fma(-Lo[0][1], e11, fma(-Lo[0][0], e01, Di[0][1]));
+      const Num h10 = fma(-Lo[1][1], e10, fma(-Lo[1][0], e00, Di[1][0]));
+      const Num h11 = fma(-Lo[1][1], e11, fma(-Lo[1][0], e01, Di[1][1]));
+      const Num det = fma(h00, h11, -(h01 * h10));
+      const Num r = precise_rcp(det);
       N[0][0] = h11 * r;
       N[0][1] = -h01 * r;
       N[1][0] = -h10 * r;
@@ -701,30 +753,30 @@ __device__ __forceinline__ void thomas_factor(int M, const double (&Lo)[2][2], c
 // prefix / suffix scans over the lanes: ceil(log2 M) steps, every lane busy, 10x shorter
 // dependent chain.  |A| < 1 for these diagonally dominant systems, so the products decay
 // (checked against the sequential sweep to 6e-15 over T in [0.5,5]^M, M <= 64).
-template <int DL, class LG = WaveLanes>
-__device__ __forceinline__ void thomas_solve(int M, const double (&Lo)[2][2], const double (&N)[2][2],
-                                             const double (&E)[2][2], const double (&R)[2][DL],
-                                             const double (&y0)[2][DL], const double (&yM)[2][DL],
-                                             double (&y)[2][DL]) {
+template <int DL, class LG = WaveLanes, typename Num = double>
+__device__ __forceinline__ void thomas_solve(int M, const Num (&Lo)[2][2], const Num (&N)[2][2],
+                                             const Num (&E)[2][2], const Num (&R)[2][DL],
+                                             const Num (&y0)[2][DL], const Num (&yM)[2][DL],
+                                             Num (&y)[2][DL]) {
   const int lane = LG::piece();
-  double A[2][2], b[2][DL];
+  Num A[2][2], b[2][DL];
   // ---- forward: lane 0 is the constant map v -> y_0
   {
     const bool in = lane >= 1 && lane < M;
-    A[0][0] = in ? -(N[0][0] * Lo[0][0] + N[0][1] * Lo[1][0]) : 0.0;
-    A[0][1] = in ? -(N[0][0] * Lo[0][1] + N[0][1] * Lo[1][1]) : 0.0;
-    A[1][0] = in ? -(N[1][0] * Lo[0][0] + N[1][1] * Lo[1][0]) : 0.0;
-    A[1][1] = in ? -(N[1][0] * Lo[0][1] + N[1][1] * Lo[1][1]) : 0.0;
+    A[0][0] = in ? -(N[0][0] * Lo[0][0] + N[0][1] * Lo[1][0]) : Num(0.0);
+    A[0][1] = in ? -(N[0][0] * Lo[0][1] + N[0][1] * Lo[1][1]) : Num(0.0);
+    A[1][0] = in ? -(N[1][0] * Lo[0][0] + N[1][1] * Lo[1][0]) : Num(0.0);
+    A[1][1] = in ? -(N[1][0] * Lo[0][1] + N[1][1] * Lo[1][1]) : Num(0.0);
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
-      const double r0 = N[0][0] * R[0][d] + N[0][1] * R[1][d];
-      const double r1 = N[1][0] * R[0][d] + N[1][1] * R[1][d];
-      b[0][d] = lane == 0 ? y0[0][d] : (in ? r0 : 0.0);
-      b[1][d] = lane == 0 ? y0[1][d] : (in ? r1 : 0.0);
+      const Num r0 = N[0][0] * R[0][d] + N[0][1] * R[1][d];
+      const Num r1 = N[1][0] * R[0][d] + N[1][1] * R[1][d];
+      b[0][d] = lane == 0 ? y0[0][d] : (in ? r0 : Num(0.0));
+      b[1][d] = lane == 0 ? y0[1][d] : (in ? r1 : Num(0.0));
     }
   }
   for (int s = 1; s < M; s <<= 1) {
-    double As[2][2], bs[2][DL];
+    Num As[2][2], bs[2][DL];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -735,13 +787,13 @@ __device__ __forceinline__ void thomas_solve(int M, const double (&Lo)[2][2], co
     if (lane >= s && lane < M) {
 #pragma unroll
       for (int d = 0; d < DL; ++d) {
-        const double n0 = A[0][0] * bs[0][d] + A[0][1] * bs[1][d] + b[0][d];
-        const double n1 = A[1][0] * bs[0][d] + A[1][1] * bs[1][d] + b[1][d];
+        const Num n0 = A[0][0] * bs[0][d] + A[0][1] * bs[1][d] + b[0][d];
+        const Num n1 = A[1][0] * bs[0][d] + A[1][1] * bs[1][d] + b[1][d];
         b[0][d] = n0;
         b[1][d] = n1;
       }
-      const double a00 = A[0][0] * As[0][0] + A[0][1] * As[1][0], a01 = A[0][0] * As[0][1] + A[0][1] * As[1][1];
-      const double a10 = A[1][0] * As[0][0] + A[1][1] * As[1][0], a11 = A[1][0] * As[0][1] + A[1][1] * As[1][1];
+      const Num a00 = A[0][0] * As[0][0] + A[0][1] * As[1][0], a01 = A[0][0] * As[0][1] + A[0][1] * As[1][1];
+      const Num a10 = A[1][0] * As[0][0] + A[1][1] * As[1][0], a11 = A[1][0] * As[0][1] + A[1][1] * As[1][1];
       A[0][0] = a00; A[0][1] = a01; A[1][0] = a10; A[1][1] = a11;
     }
   }
@@ -755,13 +807,13 @@ __device__ __forceinline__ void thomas_solve(int M, const double (&Lo)[2][2], co
         b[1][d] -= E[1][0] * yM[0][d] + E[1][1] * yM[1][d];
       }
     }
-    A[0][0] = in ? -E[0][0] : 0.0;
-    A[0][1] = in ? -E[0][1] : 0.0;
-    A[1][0] = in ? -E[1][0] : 0.0;
-    A[1][1] = in ? -E[1][1] : 0.0;
+    A[0][0] = in ? -E[0][0] : Num(0.0);
+    A[0][1] = in ? -E[0][1] : Num(0.0);
+    A[1][0] = in ? -E[1][0] : Num(0.0);
+    A[1][1] = in ? -E[1][1] : Num(0.0);
   }
   for (int s = 1; s < M; s <<= 1) {
-    double As[2][2], bs[2][DL];
+    Num As[2][2], bs[2][DL];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -772,13 +824,13 @@ __device__ __forceinline__ void thomas_solve(int M, const double (&Lo)[2][2], co
     if (lane >= 1 && lane + s <= M - 1) {
 #pragma unroll
       for (int d = 0; d < DL; ++d) {
-        const double n0 = A[0][0] * bs[0][d] + A[0][1] * bs[1][d] + b[0][d];
-        const double n1 = A[1][0] * bs[0][d] + A[1][1] * bs[1][d] + b[1][d];
+        const Num n0 = A[0][0] * bs[0][d] + A[0][1] * bs[1][d] + b[0][d];
+        const Num n1 = A[1][0] * bs[0][d] + A[1][1] * bs[1][d] + b[1][d];
         b[0][d] = n0;
         b[1][d] = n1;
       }
-      const double a00 = A[0][0] * As[0][0] + A[0][1] * As[1][0], a01 = A[0][0] * As[0][1] + A[0][1] * As[1][1];
-      const double a10 = A[1][0] * As[0][0] + A[1][1] * As[1][0], a11 = A[1][0] * As[0][1] + A[1][1] * As[1][1];
+      const Num a00 = A[0][0] * As[0][0] + A[0][1] * As[1][0], a01 = A[0][0] * As[0][1] + A[0][1] * As[1][1];
+      const Num a10 = A[1][0] * As[0][0] + A[1][1] * As[1][0], a11 = A[1][0] * As[0][1] + A[1][1] * As[1][1];
       A[0][0] = a00; A[0][1] = a01; A[1][0] = a10; A[1][1] = a11;
     }
   }
@@ -791,21 +843,21 @@ __device__ __forceinline__ void thomas_solve(int M, const double (&Lo)[2][2], co
 
 // joint-system blocks of lane p (joint p between piece p-1 "a" and piece p "b")
 // (a1..a3 = T^-1..T^-3 of piece p-1, fetched from the neighbour lane by the caller)
-template <class TrajT>
-__device__ __forceinline__ void joint_blocks(const TrajT &t, double a1, double a2, double a3,
-                                             double (&Lo)[2][2], double (&Di)[2][2], double (&Up)[2][2]) {
-  Lo[0][0] = -24.0 * a2;  Lo[0][1] = -3.0 * a1;
-  Lo[1][0] = -168.0 * a3; Lo[1][1] = -24.0 * a2;
-  Di[0][0] = -36.0 * a2 + 36.0 * t.i2;    Di[0][1] = 9.0 * a1 + 9.0 * t.i1;
-  Di[1][0] = -192.0 * a3 - 192.0 * t.i3;  Di[1][1] = 36.0 * a2 - 36.0 * t.i2;
-  Up[0][0] = 24.0 * t.i2;   Up[0][1] = -3.0 * t.i1;
-  Up[1][0] = -168.0 * t.i3; Up[1][1] = 24.0 * t.i2;
+template <class TrajT, typename Num>
+__device__ __forceinline__ void joint_blocks(const TrajT &t, Num a1, Num a2, Num a3,
+                                             Num (&Lo)[2][2], Num (&Di)[2][2], Num (&Up)[2][2]) {
+  Lo[0][0] = -Num(24.0) * a2;  Lo[0][1] = -Num(3.0) * a1;
+  Lo[1][0] = -Num(168.0) * a3; Lo[1][1] = -Num(24.0) * a2;
+  Di[0][0] = -Num(36.0) * a2 + Num(36.0) * t.i2;    Di[0][1] = Num(9.0) * a1 + Num(9.0) * t.i1;
+  Di[1][0] = -Num(192.0) * a3 - Num(192.0) * t.i3;  Di[1][1] = Num(36.0) * a2 - Num(36.0) * t.i2;
+  Up[0][0] = Num(24.0) * t.i2;   Up[0][1] = -Num(3.0) * t.i1;
+  Up[1][0] = -Num(168.0) * t.i3; Up[1][1] = Num(24.0) * t.i2;
 }
 
 // forward pass.  Inputs (PIECE layout): t.tau, t.P0, t.P1 set by the caller, head/tail uniform.
 // Returns 0 or NUMERIC_RANGE (4) when exp(-tau) overflows like math.exp does (:481).
-template <int D, class LG = WaveLanes>
-__device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D)> &t, const DevParams &prm, double &energy,
+template <int D, class LG = WaveLanes, typename Num = double>
+__device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const DevParams &prm, double &energy,
                                              double &time_sum) {
   constexpr int DL = LG::dl(D);
   const int lane = LG::piece();
@@ -813,76 +865,76 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D)> &t, const DevPar
   int bad = 0;
   // map_tau2T (:477-483)
   {
-    const double tau = act ? t.tau : 0.0;
-    if (-tau > 709.782712893384) bad = 1;
-    const double ex = exp(-tau);
-    t.T = (prm.T_max - prm.T_min) / (1.0 + ex) + prm.T_min;
+    const Num tau = act ? t.tau : Num(0.0);
+    if (-tau > Num(709.782712893384)) bad = 1;
+    const Num ex = exp(-tau);
+    t.T = (Num(prm.T_max) - Num(prm.T_min)) / (Num(1.0) + ex) + Num(prm.T_min);
     t.tau = ex;  // get_grad_T2tau needs exp(-tau) again (:490): keep it instead of tau
   }
   if (LG::any(bad)) return 4;
-  t.i1 = 1.0 / t.T;
+  t.i1 = Num(1.0) / t.T;
   t.i2 = t.i1 * t.i1;
   t.i3 = t.i2 * t.i1;
   t.i4 = t.i2 * t.i2;
-  t.ns = act ? (int)(t.T / prm.delta_t) : 0;  // int(T / delta_t) (:401)
+  t.ns = act ? (int)(t.T / Num(prm.delta_t)) : 0;  // int(T / delta_t) (:401)
 
   if (t.M > 1) {
-    double Lo[2][2], Di[2][2], Up[2][2], E[2][2], R[2][DL], y0[2][DL], yM[2][DL], y[2][DL];
-    const double a1 = LG::prev(t.i1, 1.0), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;
+    Num Lo[2][2], Di[2][2], Up[2][2], E[2][2], R[2][DL], y0[2][DL], yM[2][DL], y[2][DL];
+    const Num a1 = LG::prev(t.i1, Num(1.0)), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;
     joint_blocks(t, a1, a2, a3, Lo, Di, Up);
-    thomas_factor<LG>((prm.dbg & (2 | 8)) ? 1 : t.M, Lo, Di, Up, t.N, E);
+    thomas_factor<LG, Num>((prm.dbg & (2 | 8)) ? 1 : t.M, Lo, Di, Up, t.N, E);
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
       // displacement of piece p-1 and of piece p
-      const double dPb = t.P1[d] - t.P0[d];
-      const double dPa = LG::prev(dPb, 0.0);
-      R[0][d] = -(60.0 * a3 * dPa - 60.0 * t.i3 * dPb);
-      R[1][d] = -(360.0 * a4 * dPa + 360.0 * t.i4 * dPb);
-      y0[0][d] = bstate<D, LG>(t.head, 1, d);
-      y0[1][d] = bstate<D, LG>(t.head, 2, d);
-      yM[0][d] = bstate<D, LG>(t.tail, 1, d);
-      yM[1][d] = bstate<D, LG>(t.tail, 2, d);
+      const Num dPb = t.P1[d] - t.P0[d];
+      const Num dPa = LG::prev(dPb, Num(0.0));
+      R[0][d] = -(Num(60.0) * a3 * dPa - Num(60.0) * t.i3 * dPb);
+      R[1][d] = -(Num(360.0) * a4 * dPa + Num(360.0) * t.i4 * dPb);
+      y0[0][d] = (Num)bstate<D, LG>(t.head, 1, d);
+      y0[1][d] = (Num)bstate<D, LG>(t.head, 2, d);
+      yM[0][d] = (Num)bstate<D, LG>(t.tail, 1, d);
+      yM[1][d] = (Num)bstate<D, LG>(t.tail, 2, d);
     }
-    thomas_solve<DL, LG>((prm.dbg & (2 | 16)) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);
+    thomas_solve<DL, LG, Num>((prm.dbg & (2 | 16)) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
-      t.V0[d] = lane == 0 ? bstate<D, LG>(t.head, 1, d) : y[0][d];
-      t.A0[d] = lane == 0 ? bstate<D, LG>(t.head, 2, d) : y[1][d];
+      t.V0[d] = lane == 0 ? (Num)bstate<D, LG>(t.head, 1, d) : y[0][d];
+      t.A0[d] = lane == 0 ? (Num)bstate<D, LG>(t.head, 2, d) : y[1][d];
     }
   } else {
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
-      t.V0[d] = bstate<D, LG>(t.head, 1, d);
-      t.A0[d] = bstate<D, LG>(t.head, 2, d);
+      t.V0[d] = (Num)bstate<D, LG>(t.head, 1, d);
+      t.A0[d] = (Num)bstate<D, LG>(t.head, 2, d);
     }
   }
 #pragma unroll
   for (int d = 0; d < DL; ++d) {
-    const double v1 = LG::next(t.V0[d], 0.0), a1 = LG::next(t.A0[d], 0.0);
-    t.V1[d] = (lane == t.M - 1) ? bstate<D, LG>(t.tail, 1, d) : v1;
-    t.A1[d] = (lane == t.M - 1) ? bstate<D, LG>(t.tail, 2, d) : a1;
+    const Num v1 = LG::next(t.V0[d], Num(0.0)), a1 = LG::next(t.A0[d], Num(0.0));
+    t.V1[d] = (lane == t.M - 1) ? (Num)bstate<D, LG>(t.tail, 1, d) : v1;
+    t.A1[d] = (lane == t.M - 1) ? (Num)bstate<D, LG>(t.tail, 2, d) : a1;
   }
   // Hermite form of the quintic
-  double e = 0.0;
-  const double T = t.T, T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
+  Num e = Num(0.0);
+  const Num T = t.T, T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
 #pragma unroll
   for (int d = 0; d < DL; ++d) {
-    const double ep = t.P1[d] - t.P0[d] - T * t.V0[d] - 0.5 * T2 * t.A0[d];
-    const double ev = t.V1[d] - t.V0[d] - T * t.A0[d];
-    const double ea = t.A1[d] - t.A0[d];
+    const Num ep = t.P1[d] - t.P0[d] - T * t.V0[d] - Num(0.5) * T2 * t.A0[d];
+    const Num ev = t.V1[d] - t.V0[d] - T * t.A0[d];
+    const Num ea = t.A1[d] - t.A0[d];
     t.c[0][d] = t.P0[d];
     t.c[1][d] = t.V0[d];
-    t.c[2][d] = 0.5 * t.A0[d];
-    t.c[3][d] = (10.0 * ep - 4.0 * T * ev + 0.5 * T2 * ea) * t.i3;
-    t.c[4][d] = (-15.0 * ep + 7.0 * T * ev - T2 * ea) * t.i4;
-    t.c[5][d] = (6.0 * ep - 3.0 * T * ev + 0.5 * T2 * ea) * t.i4 * t.i1;
+    t.c[2][d] = Num(0.5) * t.A0[d];
+    t.c[3][d] = (Num(10.0) * ep - Num(4.0) * T * ev + Num(0.5) * T2 * ea) * t.i3;
+    t.c[4][d] = (-Num(15.0) * ep + Num(7.0) * T * ev - T2 * ea) * t.i4;
+    t.c[5][d] = (Num(6.0) * ep - Num(3.0) * T * ev + Num(0.5) * T2 * ea) * t.i4 * t.i1;
     // add_energy_cost (:345-359): c^T Q(T) c with the closed-form jerk Gram matrix
-    const double c3 = t.c[3][d], c4 = t.c[4][d], c5 = t.c[5][d];
-    e += 36.0 * T * c3 * c3 + 144.0 * T2 * c3 * c4 + 240.0 * T3 * c3 * c5 + 192.0 * T3 * c4 * c4 +
-         720.0 * T4 * c4 * c5 + 720.0 * T5 * c5 * c5;
+    const Num c3 = t.c[3][d], c4 = t.c[4][d], c5 = t.c[5][d];
+    e += Num(36.0) * T * c3 * c3 + Num(144.0) * T2 * c3 * c4 + Num(240.0) * T3 * c3 * c5 + Num(192.0) * T3 * c4 * c4 +
+         Num(720.0) * T4 * c4 * c5 + Num(720.0) * T5 * c5 * c5;
   }
-  energy = LG::sum(act ? e : 0.0);
-  time_sum = LG::sum((act && LG::dim0() == 0) ? t.T : 0.0);  // add_time_cost (:386-387): once per piece
+  energy = LG::sum(act ? e : Num(0.0));
+  time_sum = LG::sum((act && LG::dim0() == 0) ? t.T : Num(0.0));  // add_time_cost (:386-387): once per piece
   return 0;
 }
 
@@ -1320,65 +1372,65 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
 // Returns 0, or 4 where the reference would leave through OverflowError: it raises Python floats to
 // a power in two places, `(np.dot(c, beta3).item())**2` (:382) and `(1+math.exp(-tau))**2` (:490),
 // and Python raises once such a result exceeds the double range instead of returning inf.
-template <int D, class LG = WaveLanes>
-__device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D)> &t, const DevParams &prm,
-                                              double (&gC)[6][LG::dl(D)], double gT, double (&gq)[LG::dl(D)], double &gtau) {
+template <int D, class LG = WaveLanes, typename Num = double>
+__device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D), Num> &t, const DevParams &prm,
+                                              Num (&gC)[6][LG::dl(D)], Num gT, Num (&gq)[LG::dl(D)], Num &gtau) {
   constexpr int DL = LG::dl(D);
   const int lane = LG::piece();
   const int M = t.M;
   int pow_overflow = 0;
-  const double a1 = LG::prev(t.i1, 1.0), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;  // piece p-1
-  const double T = t.T, T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
-  const double w0 = prm.w[0];
-  double jerk_end[DL], snap_end[DL], crackle[DL];
+  const Num a1 = LG::prev(t.i1, Num(1.0)), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;  // piece p-1
+  const Num T = t.T, T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
+  const Num w0 = Num(prm.w[0]);
+  Num jerk_end[DL], snap_end[DL], crackle[DL];
   // add_energy_grad_CT (:361-384), add_time_grad_CT (:389-390)
   // (gT: the sampled partial and the time weight enter once per piece -- in the lane of its first dimension)
-  gT = (LG::dim0() == 0) ? gT + prm.w[1] : 0.0;
+  gT = (LG::dim0() == 0) ? gT + Num(prm.w[1]) : Num(0.0);
 #pragma unroll
   for (int d = 0; d < DL; ++d) {
-    const double c3 = t.c[3][d], c4 = t.c[4][d], c5 = t.c[5][d];
-    gC[3][d] += 2.0 * w0 * (36.0 * T * c3 + 72.0 * T2 * c4 + 120.0 * T3 * c5);
-    gC[4][d] += 2.0 * w0 * (72.0 * T2 * c3 + 192.0 * T3 * c4 + 360.0 * T4 * c5);
-    gC[5][d] += 2.0 * w0 * (120.0 * T3 * c3 + 360.0 * T4 * c4 + 720.0 * T5 * c5);
-    jerk_end[d] = 6.0 * c3 + 24.0 * T * c4 + 60.0 * T2 * c5;
-    snap_end[d] = 24.0 * c4 + 120.0 * T * c5;
-    crackle[d] = 120.0 * c5;
-    if (lane < M && fabs(jerk_end[d]) > 1.3407807929942596e154) pow_overflow = 1;  // sqrt(DBL_MAX)
+    const Num c3 = t.c[3][d], c4 = t.c[4][d], c5 = t.c[5][d];
+    gC[3][d] += Num(2.0) * w0 * (Num(36.0) * T * c3 + Num(72.0) * T2 * c4 + Num(120.0) * T3 * c5);
+    gC[4][d] += Num(2.0) * w0 * (Num(72.0) * T2 * c3 + Num(192.0) * T3 * c4 + Num(360.0) * T4 * c5);
+    gC[5][d] += Num(2.0) * w0 * (Num(120.0) * T3 * c3 + Num(360.0) * T4 * c4 + Num(720.0) * T5 * c5);
+    jerk_end[d] = Num(6.0) * c3 + Num(24.0) * T * c4 + Num(60.0) * T2 * c5;
+    snap_end[d] = Num(24.0) * c4 + Num(120.0) * T * c5;
+    crackle[d] = Num(120.0) * c5;
+    if (lane < M && fabs(jerk_end[d]) > Num(1.3407807929942596e154)) pow_overflow = 1;  // sqrt(DBL_MAX)
     gT += w0 * jerk_end[d] * jerk_end[d];
   }
   // gz = H(T)^T gC : sensitivity wrt the end states Z = (p0, v0, a0, p1, v1, a1)
-  double gz[6][DL];
+  Num gz[6][DL];
 #pragma unroll
   for (int d = 0; d < DL; ++d) {
-    const double gep = 10.0 * gC[3][d] * t.i3 - 15.0 * gC[4][d] * t.i4 + 6.0 * gC[5][d] * t.i4 * t.i1;
-    const double gev = -4.0 * gC[3][d] * t.i2 + 7.0 * gC[4][d] * t.i3 - 3.0 * gC[5][d] * t.i4;
-    const double gea = 0.5 * gC[3][d] * t.i1 - gC[4][d] * t.i2 + 0.5 * gC[5][d] * t.i3;
+    const Num gep = Num(10.0) * gC[3][d] * t.i3 - Num(15.0) * gC[4][d] * t.i4 + Num(6.0) * gC[5][d] * t.i4 * t.i1;
+    const Num gev = -Num(4.0) * gC[3][d] * t.i2 + Num(7.0) * gC[4][d] * t.i3 - Num(3.0) * gC[5][d] * t.i4;
+    const Num gea = Num(0.5) * gC[3][d] * t.i1 - gC[4][d] * t.i2 + Num(0.5) * gC[5][d] * t.i3;
     gz[0][d] = gC[0][d] - gep;
     gz[1][d] = gC[1][d] - T * gep - gev;
-    gz[2][d] = 0.5 * gC[2][d] - 0.5 * T2 * gep - T * gev - gea;
+    gz[2][d] = Num(0.5) * gC[2][d] - Num(0.5) * T2 * gep - T * gev - gea;
     gz[3][d] = gep;
     gz[4][d] = gev;
     gz[5][d] = gea;
   }
   // S_p = dW/d(state of joint p) = gz_{p-1}[3:6] + gz_p[0:3]   (lanes 1..M-1)
-  double S[3][DL];
+  Num S[3][DL];
 #pragma unroll
   for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int d = 0; d < DL; ++d) S[k][d] = LG::prev(gz[3 + k][d], 0.0) + gz[k][d];
+    for (int d = 0; d < DL; ++d) S[k][d] = LG::prev(gz[3 + k][d], Num(0.0)) + gz[k][d];
 
-  double lam[2][DL];
+  Num lam[2][DL];
 #pragma unroll
-  for (int d = 0; d < DL; ++d) lam[0][d] = lam[1][d] = 0.0;
+  for (int d = 0; d < DL; ++d) lam[0][d] = lam[1][d] = Num(0.0);
   if (M > 1) {
     // transposed system: row p of K^T has Up_{p-1}^T, Di_p^T, Lo_{p+1}^T; pivot inverses are N^T
-    double LoT[2][2], NT[2][2], ET[2][2], R[2][DL], z0[2][DL], y[2][DL];
-    LoT[0][0] = 24.0 * a2;  LoT[0][1] = -168.0 * a3;   // Up_{p-1}^T (piece p-1 = "a")
-    LoT[1][0] = -3.0 * a1;  LoT[1][1] = 24.0 * a2;
+    Num LoT[2][2], NT[2][2], ET[2][2], R[2][DL], z0[2][DL], y[2][DL];
+    LoT[0][0] = Num(24.0) * a2;  LoT[0][1] = -Num(168.0) * a3;   // Up_{p-1}^T (piece p-1 = "a")
+    LoT[1][0] = -Num(3.0) * a1;  LoT[1][1] = Num(24.0) * a2;
     NT[0][0] = t.N[0][0]; NT[0][1] = t.N[1][0]; NT[1][0] = t.N[0][1]; NT[1][1] = t.N[1][1];
     {
-      const double u00 = -24.0 * t.i2, u01 = -168.0 * t.i3;  // Lo_{p+1}^T (piece p = "b")
-      const double u10 = -3.0 * t.i1, u11 = -24.0 * t.i2;
+      const Num u00 = -Num(24.0) * t.i2, u01 = -Num(168.0) * t.i3;  // Lo_{p+1}^T (piece p = "b")
+      const Num u10 = -Num(3.0) * t.i1, u11 = -Num(24.0) * t.i2;
       ET[0][0] = NT[0][0] * u00 + NT[0][1] * u10;
       ET[0][1] = NT[0][0] * u01 + NT[0][1] * u11;
       ET[1][0] = NT[1][0] * u00 + NT[1][1] * u10;
@@ -1388,75 +1440,75 @@ __device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D)> &t, const
     for (int d = 0; d < DL; ++d) {
       R[0][d] = S[1][d];
       R[1][d] = S[2][d];
-      z0[0][d] = z0[1][d] = 0.0;
+      z0[0][d] = z0[1][d] = Num(0.0);
     }
-    thomas_solve<DL, LG>((prm.dbg & (2 | 16)) ? 1 : M, LoT, NT, ET, R, z0, z0, y);
+    thomas_solve<DL, LG, Num>((prm.dbg & (2 | 16)) ? 1 : M, LoT, NT, ET, R, z0, z0, y);
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
-      lam[0][d] = (lane >= 1 && lane < M) ? y[0][d] : 0.0;
-      lam[1][d] = (lane >= 1 && lane < M) ? y[1][d] : 0.0;
+      lam[0][d] = (lane >= 1 && lane < M) ? y[0][d] : Num(0.0);
+      lam[1][d] = (lane >= 1 && lane < M) ? y[1][d] : Num(0.0);
     }
   }
   // dW/dq: G[6i+3] of the reference (:506-508)
-  double Gt[3][DL];  // sensitivity wrt the tail state (lane M-1), = G[-3:] of the reference
+  Num Gt[3][DL];  // sensitivity wrt the tail state (lane M-1), = G[-3:] of the reference
 #pragma unroll
   for (int d = 0; d < DL; ++d) {
-    const double l1 = lam[0][d], l2 = lam[1][d];
-    const double dp_prev = -60.0 * a3 * l1 - 360.0 * a4 * l2;
-    const double dp_here = (60.0 * a3 + 60.0 * t.i3) * l1 + (360.0 * a4 - 360.0 * t.i4) * l2;
-    const double dp_next = -60.0 * t.i3 * l1 + 360.0 * t.i4 * l2;
-    const double from_left = LG::prev(dp_next, 0.0);   // joint p-1 pushes on p_{p}
-    const double from_right = LG::next(dp_prev, 0.0);  // joint p+1 pushes on p_{p}
-    gq[d] = S[0][d] - dp_here - (lane >= 2 ? from_left : 0.0) - (lane + 1 <= M - 1 ? from_right : 0.0);
+    const Num l1 = lam[0][d], l2 = lam[1][d];
+    const Num dp_prev = -Num(60.0) * a3 * l1 - Num(360.0) * a4 * l2;
+    const Num dp_here = (Num(60.0) * a3 + Num(60.0) * t.i3) * l1 + (Num(360.0) * a4 - Num(360.0) * t.i4) * l2;
+    const Num dp_next = -Num(60.0) * t.i3 * l1 + Num(360.0) * t.i4 * l2;
+    const Num from_left = LG::prev(dp_next, Num(0.0));   // joint p-1 pushes on p_{p}
+    const Num from_right = LG::next(dp_prev, Num(0.0));  // joint p+1 pushes on p_{p}
+    gq[d] = S[0][d] - dp_here - (lane >= 2 ? from_left : Num(0.0)) - (lane + 1 <= M - 1 ? from_right : Num(0.0));
     // tail sensitivity on lane M-1: S_M = gz[3:6] of the last piece, minus joint M-1's pull
-    const double lt1 = (M > 1) ? l1 : 0.0, lt2 = (M > 1) ? l2 : 0.0;
-    Gt[0][d] = gz[3][d] - (-60.0 * t.i3 * lt1 + 360.0 * t.i4 * lt2);
-    Gt[1][d] = gz[4][d] - (24.0 * t.i2 * lt1 - 168.0 * t.i3 * lt2);
-    Gt[2][d] = gz[5][d] - (-3.0 * t.i1 * lt1 + 24.0 * t.i2 * lt2);
+    const Num lt1 = (M > 1) ? l1 : Num(0.0), lt2 = (M > 1) ? l2 : Num(0.0);
+    Gt[0][d] = gz[3][d] - (-Num(60.0) * t.i3 * lt1 + Num(360.0) * t.i4 * lt2);
+    Gt[1][d] = gz[4][d] - (Num(24.0) * t.i2 * lt1 - Num(168.0) * t.i3 * lt2);
+    Gt[2][d] = gz[5][d] - (-Num(3.0) * t.i1 * lt1 + Num(24.0) * t.i2 * lt2);
   }
   // dW/dT (:511-533)
-  double gTt = gT;
+  Num gTt = gT;
 #pragma unroll
   for (int d = 0; d < DL; ++d) {
-    const double v1 = t.V1[d], a1 = t.A1[d], je = jerk_end[d];
+    const Num v1 = t.V1[d], a1 = t.A1[d], je = jerk_end[d];
     gTt -= gz[3][d] * v1 + gz[4][d] * a1 + gz[5][d] * je;
     // joint p+1 (this piece ends there): rows +je.Z, +se.Z
-    const double ln1 = LG::next(lam[0][d], 0.0), ln2 = LG::next(lam[1][d], 0.0);
+    const Num ln1 = LG::next(lam[0][d], Num(0.0)), ln2 = LG::next(lam[1][d], Num(0.0));
     if (lane + 1 <= M - 1) {
-      const double d_je = snap_end[d] - (60.0 * t.i3 * v1 - 36.0 * t.i2 * a1 + 9.0 * t.i1 * je);
-      const double d_se = crackle[d] - (360.0 * t.i4 * v1 - 192.0 * t.i3 * a1 + 36.0 * t.i2 * je);
+      const Num d_je = snap_end[d] - (Num(60.0) * t.i3 * v1 - Num(36.0) * t.i2 * a1 + Num(9.0) * t.i1 * je);
+      const Num d_se = crackle[d] - (Num(360.0) * t.i4 * v1 - Num(192.0) * t.i3 * a1 + Num(36.0) * t.i2 * je);
       gTt -= ln1 * d_je + ln2 * d_se;
     }
     // joint p (this piece starts there): rows -js.Z, -ss.Z
     if (lane >= 1) {
-      const double d_js = -(60.0 * t.i3 * v1 - 24.0 * t.i2 * a1 + 3.0 * t.i1 * je);
-      const double d_ss = -(-360.0 * t.i4 * v1 + 168.0 * t.i3 * a1 - 24.0 * t.i2 * je);
+      const Num d_js = -(Num(60.0) * t.i3 * v1 - Num(24.0) * t.i2 * a1 + Num(3.0) * t.i1 * je);
+      const Num d_ss = -(-Num(360.0) * t.i4 * v1 + Num(168.0) * t.i3 * a1 - Num(24.0) * t.i2 * je);
       gTt += lam[0][d] * d_js + lam[1][d] * d_ss;
     }
   }
   // the reference evaluates the tail rows' d/dT with the previous piece's duration (:528-533)
   {
-    const double Ts = LG::prev(T, T);
+    const Num Ts = LG::prev(T, T);
     if (prm.stale_T && M >= 2 && lane == M - 1) {
-      const double S2 = Ts * Ts, S3 = S2 * Ts, S4 = S2 * S2;
+      const Num S2 = Ts * Ts, S3 = S2 * Ts, S4 = S2 * S2;
 #pragma unroll
       for (int d = 0; d < DL; ++d) {
-        const double c1 = t.c[1][d], c2 = t.c[2][d], c3 = t.c[3][d], c4 = t.c[4][d], c5 = t.c[5][d];
-        const double velL = c1 + 2.0 * T * c2 + 3.0 * T2 * c3 + 4.0 * T3 * c4 + 5.0 * T4 * c5;
-        const double velS = c1 + 2.0 * Ts * c2 + 3.0 * S2 * c3 + 4.0 * S3 * c4 + 5.0 * S4 * c5;
-        const double accL = 2.0 * c2 + 6.0 * T * c3 + 12.0 * T2 * c4 + 20.0 * T3 * c5;
-        const double accS = 2.0 * c2 + 6.0 * Ts * c3 + 12.0 * S2 * c4 + 20.0 * S3 * c5;
-        const double jrkL = 6.0 * c3 + 24.0 * T * c4 + 60.0 * T2 * c5;
-        const double jrkS = 6.0 * c3 + 24.0 * Ts * c4 + 60.0 * S2 * c5;
+        const Num c1 = t.c[1][d], c2 = t.c[2][d], c3 = t.c[3][d], c4 = t.c[4][d], c5 = t.c[5][d];
+        const Num velL = c1 + Num(2.0) * T * c2 + Num(3.0) * T2 * c3 + Num(4.0) * T3 * c4 + Num(5.0) * T4 * c5;
+        const Num velS = c1 + Num(2.0) * Ts * c2 + Num(3.0) * S2 * c3 + Num(4.0) * S3 * c4 + Num(5.0) * S4 * c5;
+        const Num accL = Num(2.0) * c2 + Num(6.0) * T * c3 + Num(12.0) * T2 * c4 + Num(20.0) * T3 * c5;
+        const Num accS = Num(2.0) * c2 + Num(6.0) * Ts * c3 + Num(12.0) * S2 * c4 + Num(20.0) * S3 * c5;
+        const Num jrkL = Num(6.0) * c3 + Num(24.0) * T * c4 + Num(60.0) * T2 * c5;
+        const Num jrkS = Num(6.0) * c3 + Num(24.0) * Ts * c4 + Num(60.0) * S2 * c5;
         gTt += Gt[0][d] * (velL - velS) + Gt[1][d] * (accL - accS) + Gt[2][d] * (jrkL - jrkS);
       }
     }
   }
   // get_grad_T2tau (:485-492)
-  const double ex = t.tau;  // exp(-tau), left there by minco_forward
+  const Num ex = t.tau;  // exp(-tau), left there by minco_forward
   // `(1 + math.exp(-tau))**2` (:490) is a Python-float power too: OverflowError beyond sqrt(DBL_MAX)
-  if (lane < M && (1.0 + ex) > 1.3407807929942596e154) pow_overflow = 1;
-  gtau = LG::sum_dims(gTt) * (prm.T_max - prm.T_min) * ex / ((1.0 + ex) * (1.0 + ex));  // (valid in the piece's first lane)
+  if (lane < M && (Num(1.0) + ex) > Num(1.3407807929942596e154)) pow_overflow = 1;
+  gtau = LG::sum_dims(gTt) * (Num(prm.T_max) - Num(prm.T_min)) * ex / ((Num(1.0) + ex) * (Num(1.0) + ex));  // (valid in the piece's first lane)
   return LG::any(pow_overflow) ? 4 : 0;
 }
 

@@ -4,11 +4,11 @@
 
 namespace neo {
 
-template <int D, typename Real, class MapT, class LookupT>
+template <int D, typename Real, class MapT, class LookupT, typename Num = double>
 int launch_eval(neo_ctx *c, const MapT &map, const EvalArgs &a) {
   const dim3 grid(a.B), blk(kWave);
 #define NEO_EVAL_LG(NS, LG)                                                                                        \
-  hipLaunchKernelGGL((eval_kernel<D, NS, Real, MapT, LookupT, LG>), grid, blk, 0, c->stream, a.B, a.M, c->dev, map, \
+  hipLaunchKernelGGL((eval_kernel<D, NS, Real, MapT, LookupT, LG, Num>), grid, blk, 0, c->stream, a.B, a.M, c->dev, map, \
                      a.x, a.head, a.tail, a.cost, a.costs4, a.grad, a.coeffs, a.status)
   const bool pd = D * a.M <= kWave && !(c->params.flags & 512);  // lane = (piece, dimension), as in launch_opt
 #define NEO_EVAL(NS)                      \
@@ -43,6 +43,15 @@ int dispatch_eval(neo_ctx *c, const MapEntry &e, int D, const EvalArgs &a) {
                : launch_eval<3, double, Map2D, Lookup2D<double>>(c, e.m2, a);
   }
   if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
+  if (f32 && (c->params.flags & NEO_FLAG_F32_SOLVE)) {  // all-fp32 mode (neo_disp_opt3d_x.hip runs the optimiser)
+#define NEO_3DX(LAY)                                                                                        \
+  if (e.elem == NEO_F32) return launch_eval<3, float, Map3D, Lookup3D<float, float, LAY>, float>(c, e.m3, a); \
+  return launch_eval<3, float, Map3D, Lookup3D<float, __half, LAY>, float>(c, e.m3, a);
+    if (e.m3.layout == 0) { NEO_3DX(0) }
+    if (e.m3.layout == 2) { NEO_3DX(2) }
+    NEO_3DX(1)
+#undef NEO_3DX
+  }
 #define NEO_3D(LAY)                                                                                  \
   if (e.elem == NEO_F32)                                                                             \
     return f32 ? launch_eval<3, float, Map3D, Lookup3D<float, float, LAY>>(c, e.m3, a)               \

@@ -62,15 +62,16 @@ __host__ __device__ constexpr bool pairs_in_f32() {
   return sizeof(Real) == 4 && ((NEO_PAIRS_F32 != 0) || (WAVES == 2 && NS > 2));
 }
 // PAIRS32: the L-BFGS pairs are stored in fp32
+// Num: arithmetic of the coefficient solve, the adjoint and the optimiser vectors (double; float = the all-fp32 mode)
 template <int D, int NS, typename Real, class MapT, class LookupT, int SU = NEO_FUSED_U, class LG = WaveLanes,
-          bool PAIRS32 = false>
+          bool PAIRS32 = false, typename Num = double>
 struct DevBackend {
   static constexpr int DL = LG::dl(D);
   // FLAT layout with NS slots: n <= 64 * NS
   struct Vec {
-    double v[NS];
+    Num v[NS];
   };
-  Traj<D, DL> t;
+  Traj<D, DL, Num> t;
   const DevParams &prm;
   const MapT &map;
   double *xs;    // LDS [kStage]: FLAT <-> PIECE staging; between scatter_x and the gradient gather the same memory
@@ -100,13 +101,13 @@ struct DevBackend {
   __device__ DevBackend(const DevParams &p, const MapT &mp) : prm(p), map(mp) {}
 
   __device__ __forceinline__ double dot(const Vec &a, const Vec &b) const {
-    double s = 0.0;
+    Num s = Num(0);
 #pragma unroll
     for (int k = 0; k < NS; ++k) s += a.v[k] * b.v[k];
     return wave_sum(s);
   }
   __device__ __forceinline__ double amax(const Vec &a) const {
-    double s = 0.0;
+    Num s = Num(0);
 #pragma unroll
     for (int k = 0; k < NS; ++k) s = fmax(s, fabs(a.v[k]));
     return wave_max_nonneg(s);
@@ -121,15 +122,15 @@ struct DevBackend {
   }
   __device__ __forceinline__ void axpy(double a, const Vec &x, Vec &y) const {
 #pragma unroll
-    for (int k = 0; k < NS; ++k) y.v[k] += a * x.v[k];
+    for (int k = 0; k < NS; ++k) y.v[k] += (Num)a * x.v[k];
   }
   __device__ __forceinline__ void lincomb(Vec &o, const Vec &a, double s, const Vec &b) const {
 #pragma unroll
-    for (int k = 0; k < NS; ++k) o.v[k] = a.v[k] + s * b.v[k];
+    for (int k = 0; k < NS; ++k) o.v[k] = a.v[k] + (Num)s * b.v[k];
   }
   __device__ __forceinline__ void scale(Vec &v, double s) const {
 #pragma unroll
-    for (int k = 0; k < NS; ++k) v.v[k] *= s;
+    for (int k = 0; k < NS; ++k) v.v[k] *= (Num)s;
   }
   // element k * 64 + lane of a FLAT vector exists.  The kernel with NS slots is launched for (NS / 2) * 64 < n <=
   // NS * 64 (slots_for), so the first NS / 2 slots are full in every lane: no exec masking around their LDS accesses.
@@ -147,7 +148,7 @@ struct DevBackend {
   __device__ __forceinline__ void hist_get(int row, Vec &v) const {
     const int lane = lane_id();
 #pragma unroll
-    for (int k = 0; k < NS; ++k) v.v[k] = in_range(k, lane) ? (double)hist[row * t.n + k * kWave + lane] : 0.0;
+    for (int k = 0; k < NS; ++k) v.v[k] = in_range(k, lane) ? (Num)hist[row * t.n + k * kWave + lane] : Num(0);
   }
   __device__ __forceinline__ void hist_get_s(int slot, Vec &v) const { hist_get(slot, v); }
   __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
@@ -157,11 +158,11 @@ struct DevBackend {
     const Hist *ps = hist + slot * t.n + lane, *py = hist + (m + slot) * t.n + lane;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-      s.v[k] = 0.0;
-      y.v[k] = 0.0;
+      s.v[k] = Num(0);
+      y.v[k] = Num(0);
       if (in_range(k, lane)) {
-        s.v[k] = (double)ps[k * kWave];
-        y.v[k] = (double)py[k * kWave];
+        s.v[k] = (Num)ps[k * kWave];
+        y.v[k] = (Num)py[k * kWave];
       }
     }
   }
@@ -280,19 +281,20 @@ struct DevBackend {
   __device__ __forceinline__ void scatter_x(const Vec &x) {
     const int lane = lane_id();
     lds_wave_sync();
+    Num *xn = reinterpret_cast<Num *>(xs);  // (the staging holds Num values)
 #pragma unroll
     for (int k = 0; k < NS; ++k)
-      if (in_range(k, lane)) xs[k * kWave + lane] = x.v[k];
+      if (in_range(k, lane)) xn[k * kWave + lane] = x.v[k];
     lds_wave_sync();
     const int M = t.M;
     const int p = LG::piece();
     const bool act = p < M;
-    t.tau = act ? xs[t.nq + p] : 0.0;
+    t.tau = act ? xn[t.nq + p] : Num(0);
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
       const int dg = LG::dim0() + d;  // the dimension: compile-time when the lane holds all of them
-      t.P0[d] = (p == 0 || !act) ? bstate<D, LG>(t.head, 0, d) : xs[dg * (M - 1) + (p > 0 ? p - 1 : 0)];
-      t.P1[d] = (p >= M - 1) ? bstate<D, LG>(t.tail, 0, d) : xs[dg * (M - 1) + p];
+      t.P0[d] = (p == 0 || !act) ? (Num)bstate<D, LG>(t.head, 0, d) : xn[dg * (M - 1) + (p > 0 ? p - 1 : 0)];
+      t.P1[d] = (p >= M - 1) ? (Num)bstate<D, LG>(t.tail, 0, d) : xn[dg * (M - 1) + p];
     }
   }
 
@@ -304,8 +306,9 @@ struct DevBackend {
     const long long s0 = wall_clock64();
 #endif
     scatter_x(x);
+    Num *xn = reinterpret_cast<Num *>(xs);
     double energy, tsum;
-    const int st = minco_forward<D, LG>(t, prm, energy, tsum);
+    const int st = minco_forward<D, LG, Num>(t, prm, energy, tsum);
 #ifdef NEO_STAMPS
     const long long s1 = wall_clock64();
 #endif
@@ -321,9 +324,10 @@ struct DevBackend {
 #pragma unroll
       for (int k = 0; k < 6; ++k)
 #pragma unroll
-        for (int d = 0; d < DL; ++d) coeff_out[(size_t)(6 * p + k) * D + LG::dim0() + d] = t.c[k][d];
+        for (int d = 0; d < DL; ++d) coeff_out[(size_t)(6 * p + k) * D + LG::dim0() + d] = (double)t.c[k][d];
     }
-    double gC[6][DL], gT = 0.0, cf, ck;
+    Num gC[6][DL], gT = Num(0);
+    double cf, ck;
     {
       Real cr[6][DL], gCr[6][DL], gTr;
 #pragma unroll
@@ -351,8 +355,8 @@ struct DevBackend {
 #pragma unroll
       for (int k = 0; k < 6; ++k)
 #pragma unroll
-        for (int d = 0; d < DL; ++d) gC[k][d] = (double)gCr[k][d];
-      gT = (double)gTr;
+        for (int d = 0; d < DL; ++d) gC[k][d] = (Num)gCr[k][d];
+      gT = (Num)gTr;
     }
 #ifdef NEO_STAMPS
     const long long s2 = wall_clock64();
@@ -362,19 +366,19 @@ struct DevBackend {
     costs[2] = uniform(cf);
     costs[3] = uniform(ck);
     f = costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3];
-    double gq[DL], gtau;
-    const int bst = minco_backward<D, LG>(t, prm, gC, gT, gq, gtau);
+    Num gq[DL], gtau;
+    const int bst = minco_backward<D, LG, Num>(t, prm, gC, gT, gq, gtau);
     if (bst != 0) return bst;
     // PIECE -> FLAT
     lds_wave_sync();
     if (p >= 1 && p < t.M) {
 #pragma unroll
-      for (int d = 0; d < DL; ++d) xs[(LG::dim0() + d) * (t.M - 1) + p - 1] = gq[d];
+      for (int d = 0; d < DL; ++d) xn[(LG::dim0() + d) * (t.M - 1) + p - 1] = gq[d];
     }
-    if (p < t.M && LG::dim0() == 0) xs[t.nq + p] = gtau;
+    if (p < t.M && LG::dim0() == 0) xn[t.nq + p] = gtau;
     lds_wave_sync();
 #pragma unroll
-    for (int k = 0; k < NS; ++k) g.v[k] = in_range(k, lane) ? xs[k * kWave + lane] : 0.0;
+    for (int k = 0; k < NS; ++k) g.v[k] = in_range(k, lane) ? xn[k * kWave + lane] : Num(0);
 #ifdef NEO_STAMPS
     const long long s3 = wall_clock64();
     tk[0] += s1 - s0;
@@ -386,8 +390,8 @@ struct DevBackend {
   }
 };
 
-template <int D, int DL>
-__device__ __forceinline__ void load_boundary(Traj<D, DL> &t, const double *head, const double *tail, int M) {
+template <int D, int DL, typename Num>
+__device__ __forceinline__ void load_boundary(Traj<D, DL, Num> &t, const double *head, const double *tail, int M) {
   t.M = M;
   t.nq = D * (M - 1);
   t.n = t.nq + M;
@@ -401,7 +405,7 @@ struct MapTable {
 };
 
 // ------------------------------------------------------------------ kernels
-template <int D, int NS, typename Real, class MapT, class LookupT, class LG = WaveLanes>
+template <int D, int NS, typename Real, class MapT, class LookupT, class LG = WaveLanes, typename Num = double>
 __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm, MapT map,
                                                       const double *__restrict__ x,
                                                       const double *__restrict__ head,
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
   __shared__ double cst[12];
   const int b = blockIdx.x;
   if (b >= B) return;
-  using BE = DevBackend<D, NS, Real, MapT, LookupT, NEO_FUSED_U, LG>;
+  using BE = DevBackend<D, NS, Real, MapT, LookupT, NEO_FUSED_U, LG, false, Num>;
   BE be(prm, map);
   be.xs = xs;
   be.sc = sc;
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
 // Dynamic LDS (launch parameter): `stage` doubles of staging (DevBackend::xs) followed by the 2 * maxcor * n doubles of
 // the L-BFGS pairs.  The launcher gives the staging its full size (room for the rows of the per-piece fold) unless that
 // would cost a wavefront of occupancy -- then NS * 64 doubles, and the fold runs in registers.
-template <int D, int NS, typename Real, class MapT, class LookupT, int WAVES, class LG = WaveLanes>
+template <int D, int NS, typename Real, class MapT, class LookupT, int WAVES, class LG = WaveLanes, typename Num = double>
 __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
                                                           const int *__restrict__ scene_slot, int nmaps,
                                                           double *__restrict__ x,
@@ -484,7 +488,8 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize
   const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
   // the two-waves variant has half the registers: two samples per lane in flight instead of four (with the lean
   // Horner form, cfg2 with three batches in flight: 414 k -> 541 k traj/s; scratch 640 -> 336 B per lane)
-  using BE = DevBackend<D, NS, Real, MapT, LookupT, (WAVES == 2 ? NEO_W2_U : NEO_FUSED_U), LG, pairs_in_f32<Real, NS, WAVES>()>;
+  using BE = DevBackend<D, NS, Real, MapT, LookupT, (WAVES == 2 ? NEO_W2_U : NEO_FUSED_U), LG,
+                        pairs_in_f32<Real, NS, WAVES>() || sizeof(Num) == 4, Num>;
   // a slot outside the table (a stale or foreign slot array): the trajectory is left untouched and flagged
   const int slot = scene_slot ? scene_slot[b] : 0;
   if (slot < 0 || slot >= nmaps) {

@@ -5,7 +5,8 @@
 
 namespace neo {
 
-template <int D, typename Real, class MapT, class LookupT, int WAVES = 1>
+// Num = float: the all-fp32 mode (NEO_FLAG_F32_SOLVE) -- solve, adjoint and optimiser vectors in fp32, pairs in fp32
+template <int D, typename Real, class MapT, class LookupT, int WAVES = 1, typename Num = double>
 int launch_opt(neo_ctx *c, const OptArgs &a) {
   const dim3 grid(a.B), blk(kWave);
   const size_t pair_elems = (size_t)2 * NEO_LBFGS_M * (D * (a.M - 1) + a.M);  // L-BFGS pairs in LDS
@@ -15,10 +16,10 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
   const size_t lds_share = (size_t)160 * 1024 / 8 - 512;
 #define NEO_OPT_LG(NS, LG)                                                                                    \
   do {                                                                                                        \
-    const size_t pairs = pair_elems * (pairs_in_f32<Real, NS, WAVES>() ? sizeof(float) : sizeof(double));    \
+    const size_t pairs = pair_elems * ((pairs_in_f32<Real, NS, WAVES>() || sizeof(Num) == 4) ? sizeof(float) : sizeof(double)); \
     const int full = stage_doubles<D, NS, Real>(), small = NS * kWave;                                        \
     const int stage = pairs + (size_t)full * 8 <= lds_share ? full : small;                                   \
-    hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES, LG>), grid, blk,                   \
+    hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES, LG, Num>), grid, blk,                   \
                        pairs + (size_t)stage * 8, c->stream, a.B, a.M, c->dev,                                \
                        static_cast<const MapT *>(a.table), a.slots, a.nmaps, a.x, a.head, a.tail, a.costs4,   \
                        a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter,                             \

@@ -17,6 +17,7 @@ NEO_TRAJ_MAXITER, NEO_TRAJ_NUMERIC_RANGE, NEO_TRAJ_NONFINITE, NEO_TRAJ_BAD_SCENE
 NEO_TRAJ_FLAG_COLLISION = 0x100
 NEO_KERNEL_EVAL, NEO_KERNEL_OPTIMIZE, NEO_KERNEL_ESDF_BUILD, NEO_KERNEL_ESDF_SAMPLE = 0, 1, 2, 3
 NEO_FLAG_ONE_WAVE_PER_SIMD, NEO_FLAG_TWO_WAVES_PER_SIMD, NEO_FLAG_LANE_GROUPS = 32, 64, 128
+NEO_FLAG_F32_SOLVE = 2048
 
 # every symbol include/neo_planner.h declares (tests check the library exports them all)
 EXPORTS = [

@@ -386,14 +386,21 @@ class BatchPlanner:
 
     def __init__(self, config=None, ctx=None, sample_dtype="f64", stale_T=True, waves_per_simd=None, lane_groups=False):
         """waves_per_simd: None (the library decides by batch size), 1 (shortest evaluations) or 2 (highest
-        throughput when several batches are in flight) -- include/neo_planner.h NEO_FLAG_*; same results"""
+        throughput when several batches are in flight) -- include/neo_planner.h NEO_FLAG_*; same results.
+        sample_dtype: "f64" (parity mode), "f32" (fp32 sampled terms, fp64 solve and optimiser) or "f32x" (3-D fields:
+        everything in fp32, NEO_FLAG_F32_SOLVE)"""
         self.cfg = config if config is not None else PlannerConfig()
         self._ctx = ctx
+        self.all_f32 = sample_dtype == "f32x"
+        if self.all_f32:
+            sample_dtype = "f32"
         self.sample_dtype = sample_dtype
         self.stale_T = stale_T
         self.flags = {None: 0, 1: _lib.NEO_FLAG_ONE_WAVE_PER_SIMD, 2: _lib.NEO_FLAG_TWO_WAVES_PER_SIMD}[waves_per_simd]
         if lane_groups:     # small problems: eight trajectories per wavefront (NEO_FLAG_LANE_GROUPS; fp32-rounding-level
             self.flags |= _lib.NEO_FLAG_LANE_GROUPS   # differences to the default kernel)
+        if self.all_f32:
+            self.flags |= _lib.NEO_FLAG_F32_SOLVE
 
     @property
     def ctx(self):
