@@ -97,7 +97,7 @@ def parse(argv=None):
                     help="request batches (launches) per step; default 16 for cfg2, 4 for cfg5, 1 otherwise")
     ap.add_argument("--waypoints", type=int, default=20)
     ap.add_argument("--grid", type=int, default=300)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64", "f32x"],
+    ap.add_argument("--dtype", default="f32x", choices=["f32", "f64", "f32x"],
                     help="f32: fp32 sampled terms, fp64 solve and optimiser; f64: the parity mode; f32x: everything in fp32")
     ap.add_argument("--layout", default="yz4", choices=["linear", "yz4", "cell8"],
                     help="voxel order of the field in HBM (include/neo_planner.h NEO_LAYOUT_*); yz4 = one line per lookup")
@@ -354,7 +354,7 @@ def main():
     M, D, B = a.waypoints + 1, 3, a.batch
     n = D * (M - 1) + M
     default_workload = (a.config == "cfg2" and a.batch == 4096 and a.waypoints == 20 and a.grid == 300
-                        and a.dtype == "f32" and a.layout == "yz4" and not a.planar)
+                        and a.dtype == "f32x" and a.layout == "yz4" and not a.planar)
     if a.dry_run:
         return dry_run(a, rank, world, n)
     from neo_planner_amd import synth

@@ -298,6 +298,29 @@ def test_two_waves_with_four_slots_store_the_pairs_in_fp32():
     assert np.array_equal(a["status"] >= 0, b["status"] >= 0)
 
 
+def test_all_fp32_mode_has_the_statistics_of_the_default_mode():
+    """NEO_FLAG_F32_SOLVE ("f32x"): solve, adjoint, optimiser vectors and pairs in fp32.  Per evaluation within 4e-5 of
+    the oracle (test_gpu_parity.py); whole runs part from the mixed-precision mode's as any two fp32 evaluations of
+    this objective do, the batch ends at the same costs with the same effort, bit-reproducibly."""
+    dist = synth.esdf_3d(2, n=100, res=0.3)
+    g3 = npa.ESDF3D(dist, 0.3, synth.DOMAIN_ORIGIN, store="f32", layout="yz4")
+    for M, B in ((21, 768), (41, 256), (5, 256)):
+        head, tail, wp, ts = synth.replan_requests(5, B, M - 1, D=3)
+        ref = npa.BatchPlanner(sample_dtype="f32")
+        x0 = ref.pack_x(wp, ts)
+        a = ref.optimize(g3, x0, head, tail)
+        bx = npa.BatchPlanner(sample_dtype="f32x")
+        b, b2 = bx.optimize(g3, x0, head, tail), bx.optimize(g3, x0, head, tail)
+        assert np.array_equal(b["x"], b2["x"]) and np.array_equal(b["nfev"], b2["nfev"])
+        ok = (a["status"] <= 1) & (b["status"] <= 1)
+        assert ok.mean() > 0.9
+        assert abs(a["nfev"][ok].mean() - b["nfev"][ok].mean()) <= 0.08 * a["nfev"][ok].mean()
+        med = np.median(a["final_cost"][ok])
+        assert abs(med - np.median(b["final_cost"][ok])) <= 1e-2 * med
+        e0 = bx.cost_grad(g3, x0, head, tail)
+        assert np.all(b["final_cost"][ok] <= e0["cost"][ok] * (1 + 1e-6))
+
+
 def test_lane_group_kernel_small_problems():
     """NEO_FLAG_LANE_GROUPS: eight trajectories per wavefront (M = 3, n = 9).  Same algorithm, fp32 sums associated
     differently: runs either follow the default kernel's path (then the results agree to fp32 rounding) or part

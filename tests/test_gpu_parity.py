@@ -8,7 +8,7 @@ Tolerances
       two different but exact solution methods, cond <= 4e5); optimiser results 1e-4 relative
       (BASELINE.json) on every recorded reference run bar the two named in KNOWN_PARTED, in practice 1e-12
       whenever the run is not decided by round-off.
-  fp32 sampling mode: per-evaluation 2e-5 relative; optimiser: final cost statistics only.
+  fp32 sampling mode: per-evaluation 2e-5 relative (all-fp32 mode "f32x": 4e-5); optimiser: final cost statistics only.
   ESDF construction and lookups: bit-exact.
 """
 import contextlib
@@ -196,7 +196,8 @@ def test_cost_grad_trilinear_matches_oracle():
         for M, B in ((3, 4), (21, 4), (41, 2)):
             head, tail, wp, ts = _random_requests(rng, B, M, 3, (np.array([0.0, -5.0, 1.0]), np.array([10.5, 5.0, 8.0])))
             ts = rng.uniform(0.7, 3.0, (B, M))
-            for dtype, tol in (("f64", 1e-10), ("f32", 2e-5)):
+            # "f32x": the all-fp32 mode (solve and adjoint in fp32 too, NEO_FLAG_F32_SOLVE)
+            for dtype, tol in (("f64", 1e-10), ("f32", 2e-5), ("f32x", 4e-5)):
                 bp = npa.BatchPlanner(sample_dtype=dtype)
                 x = bp.pack_x(wp, ts)
                 out = bp.cost_grad(g3, x, head, tail)
@@ -403,7 +404,7 @@ def cfg2():
     return g3, head, tail, wp, ts
 
 
-@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("dtype", ["f64", "f32", "f32x"])
 def test_full_size_batch_properties(cfg2, dtype):
     g3, head, tail, wp, ts = cfg2
     bp = npa.BatchPlanner(sample_dtype=dtype)

@@ -20,7 +20,7 @@ st = torch.cuda.Stream(); torch.cuda.set_stream(st)
 ctx = npa.Context(0, stream=st.cuda_stream)
 g3 = npa.ESDF3D(torch.from_numpy(dist).to(dev), res, synth.DOMAIN_ORIGIN, store="f32", ctx=ctx,
                 layout=os.environ.get("NEO_LAYOUT", "yz4"))
-bp = npa.BatchPlanner(ctx=ctx, sample_dtype="f32", waves_per_simd=int(os.environ.get("NEO_WAVES", "2")))
+bp = npa.BatchPlanner(ctx=ctx, sample_dtype=os.environ.get("NEO_DTYPE", "f32x"), waves_per_simd=int(os.environ.get("NEO_WAVES", "2")))
 bp.flags |= int(os.environ.get("NEO_FLAGS_OR", "0"))      # e.g. 1024: gathers dropped by the range check (timing only)
 bp._sync()
 x0 = torch.from_numpy(bp.pack_x(wp, ts)).to(dev); x = x0.clone()
