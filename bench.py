@@ -266,7 +266,11 @@ def cpu_leg(workdir):
                                          "(what the GPU's timed mode does)", sample_f32=True),
         cpu_vs_cpu_coeffs_1ulp=control("cpu_native against itself with every polynomial coefficient perturbed by a "
                                        "relative 2.2e-16 (what any other solver of the same system does)",
-                                       coeff_eps=2.2e-16))
+                                       coeff_eps=2.2e-16),
+        cpu_vs_cpu_all_fp32_like=control("cpu_native against itself with the sampled terms in fp32 arithmetic, the "
+                                         "coefficients perturbed by a relative 1e-7 and the gradient entries by 3e-6 (the "
+                                         "per-evaluation deviations of the GPU's all-fp32 mode from the fp64 solve)",
+                                         sample_f32=True, coeff_eps=1e-7, grad_eps=3e-6))
     np.savez(os.path.join(workdir, "out.npz"), **arrays)
     json.dump(out, open(os.path.join(workdir, "out.json"), "w"))
 
