@@ -23,6 +23,7 @@
 // propagate_grad_q_tau becomes the transposed 2x2 block system.  tools/proto_reduced.py checks
 // the algebra against the reference formulation to 1e-13, including the stale-T quirk.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
@@ -563,6 +564,8 @@ struct GroupLanes {
     if constexpr (W == 16) {
       if constexpr (sizeof(T) == 8) {
         v = op(v, dpp_d<0x111>(v)); v = op(v, dpp_d<0x112>(v)); v = op(v, dpp_d<0x114>(v)); v = op(v, dpp_d<0x118>(v));
+      } else if constexpr (std::is_same<T, float>::value) {
+        v = op(v, dpp_f<0x111>(v)); v = op(v, dpp_f<0x112>(v)); v = op(v, dpp_f<0x114>(v)); v = op(v, dpp_f<0x118>(v));
       } else {
         v = op(v, dpp_i<0x111>(v)); v = op(v, dpp_i<0x112>(v)); v = op(v, dpp_i<0x114>(v)); v = op(v, dpp_i<0x118>(v));
       }
@@ -571,6 +574,8 @@ struct GroupLanes {
       // quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E, row_half_mirror = 0x141
       if constexpr (sizeof(T) == 8) {
         v = op(v, dpp_d<0xB1>(v)); v = op(v, dpp_d<0x4E>(v)); v = op(v, dpp_d<0x141>(v));
+      } else if constexpr (std::is_same<T, float>::value) {
+        v = op(v, dpp_f<0xB1>(v)); v = op(v, dpp_f<0x4E>(v)); v = op(v, dpp_f<0x141>(v));
       } else {
         v = op(v, dpp_i<0xB1>(v)); v = op(v, dpp_i<0x4E>(v)); v = op(v, dpp_i<0x141>(v));
       }
@@ -591,6 +596,22 @@ struct GroupLanes {
   }
   static __device__ __forceinline__ double read(double v, int src /* lane inside the group, the same for all groups */) {
     return __shfl(v, base() + src, kWave);
+  }
+  static __device__ __forceinline__ float sum(float v) {
+    return reduce(v, [](float a, float b) { return a + b; });
+  }
+  static __device__ __forceinline__ float max_nonneg(float v) {
+    return reduce(v, [](float a, float b) { return fmaxf(a, b); });
+  }
+  static __device__ __forceinline__ float sum_dims(float v) { return v; }
+  static __device__ __forceinline__ float read(float v, int src) { return __shfl(v, base() + src, kWave); }
+  static __device__ __forceinline__ float prev(float v, float fill) {
+    const float o = dpp_f<0x138>(v);
+    return lane() == 0 ? fill : o;
+  }
+  static __device__ __forceinline__ float next(float v, float fill) {
+    const float o = dpp_f<0x130>(v);
+    return lane() == W - 1 ? fill : o;
   }
   static __device__ __forceinline__ double prev(double v, double fill) {
     const double o = dpp_d<0x138>(v);  // wave_shr:1

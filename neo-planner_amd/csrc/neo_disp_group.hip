@@ -7,7 +7,7 @@ namespace neo {
 
 constexpr int kTicketRing = 64;
 
-template <typename Real, class LookupT, int W, int NS>
+template <typename Real, class LookupT, int W, int NS, typename Num>
 int launch_group_w(neo_ctx *c, const OptArgs &a) {
   constexpr int D = 3, G = kWave / W;
   if (!c->tickets) {
@@ -16,9 +16,9 @@ int launch_group_w(neo_ctx *c, const OptArgs &a) {
   int *ticket = c->tickets + (c->ticket_next++ % kTicketRing);
   HIPCHK(c, hipMemsetAsync(ticket, 0, sizeof(int), c->stream));
   const int n = D * (a.M - 1) + a.M;
-  const size_t dyn = (size_t)G * 2 * NEO_LBFGS_M * n * sizeof(double);
+  const size_t dyn = (size_t)G * 2 * NEO_LBFGS_M * n * sizeof(Num);
   const int waves = std::min((a.B + G - 1) / G, 4096);  // persistent groups: they draw trajectories off the ticket
-  hipLaunchKernelGGL((optimize_group_kernel<D, Real, Map3D, LookupT, W, NS>), dim3(waves), dim3(kWave), dyn, c->stream,
+  hipLaunchKernelGGL((optimize_group_kernel<D, Real, Map3D, LookupT, W, NS, Num>), dim3(waves), dim3(kWave), dyn, c->stream,
                      a.B, a.M, c->dev, static_cast<const Map3D *>(a.table), a.x, a.head, a.tail, a.costs4, a.costs4_last,
                      a.nit, a.nfev, a.status, c->sample_counter, (c->order_B == a.B ? c->dispatch_order : nullptr),
                      ticket);
@@ -27,12 +27,18 @@ int launch_group_w(neo_ctx *c, const OptArgs &a) {
 
 // n <= 16: eight trajectories per wavefront when the pieces fit 8 lanes (flags bit 256: sixteen-lane groups, for
 // comparison), else four
+template <typename Real, class LookupT, typename Num>
+int launch_group_n(neo_ctx *c, const OptArgs &a) {
+  const int n = 3 * (a.M - 1) + a.M;
+  if (n > 16) return launch_group_w<Real, LookupT, 16, 2, Num>(c, a);  // n <= 32 (M <= 8): four per wavefront, two slots
+  if (a.M <= 8 && !(c->params.flags & 256)) return launch_group_w<Real, LookupT, 8, 2, Num>(c, a);
+  return launch_group_w<Real, LookupT, 16, 1, Num>(c, a);
+}
+// NEO_FLAG_F32_SOLVE: solve, adjoint, optimiser vectors and pairs in fp32
 template <typename Real, class LookupT>
 int launch_group(neo_ctx *c, const OptArgs &a) {
-  const int n = 3 * (a.M - 1) + a.M;
-  if (n > 16) return launch_group_w<Real, LookupT, 16, 2>(c, a);  // n <= 32 (M <= 8): four per wavefront, two slots
-  if (a.M <= 8 && !(c->params.flags & 256)) return launch_group_w<Real, LookupT, 8, 2>(c, a);
-  return launch_group_w<Real, LookupT, 16, 1>(c, a);
+  if (c->params.flags & NEO_FLAG_F32_SOLVE) return launch_group_n<Real, LookupT, float>(c, a);
+  return launch_group_n<Real, LookupT, double>(c, a);
 }
 
 int launch_opt_groups(neo_ctx *c, int elem, int layout, const OptArgs &a) {

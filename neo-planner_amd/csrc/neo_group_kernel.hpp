@@ -14,31 +14,32 @@
 
 namespace neo {
 
-template <int D, int W, int NS, typename Real, class MapT, class LookupT, int SU>
+template <int D, int W, int NS, typename Real, class MapT, class LookupT, int SU, typename Num = double>
 struct GroupBackend {
+  using Hist = Num;  // the stored pairs follow the arithmetic (fp32 in the all-fp32 mode)
   struct Vec {
-    double v[NS];  // FLAT layout inside the group: element e <-> (lane e % W, slot e / W), n <= W * NS
+    Num v[NS];  // FLAT layout inside the group: element e <-> (lane e % W, slot e / W), n <= W * NS
   };
-  Traj<D> t;
+  Traj<D, D, Num> t;
   const DevParams &prm;
   const MapT &map;
   double *xs;       // LDS [W * NS] of this group: FLAT <-> PIECE staging
   double *sc;       // LDS [2m]
   LineSearch *lsp;  // LDS
   double *cst;      // LDS [12]
-  double *hist;     // LDS [2][m][n]
+  Hist *hist;       // LDS [2][m][n]
   int m;
 
   __device__ GroupBackend(const DevParams &p, const MapT &mp) : prm(p), map(mp) {}
 
   __device__ __forceinline__ double dot(const Vec &a, const Vec &b) const {
-    double s = 0.0;
+    Num s = Num(0);
 #pragma unroll
     for (int k = 0; k < NS; ++k) s += a.v[k] * b.v[k];
     return GroupLanes<W>::sum(s);
   }
   __device__ __forceinline__ double amax(const Vec &a) const {
-    double s = 0.0;
+    Num s = Num(0);
 #pragma unroll
     for (int k = 0; k < NS; ++k) s = fmax(s, fabs(a.v[k]));
     return GroupLanes<W>::max_nonneg(s);
@@ -53,15 +54,15 @@ struct GroupBackend {
   }
   __device__ __forceinline__ void axpy(double a, const Vec &x, Vec &y) const {
 #pragma unroll
-    for (int k = 0; k < NS; ++k) y.v[k] += a * x.v[k];
+    for (int k = 0; k < NS; ++k) y.v[k] += (Num)a * x.v[k];
   }
   __device__ __forceinline__ void lincomb(Vec &o, const Vec &a, double s, const Vec &b) const {
 #pragma unroll
-    for (int k = 0; k < NS; ++k) o.v[k] = a.v[k] + s * b.v[k];
+    for (int k = 0; k < NS; ++k) o.v[k] = a.v[k] + (Num)s * b.v[k];
   }
   __device__ __forceinline__ void scale(Vec &v, double s) const {
 #pragma unroll
-    for (int k = 0; k < NS; ++k) v.v[k] *= s;
+    for (int k = 0; k < NS; ++k) v.v[k] *= (Num)s;
   }
   __device__ __forceinline__ void hist_put(int slot, const Vec &s, const Vec &y) {
     const int gl = GroupLanes<W>::lane();
@@ -76,7 +77,7 @@ struct GroupBackend {
   __device__ __forceinline__ void hist_get(int row, Vec &v) const {
     const int gl = GroupLanes<W>::lane();
 #pragma unroll
-    for (int k = 0; k < NS; ++k) v.v[k] = (k * W + gl < t.n) ? hist[row * t.n + k * W + gl] : 0.0;
+    for (int k = 0; k < NS; ++k) v.v[k] = (k * W + gl < t.n) ? hist[row * t.n + k * W + gl] : Num(0);
   }
   __device__ __forceinline__ void hist_get_s(int slot, Vec &v) const { hist_get(slot, v); }
   __device__ __forceinline__ void hist_get_y(int slot, Vec &v) const { hist_get(m + slot, v); }
@@ -98,25 +99,27 @@ struct GroupBackend {
   __device__ __forceinline__ int eval(const Vec &x, double &f, Vec &g, double (&costs)[4], int &nsamp) {
     const int lane = GroupLanes<W>::lane();
     const int M = t.M;
+    Num *xn = reinterpret_cast<Num *>(xs);  // (the staging holds Num values)
     lds_wave_sync();
 #pragma unroll
     for (int k = 0; k < NS; ++k)
-      if (k * W + lane < t.n) xs[k * W + lane] = x.v[k];
+      if (k * W + lane < t.n) xn[k * W + lane] = x.v[k];
     lds_wave_sync();
     const bool act = lane < M;
-    t.tau = act ? xs[t.nq + lane] : 0.0;
+    t.tau = act ? xn[t.nq + lane] : Num(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      t.P0[d] = (lane == 0 || !act) ? t.head[d] : xs[d * (M - 1) + (lane > 0 ? lane - 1 : 0)];
-      t.P1[d] = (lane >= M - 1) ? t.tail[d] : xs[d * (M - 1) + lane];
+      t.P0[d] = (lane == 0 || !act) ? (Num)t.head[d] : xn[d * (M - 1) + (lane > 0 ? lane - 1 : 0)];
+      t.P1[d] = (lane >= M - 1) ? (Num)t.tail[d] : xn[d * (M - 1) + lane];
     }
     double energy = 0.0, tsum = 0.0;
-    const int st = minco_forward<D, GroupLanes<W>>(t, prm, energy, tsum);
+    const int st = minco_forward<D, GroupLanes<W>, Num>(t, prm, energy, tsum);
     // (a group whose forward pass fails -- exp overflow -- still walks through the rest on the state its last
     //  good evaluation left in `t`: the wavefront-wide loop bounds need finite values, and its own results are
     //  zeroed below exactly as DevBackend::eval returns them)
     nsamp = GroupLanes<W>::sum(act ? t.ns : 0);
-    double gC[6][D], gT = 0.0, cf, ck;
+    Num gC[6][D], gT = Num(0);
+    double cf, ck;
     {
       Real cr[6][D], gCr[6][D], gTr;
 #pragma unroll
@@ -129,25 +132,25 @@ struct GroupBackend {
 #pragma unroll
       for (int k = 0; k < 6; ++k)
 #pragma unroll
-        for (int d = 0; d < D; ++d) gC[k][d] = (double)gCr[k][d];
-      gT = (double)gTr;
+        for (int d = 0; d < D; ++d) gC[k][d] = (Num)gCr[k][d];
+      gT = (Num)gTr;
     }
     costs[0] = energy;
     costs[1] = tsum;
     costs[2] = cf;
     costs[3] = ck;
     f = costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3];
-    double gq[D], gtau;
-    const int bst = minco_backward<D, GroupLanes<W>>(t, prm, gC, gT, gq, gtau);
+    Num gq[D], gtau;
+    const int bst = minco_backward<D, GroupLanes<W>, Num>(t, prm, gC, gT, gq, gtau);
     lds_wave_sync();
     if (lane >= 1 && lane < M) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) xs[d * (M - 1) + lane - 1] = gq[d];
+      for (int d = 0; d < D; ++d) xn[d * (M - 1) + lane - 1] = gq[d];
     }
-    if (lane < M) xs[t.nq + lane] = gtau;
+    if (lane < M) xn[t.nq + lane] = gtau;
     lds_wave_sync();
 #pragma unroll
-    for (int k = 0; k < NS; ++k) g.v[k] = (k * W + lane < t.n) ? xs[k * W + lane] : 0.0;
+    for (int k = 0; k < NS; ++k) g.v[k] = (k * W + lane < t.n) ? xn[k * W + lane] : Num(0);
     if (st != 0) {
       f = 0.0;
 #pragma unroll
@@ -162,11 +165,14 @@ struct GroupBackend {
 #ifndef NEO_GRP_OCC
 #define NEO_GRP_OCC 1  // (measured at cfg3: 12.2 M traj/s with the whole register file and no spills, 10.8 M at two per SIMD with ~110 spilled)
 #endif
+#ifndef NEO_GRP_OCC_F32
+#define NEO_GRP_OCC_F32 2  // all-fp32 mode: the state fits half the register file
+#endif
 #ifndef NEO_GRP_U
 #define NEO_GRP_U 2
 #endif
-template <int D, typename Real, class MapT, class LookupT, int W, int NS>
-__global__ __launch_bounds__(kWave, NEO_GRP_OCC) void optimize_group_kernel(int B, int M, DevParams prm, const MapT *maps,
+template <int D, typename Real, class MapT, class LookupT, int W, int NS, typename Num = double>
+__global__ __launch_bounds__(kWave, (sizeof(Num) == 4 ? NEO_GRP_OCC_F32 : NEO_GRP_OCC)) void optimize_group_kernel(int B, int M, DevParams prm, const MapT *maps,
                                                                    double *__restrict__ x,
                                                                    const double *__restrict__ head,
                                                                    const double *__restrict__ tail,
@@ -183,10 +189,10 @@ __global__ __launch_bounds__(kWave, NEO_GRP_OCC) void optimize_group_kernel(int 
   __shared__ LineSearch lsm[G];
   __shared__ double cst[G][12];
   extern __shared__ double dyn_lds[];  // G * 2 * maxcor * n doubles
-  using BE = GroupBackend<D, W, NS, Real, MapT, LookupT, NEO_GRP_U>;
+  using BE = GroupBackend<D, W, NS, Real, MapT, LookupT, NEO_GRP_U, Num>;
   const MapT map = maps[0];
   BE be(prm, map);
-  be.t = Traj<D>{};
+  be.t = Traj<D, D, Num>{};
   const int gl = GroupLanes<W>::lane();
   const int g = lane_id() / W;
   const int nq = D * (M - 1), n = nq + M;
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(kWave, NEO_GRP_OCC) void optimize_group_kernel(int 
   be.lsp = &lsm[g];
   be.cst = cst[g];
   be.m = NEO_LBFGS_M;
-  be.hist = dyn_lds + (size_t)g * 2 * NEO_LBFGS_M * n;
+  be.hist = reinterpret_cast<typename BE::Hist *>(dyn_lds) + (size_t)g * 2 * NEO_LBFGS_M * n;
   be.t.M = M;
   be.t.nq = nq;
   be.t.n = n;

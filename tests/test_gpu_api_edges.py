@@ -319,6 +319,17 @@ def test_all_fp32_mode_has_the_statistics_of_the_default_mode():
         assert abs(med - np.median(b["final_cost"][ok])) <= 1e-2 * med
         e0 = bx.cost_grad(g3, x0, head, tail)
         assert np.all(b["final_cost"][ok] <= e0["cost"][ok] * (1 + 1e-6))
+    # the lane-group kernel in the same mode (eight small trajectories per wavefront, two wavefronts per SIMD)
+    head, tail, wp, ts = synth.replan_requests(6, 2048, 2, D=3, length_range=(4.0, 6.0))
+    ga, gb = npa.BatchPlanner(sample_dtype="f32", lane_groups=True), npa.BatchPlanner(sample_dtype="f32x", lane_groups=True)
+    x0 = ga.pack_x(wp, ts)
+    a, b, b2 = ga.optimize(g3, x0, head, tail), gb.optimize(g3, x0, head, tail), gb.optimize(g3, x0, head, tail)
+    assert np.array_equal(b["x"], b2["x"]) and np.array_equal(b["nfev"], b2["nfev"])
+    ok = (a["status"] <= 1) & (b["status"] <= 1)
+    assert ok.mean() > 0.9
+    assert abs(a["nfev"][ok].mean() - b["nfev"][ok].mean()) <= 0.08 * a["nfev"][ok].mean()
+    med = np.median(a["final_cost"][ok])
+    assert abs(med - np.median(b["final_cost"][ok])) <= 1e-2 * med
 
 
 def test_lane_group_kernel_small_problems():
