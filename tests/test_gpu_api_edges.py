@@ -326,7 +326,8 @@ def test_all_fp32_mode_has_the_statistics_of_the_default_mode():
     a, b, b2 = ga.optimize(g3, x0, head, tail), gb.optimize(g3, x0, head, tail), gb.optimize(g3, x0, head, tail)
     assert np.array_equal(b["x"], b2["x"]) and np.array_equal(b["nfev"], b2["nfev"])
     ok = (a["status"] <= 1) & (b["status"] <= 1)
-    assert ok.mean() > 0.9
+    assert ok.mean() > 0.8                                    # (short requests in a dense scene: more end flagged)
+    assert abs(int((a["status"] <= 1).sum()) - int((b["status"] <= 1).sum())) <= 0.05 * len(ok)
     assert abs(a["nfev"][ok].mean() - b["nfev"][ok].mean()) <= 0.08 * a["nfev"][ok].mean()
     med = np.median(a["final_cost"][ok])
     assert abs(med - np.median(b["final_cost"][ok])) <= 1e-2 * med
