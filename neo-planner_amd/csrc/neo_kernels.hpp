@@ -28,6 +28,13 @@
 #ifndef NEO_W2_OCC
 #define NEO_W2_OCC 2  // wavefronts per SIMD the throughput variant is allocated for (experiments: 3)
 #endif
+#ifndef NEO_X_OCC
+// all-fp32 kernels (Num = float) with up to two FLAT slots (n <= 128; four slots -- cfg5 -- spill 167 registers at that
+// budget and stay at two per SIMD): allocated for THREE wavefronts per SIMD (168 registers; the cfg2 instantiation
+// spills 25 of them, built with -amdgpu-use-amdgpu-trackers: neo_planner_amd/build.py) -- measured 933 k traj/s against
+// 889 k at two per SIMD without spills; LDS: fp32 pairs + staging = 12.6 KB of the 13.3 KB a twelfth of a CU has
+#define NEO_X_OCC 3
+#endif
 #ifndef NEO_W2_MAX_SLOTS
 #define NEO_W2_MAX_SLOTS 4  // two waves per SIMD for every n <= 256 (four FLAT slots: with fp32 pairs, pairs_in_f32)
 #endif
@@ -104,8 +111,11 @@ struct DevBackend {
     Num s = Num(0);
 #pragma unroll
     for (int k = 0; k < NS; ++k) s += a.v[k] * b.v[k];
-    return wave_sum(s);
+    return uni((double)wave_sum(s));
   }
+  // a wave-uniform scalar back into scalar registers (two v_readfirstlane): the optimiser's scalar state then costs
+  // no vector registers
+  __device__ __forceinline__ double uni(double v) const { return uniform(v); }
   __device__ __forceinline__ double amax(const Vec &a) const {
     Num s = Num(0);
 #pragma unroll
@@ -365,7 +375,7 @@ struct DevBackend {
     costs[1] = uniform(tsum);
     costs[2] = uniform(cf);
     costs[3] = uniform(ck);
-    f = costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3];
+    f = uniform(costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3]);
     Num gq[DL], gtau;
     const int bst = minco_backward<D, LG, Num>(t, prm, gC, gT, gq, gtau);
     if (bst != 0) return bst;
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
 // the L-BFGS pairs.  The launcher gives the staging its full size (room for the rows of the per-piece fold) unless that
 // would cost a wavefront of occupancy -- then NS * 64 doubles, and the fold runs in registers.
 template <int D, int NS, typename Real, class MapT, class LookupT, int WAVES, class LG = WaveLanes, typename Num = double>
-__global__ __launch_bounds__(kWave, (WAVES == 2 ? NEO_W2_OCC : 1)) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
+__global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ? NEO_X_OCC : NEO_W2_OCC) : 1)) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
                                                           const int *__restrict__ scene_slot, int nmaps,
                                                           double *__restrict__ x,
                                                           const double *__restrict__ head,

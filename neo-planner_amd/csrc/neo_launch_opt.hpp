@@ -13,11 +13,12 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
   // staging in front of the pairs: the full size (with the rows of the per-piece fold) unless that costs the two-waves
   // variant occupancy -- eight wavefronts per CU want 160 KB / 8 each, less ~0.5 KB of static LDS.  The one-wave
   // variant follows the same rule so that both sum the partials in the same order (bit-identical results).
-  const size_t lds_share = (size_t)160 * 1024 / 8 - 512;
+  const size_t lds_share8 = (size_t)160 * 1024 / 8 - 512, lds_share12 = (size_t)160 * 1024 / (4 * NEO_X_OCC) - 512;
 #define NEO_OPT_LG(NS, LG)                                                                                    \
   do {                                                                                                        \
     const size_t pairs = pair_elems * ((pairs_in_f32<Real, NS, WAVES>() || sizeof(Num) == 4) ? sizeof(float) : sizeof(double)); \
     const int full = stage_doubles<D, NS, Real>(), small = NS * kWave;                                        \
+    const size_t lds_share = (sizeof(Num) == 4 && NS <= 2) ? lds_share12 : lds_share8; /* all-fp32: twelve per CU */ \
     const int stage = pairs + (size_t)full * 8 <= lds_share ? full : small;                                   \
     hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES, LG, Num>), grid, blk,                   \
                        pairs + (size_t)stage * 8, c->stream, a.B, a.M, c->dev,                                \

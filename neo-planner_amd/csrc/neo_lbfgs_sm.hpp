@@ -109,7 +109,7 @@ struct LbfgsMachine {
         for (int k = 0; k < 4; ++k) old()[k] = cur()[k];
         // (lnsrlb forms |d| every iteration but, without bounds, uses it only for the first step)
         stp = 1.0;
-        if (iter == 0) stp = fmin(1.0 / sqrt(be.dot(d, d)), big);
+        if (iter == 0) stp = be.uni(fmin(1.0 / sqrt(be.dot(d, d)), big));
         gd = be.dot(g, d);
         gdold = gd;
         if (gd >= 0.0) {
@@ -130,6 +130,7 @@ struct LbfgsMachine {
         next = DO_RETURN;
         for (;;) {
           task = dcsrch(be.ls(), f, gd, stp, task);
+          stp = be.uni(stp);
           if (task == LS_CONVERGENCE || task == LS_WARNING) {
             next = DO_SUCCESS;
             break;
@@ -193,7 +194,7 @@ struct LbfgsMachine {
         }
         be.hist_put(slot, d, r);
         be.sput(slot, 1.0 / dr);
-        theta = rr / dr;
+        theta = be.uni(rr / dr);
         lbfgs_pair_stored<COMPACT>(be, slot, r);
       }
     }

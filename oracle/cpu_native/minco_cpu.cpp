@@ -541,6 +541,7 @@ struct HostBackend {
   }
   void hist_get_s(int slot, Vec &v) const { v.assign(&S[(size_t)slot * n], &S[(size_t)slot * n] + n); }
   void hist_get_y(int slot, Vec &v) const { v.assign(&Y[(size_t)slot * n], &Y[(size_t)slot * n] + n); }
+  double uni(double v) const { return v; }
   void hist_get_sy(int slot, Vec &s, Vec &y) const {
     hist_get_s(slot, s);
     hist_get_y(slot, y);
