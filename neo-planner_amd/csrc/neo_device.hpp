@@ -1339,8 +1339,9 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
         gC[4][dd] = hi[dd].x; gC[5][dd] = hi[dd].y;
       }
       gT = hi[0].z;
-      cost_feas = LG::sum(act ? (double)aF : 0.0);
-      cost_coll = LG::sum(act ? (double)aK : 0.0);
+      // (summed in the sampling arithmetic: 10 instructions a reduction in fp32 against 26 in fp64)
+      cost_feas = (double)LG::sum(act ? aF : Real(0));
+      cost_coll = (double)LG::sum(act ? aK : Real(0));
       return;
     }
   }
