@@ -28,7 +28,11 @@ def _hipcc():
 
 def _flags():
     # NEO_BUILD_DEFS="-DNEO_STAMPS ..." : experiment builds only (tools/); the product is built without
-    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I", INCLUDE] + \
+    # -fno-slp-vectorize: packed fp32 operations (v_pk_*) want aligned register pairs; in these register-bound kernels
+    # they cost moves and spills (8 v_mov per joint of the factor recurrence).  Measured on the MI355X with and without:
+    # cfg2 all-fp32 943 k -> 995 k traj/s, cfg3 12.5 M -> 15.2 M, cfg4 888 k -> 945 k, cfg5 244 k -> 259 k; the
+    # mixed-precision and the ESDF sample kernels unchanged.
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-unused-value", "-I", INCLUDE] + \
         os.environ.get("NEO_BUILD_DEFS", "").split()
 
 
@@ -38,7 +42,7 @@ def _newest_header():
 
 
 # per-unit compiler options: the all-fp32 optimiser kernels are allocated for three wavefronts per SIMD (168 registers);
-# LLVM's alternative register-pressure tracker spills 25 instead of 33 registers there (measured)
+# LLVM's alternative register-pressure tracker spills fewer registers there (25 instead of 33; 19 without SLP)
 UNIT_FLAGS = {"neo_disp_opt3d_x.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"]}
 
 

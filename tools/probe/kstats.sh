@@ -8,7 +8,7 @@ units=(); flags=()
 for a in "$@"; do case "$a" in *.hip) units+=("$a");; *) flags+=("$a");; esac; done
 [ ${#units[@]} -eq 0 ] && units=(neo_disp_opt3d_w2.hip)
 for u in "${units[@]}"; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -S --cuda-device-only -w "${flags[@]}" -o /tmp/isa/${u%.hip}.s $u || exit 1
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I../../include -S --cuda-device-only -w "${flags[@]}" -o /tmp/isa/${u%.hip}.s $u || exit 1
   python3 - /tmp/isa/${u%.hip}.s <<'PY'
 import re, sys
 txt=open(sys.argv[1]).read()
