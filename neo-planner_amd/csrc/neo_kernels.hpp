@@ -262,9 +262,16 @@ struct DevBackend {
 
   // the 2m wave-uniform scalars of the two-loop recursion (rho, alpha): entry i lives in lane i of one register
   // pair, written with a select and read back with v_readlane -- no LDS round trip on the recursion's dependent chain
-  double sreg = 0.0;
-  __device__ __forceinline__ void sput(int i, double v) { sreg = (lane_id() == i) ? v : sreg; }
-  __device__ __forceinline__ double sget(int i) const { return rdlane(sreg, i); }
+  Num sreg = Num(0);
+  __device__ __forceinline__ void sput(int i, double v) { sreg = (lane_id() == i) ? (Num)v : sreg; }
+  __device__ __forceinline__ double sget(int i) const { return (double)rdlane(sreg, i); }
+  // rho_slot * (a . b) in the backend's arithmetic (the two-loop recursion's coefficient)
+  __device__ __forceinline__ double rho_dot(int slot, const Vec &a, const Vec &b) const {
+    Num s = Num(0);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s += a.v[k] * b.v[k];
+    return (double)(rdlane(sreg, slot) * wave_sum(s));
+  }
 #ifndef NEO_LS_IN_REGS  // measured: LDS is faster (registers spill: 14.0 vs 15.5 ms at cfg2)
   __device__ __forceinline__ LineSearch &ls() { return *lsp; }
   __device__ __forceinline__ double *cost_store() { return cst; }

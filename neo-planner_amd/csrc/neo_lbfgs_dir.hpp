@@ -48,7 +48,7 @@ NEO_HD void lbfgs_direction(Backend &be, const typename Backend::Vec &g, typenam
   for (int k = col - 1; k >= 0; --k) {
     const int slot = head + k < m ? head + k : head + k - m;  // (head + k) % m without the division
     be.hist_get_sy(slot, tmp, tmp2);  // (y issued with the read of s: its latency hides behind the reduction)
-    const double a = be.sget(slot) * be.dot(tmp, d);  // rho * s'q
+    const double a = be.rho_dot(slot, tmp, d);  // rho * s'q
     be.sput(m + slot, a);
     be.axpy(-a, tmp2, d);
   }
@@ -56,7 +56,7 @@ NEO_HD void lbfgs_direction(Backend &be, const typename Backend::Vec &g, typenam
   for (int k = 0; k < col; ++k) {
     const int slot = head + k < m ? head + k : head + k - m;
     be.hist_get_sy(slot, tmp2, tmp);
-    const double b = be.sget(slot) * be.dot(tmp, d);
+    const double b = be.rho_dot(slot, tmp, d);
     be.axpy(be.sget(m + slot) - b, tmp2, d);
   }
   be.scale(d, -1.0);
