@@ -90,6 +90,7 @@ struct GroupBackend {
     lds_wave_sync();
   }
   __device__ __forceinline__ double sget(int i) const { return sc[i]; }
+  __device__ __forceinline__ double sdiff(int i, double b) const { return sget(i) - b; }
   __device__ __forceinline__ double rho_dot(int slot, const Vec &a, const Vec &b) const { return sget(slot) * dot(a, b); }
   __device__ __forceinline__ double uni(double v) const { return v; }  // (uniform per group only)
   __device__ __forceinline__ LineSearch &ls() { return *lsp; }

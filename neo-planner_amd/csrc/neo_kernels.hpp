@@ -265,6 +265,8 @@ struct DevBackend {
   Num sreg = Num(0);
   __device__ __forceinline__ void sput(int i, double v) { sreg = (lane_id() == i) ? (Num)v : sreg; }
   __device__ __forceinline__ double sget(int i) const { return (double)rdlane(sreg, i); }
+  // scalar i minus b, in the backend's arithmetic (alpha_k - beta of the two-loop recursion's second loop)
+  __device__ __forceinline__ double sdiff(int i, double b) const { return (double)(rdlane(sreg, i) - (Num)b); }
   // rho_slot * (a . b) in the backend's arithmetic (the two-loop recursion's coefficient)
   __device__ __forceinline__ double rho_dot(int slot, const Vec &a, const Vec &b) const {
     Num s = Num(0);

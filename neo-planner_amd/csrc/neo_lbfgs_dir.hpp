@@ -57,7 +57,7 @@ NEO_HD void lbfgs_direction(Backend &be, const typename Backend::Vec &g, typenam
     const int slot = head + k < m ? head + k : head + k - m;
     be.hist_get_sy(slot, tmp2, tmp);
     const double b = be.rho_dot(slot, tmp, d);
-    be.axpy(be.sget(m + slot) - b, tmp2, d);
+    be.axpy(be.sdiff(m + slot, b), tmp2, d);
   }
   be.scale(d, -1.0);
   } else {

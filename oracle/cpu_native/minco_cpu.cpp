@@ -542,6 +542,7 @@ struct HostBackend {
   void hist_get_s(int slot, Vec &v) const { v.assign(&S[(size_t)slot * n], &S[(size_t)slot * n] + n); }
   void hist_get_y(int slot, Vec &v) const { v.assign(&Y[(size_t)slot * n], &Y[(size_t)slot * n] + n); }
   double uni(double v) const { return v; }
+  double sdiff(int i, double b) const { return sget(i) - b; }
   double rho_dot(int slot, const Vec &a, const Vec &b) const { return sget(slot) * dot(a, b); }
   void hist_get_sy(int slot, Vec &s, Vec &y) const {
     hist_get_s(slot, s);

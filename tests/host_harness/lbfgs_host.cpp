@@ -60,6 +60,7 @@ struct HostBackend {
   void hist_get_s(int slot, Vec &v) { v.assign(&S[size_t(slot) * n], &S[size_t(slot) * n] + n); }
   void hist_get_y(int slot, Vec &v) { v.assign(&Y[size_t(slot) * n], &Y[size_t(slot) * n] + n); }
   double uni(double v) const { return v; }
+  double sdiff(int i, double b) { return sget(i) - b; }
   double rho_dot(int slot, const Vec &a, const Vec &b) { return sget(slot) * dot(a, b); }
   void hist_get_sy(int slot, Vec &s, Vec &y) {
     hist_get_s(slot, s);
