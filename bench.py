@@ -14,15 +14,24 @@ random-forest scene (pillars + floating canopy boxes) resident i
 B = 4096 replans with 20 intermediate waypoints (M = 21 pieces, D = 3, n = 81 variables) whose starts, goals and
 waypoints fill the volume (synth.VOLUME: heights 1..25 m, climbing and descending paths).  One launch optimises one
 batch of 4096 from its initial guess to L-BFGS-B termination (neo_optimize_batch_dev), inputs already in HBM.
-One STEP = one pass of the hot path over `--batches-per-step` (default 16) different request batches of the scene,
-i.e. 16 launches of 4096 trajectories: long enough for the timed region to last seconds at the driver's
-`--steps 20`.  Launches are issued round-robin on `--streams` (default 4) HIP streams with separate state and result
+One STEP = one pass of the hot path over `--batches-per-step` (default 40) different request batches of the scene,
+i.e. 40 launches of 4096 trajectories: the timed region then lasts > 3 s at the driver's `--steps 20`.  Launches are issued round-robin on `--streams` (default 4) HIP streams with separate state and result
 buffers: the end of a launch is a handful of long runs on an otherwise idle chip, and the next batches fill it
 (`--streams 1 --batches-per-step 1` gives the one-batch-at-a-time latency figure).
 With N > 1 every rank owns its own scene and batches (weak scaling, no data-path collective); the per-rank results
 of every batch are gathered with one RCCL all_gather inside the timed region.
 
+Arithmetic modes: `--dtype f32x` (default, the headline: BASELINE.json's cfg2 is an fp32
+configuration) computes everything in fp32; `f32` keeps the coefficient solve, adjoint and optimiser in fp64; `f64` is
+the parity mode.  With one GPU all three are timed in the same run under the same protocol (`modes`), each with its
+parity figures against the CPU optimiser; `value` is the `--dtype` mode's.
+
 Printed JSON (one line, rank 0): the driver contract plus
+  modes          f64 / f32 / f32x: traj/s, accepted traj/s, roofline fraction, parity against the CPU optimiser
+  accepted_traj_per_s   trajectories per second whose result the reference would accept (L-BFGS-B converged or stopped
+                 on its own, no `collision cost too large`, expert_planner.py:235-237): `value` counts plan_once runs
+  cfg1           BASELINE.json configs[0]: one plan() of the reference's own shape (M = 3, 2-D map, fp64) in ms -- GPU
+                 path, NumPy port, cpu_native
   roofline       dominant kernel = optimize_kernel; achieved = algorithmic bytes per launch (samples visited *
                  8 corners * 4 B + evaluations * (2 n 4 + 20) B) / mean launch duration from HIP
                  events on the kernel's stream
@@ -69,8 +78,9 @@ def pmc_profile(kernel, default_workload):
     if not files or not default_workload:
         return {}, None
     try:
-        k = json.load(open(files[-1]))["kernels"][kernel]
-        return {c: v["mean_per_dispatch"] for c, v in k.items()}, os.path.relpath(files[-1], REPO)
+        ks = json.load(open(files[-1]))["kernels"]
+        k = ks[kernel] if kernel in ks else ks[kernel.split("@")[0]]    # (profiles before round 3 are not keyed by grid)
+        return {c: v["mean_per_dispatch"] for c, v in k.items() if "mean_per_dispatch" in v}, os.path.relpath(files[-1], REPO)
     except Exception:
         return {}, None
 
@@ -94,7 +104,7 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--batches-per-step", type=int, default=None,
-                    help="request batches (launches) per step; default 16 for cfg2, 4 for cfg5, 1 otherwise")
+                    help="request batches (launches) per step; default 40 for cfg2, 4 for cfg5, 1 otherwise")
     ap.add_argument("--waypoints", type=int, default=20)
     ap.add_argument("--grid", type=int, default=300)
     ap.add_argument("--dtype", default="f32x", choices=["f32", "f64", "f32x"],
@@ -104,6 +114,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall budget of the NumPy-port sample")
     ap.add_argument("--native-seconds", type=float, default=4.0, help="wall budget of each cpu_native run")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-modes", action="store_true", help="time only the --dtype mode (cfg2 on one GPU times all three)")
     ap.add_argument("--planar", action="store_true", help="round-1 workload: every request in the plane z = 2 m, no canopy")
     ap.add_argument("--no-order", action="store_true", help="dispatch trajectories in index order")
     ap.add_argument("--lane-groups", action="store_true",
@@ -115,7 +126,8 @@ def parse(argv=None):
                     help="BASELINE.json configs[1..4]; cfg2 is the headline (default).  cfg3: 65536 trajectories, M=3, "
                          "warm-started by the initializer net; cfg4: --scenes scenes x 4096 per GPU; cfg5: 40 waypoints, "
                          "600^3 fp16 field")
-    ap.add_argument("--scenes", type=int, default=8, help="cfg4: scenes per GPU (256 scenes over 8 GPUs = 32)")
+    ap.add_argument("--scenes", type=int, default=None,
+                    help="cfg4: scenes per GPU; default 256 // max(world, 8) = 32 (BASELINE.json: 256 scenes over 8 GPUs)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to "
                     "exercise the multi-rank code path without GPUs")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: all ranks use cuda:0")
@@ -271,6 +283,32 @@ def cpu_leg(workdir):
                                          "coefficients perturbed by a relative 1e-7 and the gradient entries by 3e-6 (the "
                                          "per-evaluation deviations of the GPU's all-fp32 mode from the fp64 solve)",
                                          sample_f32=True, coeff_eps=1e-7, grad_eps=3e-6))
+    if cfg.get("cfg1"):
+        # BASELINE.json configs[0]: one plan() of the reference's own shape on one host core
+        import contextlib
+        import io
+        from neo_planner_amd import synth
+        occ2 = synth.occupancy_2d(3)
+        o2 = onp.GridESDF(occ2, synth.RES, 300, 300, (0.0, -15.0))
+        h2 = np.array([[0.0, 0.0], [0.0, 0.0]]); t2 = np.array([[5.0, 0.3], [0.8, 0.0]])
+        ref = onp.OraclePlanner(onp.PlannerParams())
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref.plan(o2, h2, t2)
+            t0 = time.time()
+            for _ in range(5):
+                ref.plan(o2, h2, t2)
+            port_ms = 1e3 * (time.time() - t0) / 5
+            nm2 = cn.NativeMap.from_grid2d(o2)
+            npl = cn.NativePlanner()
+            iw, its = ref.generate_init_variables(h2, t2)
+            t0 = time.time()
+            for _ in range(50):
+                npl.read_planning_conditions(nm2, h2, t2, iw, its)
+                npl.plan_once()
+            nat_ms = 1e3 * (time.time() - t0) / 50
+        out["cfg1"] = dict(plan_ms_cpu_port=port_ms, plan_ms_cpu_native=nat_ms, plan_final_cost_cpu_port=float(ref.final_cost),
+                           cpu_note="one host core; port = oracle/minco_np.py (the reference's per-sample Python loops + "
+                                    "SciPy L-BFGS-B), native = oracle/cpu_native cost/gradient in C++ under SciPy L-BFGS-B")
     np.savez(os.path.join(workdir, "out.npz"), **arrays)
     json.dump(out, open(os.path.join(workdir, "out.json"), "w"))
 
@@ -279,7 +317,8 @@ def run_cpu_leg(a, dist_host, res, origin, head, tail, wp, ts):
     wd = tempfile.mkdtemp(prefix="neo_cpu_")
     np.save(os.path.join(wd, "field.npy"), dist_host)
     np.savez(os.path.join(wd, "in.npz"), head=head, tail=tail, wp=wp, ts=ts)
-    json.dump(dict(res=res, origin=list(origin), cpu_seconds=a.cpu_seconds, native_seconds=a.native_seconds),
+    json.dump(dict(res=res, origin=list(origin), cpu_seconds=a.cpu_seconds, native_seconds=a.native_seconds,
+                   cfg1=(a.config == "cfg2")),
               open(os.path.join(wd, "in.json"), "w"))
     env = dict(os.environ)
     env["NEO_NO_TORCH_PRELOAD"] = "1"
@@ -294,20 +333,38 @@ def run_cpu_leg(a, dist_host, res, origin, head, tail, wp, ts):
 
 # ================================================================== self-launch of the N ranks
 def self_launch(a, argv):
-    """one child process per GPU, started before this process touches any GPU; rank 0 prints the JSON line"""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(a.gpus):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    """one child process per GPU, started before this process touches any GPU; rank 0 prints the JSON line.
+    The children are polled: when one of them dies the others are terminated (they would otherwise sit in a
+    collective until the RCCL timeout) and its exit code is returned."""
+    for attempt in range(3):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = []
+        for r in range(a.gpus):
+            env = dict(os.environ)
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+        rc = 0
+        live = list(procs)
+        while live:
+            time.sleep(0.05)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = abs(code)
+                    for q in live:
+                        q.terminate()
+        if rc != EADDRINUSE_RC:
+            return rc
     return rc
+
+
+EADDRINUSE_RC = 98    # a rank exits with this when the rendezvous port was taken between the probe and rank 0's bind
 
 
 # ================================================================== one rank
@@ -342,7 +399,9 @@ def main():
     use_dist = world > 1 or bool(os.environ.get("NEO_BENCH_FORCE_DIST"))
     store = "f32"
     n_scenes = 1
-    bps_default = 16
+    bps_default = 40
+    if a.scenes is None:
+        a.scenes = 256 // max(world, 8)      # cfg4: 256 scenes over the 8 GPUs of a node = 32 per GPU
     if a.config == "cfg3":
         a.batch, a.waypoints, a.no_cpu = 65536, 2, True
         a.lane_groups = True            # M = 3: eight trajectories per wavefront
@@ -359,6 +418,9 @@ def main():
     n = D * (M - 1) + M
     default_workload = (a.config == "cfg2" and a.batch == 4096 and a.waypoints == 20 and a.grid == 300
                         and a.dtype == "f32x" and a.layout == "yz4" and not a.planar)
+    # one GPU, cfg2: all three arithmetic modes are timed under the same protocol
+    modes = [a.dtype] + ([m_ for m_ in ("f32x", "f32", "f64") if m_ != a.dtype]
+                         if (a.config == "cfg2" and world == 1 and not a.no_modes) else [])
     if a.dry_run:
         return dry_run(a, rank, world, n)
     from neo_planner_amd import synth
@@ -381,10 +443,15 @@ def main():
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        if a.dist_backend == "nccl":
-            dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist_.init_process_group(a.dist_backend, rank=rank, world_size=world)
+        try:
+            if a.dist_backend == "nccl":
+                dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist_.init_process_group(a.dist_backend, rank=rank, world_size=world)
+        except Exception as ex:
+            if "EADDRINUSE" in str(ex) or "address already in use" in str(ex).lower():
+                sys.exit(EADDRINUSE_RC)      # self_launch picks another port
+            raise
     # one explicit (non-default) stream for everything: torch copies, our kernels, RCCL.  The default
     # stream has handle 0, which the C ABI reads as "create your own stream".
     tstream = torch.cuda.Stream(device=dev)
@@ -392,9 +459,12 @@ def main():
     assert tstream.cuda_stream != 0
     ctx = npa.Context(local_rank, stream=tstream.cuda_stream)
     # several launches in flight -> the throughput variant of the optimiser kernel (two wavefronts per SIMD)
-    bp = npa.BatchPlanner(ctx=ctx, sample_dtype=a.dtype, waves_per_simd=2 if a.streams > 1 else None,
-                          lane_groups=a.lane_groups)
-    bp.flags |= int(os.environ.get("NEO_BENCH_FLAGS_OR", "0"))     # kernel experiments
+    def planner_for(mode):
+        p_ = npa.BatchPlanner(ctx=ctx, sample_dtype=mode, waves_per_simd=2 if a.streams > 1 else None,
+                              lane_groups=a.lane_groups)
+        p_.flags |= int(os.environ.get("NEO_BENCH_FLAGS_OR", "0"))     # kernel experiments
+        return p_
+    bp = planner_for(a.dtype)
     bp._sync()
     want_cpu = world == 1 and rank == 0 and not a.no_cpu
     g3 = npa.ESDF3D.from_occupancy(torch.from_numpy(occ).to(dev), res, synth.DOMAIN_ORIGIN, store=store, layout=a.layout,
@@ -474,7 +544,7 @@ def main():
         x0_[:, :D * (M - 1)] = wp_.reshape(B, -1)
         x0_[:, D * (M - 1):] = tau_
 
-    def launch(bt):
+    def launch(bt, bpm):
         ctx.set_stream(bt["st"].cuda_stream)
         ctx.check(ctx.lib.neo_optimize_sample_counter(ctx.h, ctypes.c_void_p(bt["nsamp"].data_ptr())))
         ctx.check(ctx.lib.neo_optimize_dispatch_order(
@@ -483,9 +553,9 @@ def main():
             if init is not None:
                 with torch.no_grad():
                     warm_start(bt["x0"])
-            bt["x"].copy_(bt["x0"])
-            bp.optimize_dev(g3, bt["x"], bt["head"], bt["tail"], bt["costs"], bt["last"], bt["nit"], bt["nfev"],
-                            bt["status"], slots=slots)
+            # start points are read from x0, results written to x: no copy per launch (neo_optimize_batch_from_dev)
+            bpm.optimize_dev(g3, bt["x"], bt["head"], bt["tail"], bt["costs"], bt["last"], bt["nit"], bt["nfev"],
+                             bt["status"], slots=slots, x0=bt["x0"])
             if use_dist:
                 # results to every rank: final x, total cost, 4 cost terms.  The gather runs
                 # behind the batch on the process group's own stream; this batch's stream does not wait for it
@@ -496,30 +566,55 @@ def main():
                 _, bt["work"] = sharding.gather_results(bt["packed"], world, out=bt["gathered"], force=use_dist,
                                                         async_op=True)
 
-    def step(k):
-        for bt in batches:
-            launch(bt)
-
     def fence():
         torch.cuda.synchronize()
         if use_dist:
             dist_.barrier()
         torch.cuda.synchronize()
 
+    esz = 4 if store == "f32" else 2
+
+    def time_mode(mode):
+        """W warm-up steps, then exactly K timed steps of the hot path in arithmetic mode `mode`, fenced by a barrier
+        and a device synchronisation on both sides; returns the timing and what the launches of the last step left"""
+        bpm = bp if mode == a.dtype else planner_for(mode)
+        bpm._sync()
+        fence()
+        for k in range(a.warmup):
+            for bt in batches:
+                launch(bt, bpm)
+        fence()
+        ctx.check(ctx.lib.neo_profile_reset(ctx.h))
+        ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            for bt in batches:
+                launch(bt, bpm)
+        fence()
+        el = time.perf_counter() - t0
+        ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
+        ctx.set_stream(None)
+        launches = ctypes.c_int64()
+        kms = ctypes.c_double()
+        ctx.check(ctx.lib.neo_profile_read(ctx.h, _lib.NEO_KERNEL_OPTIMIZE, ctypes.byref(launches), ctypes.byref(kms)))
+        nfev_all = torch.stack([bt["nfev"] for bt in batches]).cpu().numpy().astype(np.int64)
+        nsamp_all = torch.stack([bt["nsamp"] for bt in batches]).cpu().numpy()
+        status_all = torch.stack([bt["status"] for bt in batches]).cpu().numpy()
+        # results the reference accepts: L-BFGS-B ended on its own (converged / abnormal line search: SciPy returns
+        # either without raising) and the weighted collision cost is within tolerance (expert_planner.py:235-237)
+        accepted = ((status_all & 0xff) <= 2) & ((status_all & 0x100) == 0)
+        kernel_ms = kms.value / max(launches.value, 1)
+        # algorithmic bytes of ONE launch, mean over the step's batches (SURVEY.md 8.d2): S*C*e per evaluation + 2*n*4 + 20
+        bytes_launch = (float(nsamp_all.sum()) * 8 * esz + float(nfev_all.sum()) * (2 * n * 4 + 20)) / n_sets
+        b0_ = batches[0]
+        return dict(mode=mode, elapsed=el, kernel_ms=kernel_ms, launches=int(launches.value), nfev_all=nfev_all,
+                    nsamp_all=nsamp_all, status_all=status_all, accepted_frac=float(accepted.mean()),
+                    bytes_launch=bytes_launch, mean_nit=float(b0_["nit"].float().mean().item()),
+                    b0=dict(x=b0_["x"].clone(), last=b0_["last"].clone(), nfev=b0_["nfev"].clone()))
+
     t_gpu0 = time.time()
-    fence()
-    for k in range(a.warmup):
-        step(k)
-    fence()
-    ctx.check(ctx.lib.neo_profile_reset(ctx.h))
-    ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        step(k)
-    fence()
-    elapsed = time.perf_counter() - t0
-    ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
-    ctx.set_stream(None)
+    main_run = time_mode(a.dtype)
+    elapsed = main_run["elapsed"]
     rank_rate = B * n_sets * a.steps / elapsed
     rccl_ranks, per_rank = None, None
     if use_dist:
@@ -530,11 +625,13 @@ def main():
         per_rank = [float(v) for v in rates.cpu()]
         elapsed = float(tmax.item())
         rccl_ranks = dist_.get_world_size()
+    mode_runs = {a.dtype: main_run}
+    for m_ in modes[1:]:
+        mode_runs[m_] = time_mode(m_)
+    bp._sync()
 
-    launches = ctypes.c_int64()
-    kms = ctypes.c_double()
-    ctx.check(ctx.lib.neo_profile_read(ctx.h, _lib.NEO_KERNEL_OPTIMIZE, ctypes.byref(launches), ctypes.byref(kms)))
-    kernel_ms = kms.value / max(launches.value, 1)
+    kernel_ms = main_run["kernel_ms"]
+    launches = ctypes.c_int64(main_run["launches"])
     pp = lambda t: ctypes.c_void_p(t.data_ptr())
 
     # ---- the ESDF-lookup kernel on its own (outside the timed region): add_sampled_cost +
@@ -590,7 +687,7 @@ def main():
                 for dx in (0, 1):
                     ids.append((((i0[:, 2] + dz) * a.grid + i0[:, 1] + dy) * a.grid + i0[:, 0] + dx) * esz // 128)
         footprint = int(np.unique(np.concatenate(ids)).size) * 128
-        pm_s, src_s = pmc_profile("sample_kernel", default_workload)
+        pm_s, src_s = pmc_profile(f"sample_kernel@{B}", default_workload)
         esdf = {"kernel": "sample_kernel", "bound": "hbm", "achieved": by_8d2 / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": by_8d2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                 "frac_8d2": by_8d2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
@@ -633,22 +730,62 @@ def main():
                                          "samples_per_launch": ns_a, "algorithmic_bytes_per_launch": by_a,
                                          "achieved": by_a / (us_a * 1e-6) / 1e9,
                                          "frac_8d2": by_a / (us_a * 1e-6) / 1e9 / HBM_PEAK_GBPS}
-    nfev_all = torch.stack([bt["nfev"] for bt in batches]).cpu().numpy().astype(np.int64)
-    nsamp_all = torch.stack([bt["nsamp"] for bt in batches]).cpu().numpy()
-    status_h = b0["status"].cpu().numpy()
-    # algorithmic bytes of ONE launch, mean over the step's batches: S*C*e per evaluation + 2*n*4 + 20
-    esz = 4 if store == "f32" else 2
-    bytes_launch = (float(nsamp_all.sum()) * 8 * esz + float(nfev_all.sum()) * (2 * n * 4 + 20)) / n_sets
+            pm_a, src_a = pmc_profile(f"sample_kernel@{Ba}", default_workload)
+            if src_a and src_a != src_s or (pm_a and pm_a != pm_s):
+                esdf["whole_step_launch"].update(traffic=hbm_traffic(pm_a), l2_hit_rate=l2_hit(pm_a), traffic_source=src_a)
+    nfev_all, nsamp_all, status_all = main_run["nfev_all"], main_run["nsamp_all"], main_run["status_all"]
+    status_h = status_all[0]
+    bytes_launch = main_run["bytes_launch"]
     achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
     value = world * rank_rate if not use_dist else world * B * n_sets * a.steps / elapsed
-    pm_o, src_o = pmc_profile("optimize_kernel", default_workload)
+    pm_o, src_o = pmc_profile(f"optimize_kernel@{B}", default_workload)
+
+    def mode_line(r_):
+        """one arithmetic mode under the bench protocol (this rank; with N ranks `value` above is the job's)"""
+        v_ = B * n_sets * a.steps / r_["elapsed"]
+        ach = r_["bytes_launch"] / (r_["kernel_ms"] * 1e-3) / 1e9
+        return {"value": v_, "unit": "traj/s", "ms_per_step": 1e3 * r_["elapsed"] / a.steps,
+                "accepted_frac": r_["accepted_frac"], "accepted_traj_per_s": v_ * r_["accepted_frac"],
+                "kernel_ms": r_["kernel_ms"], "roofline_frac": ach / HBM_PEAK_GBPS,
+                "roofline_frac_aggregate": r_["bytes_launch"] * n_sets * a.steps / r_["elapsed"] / 1e9 / HBM_PEAK_GBPS,
+                "mean_nfev": float(r_["nfev_all"].mean()), "max_nfev": int(r_["nfev_all"].max()),
+                "status_hist": np.bincount(r_["status_all"].reshape(-1) & 0xff, minlength=7).tolist(),
+                "sampling_arithmetic": "f64" if r_["mode"] == "f64" else "f32",
+                "solve_and_optimiser_arithmetic": "f32" if r_["mode"] == "f32x" else "f64"}
+
+    # ---- cfg1 (BASELINE.json configs[0]): ONE plan() of the reference's own shape through the reference-shaped API
+    cfg1 = None
+    if rank == 0 and world == 1 and a.config == "cfg2":
+        import contextlib
+        import io
+        occ2 = synth.occupancy_2d(3)
+        m2 = npa.ESDF(ctx=ctx)
+        m2.occupancy_map_cb(synth.OccupancyGridMsg(occ2))
+        h2 = np.array([[0.0, 0.0], [0.0, 0.0]]); t2 = np.array([[5.0, 0.3], [0.8, 0.0]])
+        pl1 = npa.MinJerkPlanner(npa.PlannerConfig(), ctx=ctx)
+        with contextlib.redirect_stdout(io.StringIO()):
+            pl1.plan(m2, h2, t2)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                pl1.plan(m2, h2, t2)
+            plan_ms = 1e3 * (time.perf_counter() - t1) / 20
+            t1 = time.perf_counter()
+            for _ in range(20):
+                pl1.batch_plan(m2, h2, t2)
+            batch_plan_ms = 1e3 * (time.perf_counter() - t1) / 20
+        cfg1 = {"what": "one plan() / batch_plan() call of the reference's shape: M = 3, D = 2, 300 x 300 nearest-cell map, fp64 "
+                        "(expert_planner.py:62-80, :142-168); scenario of tests/golden g3 / __graft_entry__.smoke()",
+                "plan_ms_gpu": plan_ms, "batch_plan_ms_gpu": batch_plan_ms, "plan_nfev": int(pl1.last_nfev),
+                "plan_final_cost_gpu": float(pl1.final_cost)}
+        bp._sync()
 
     if rank == 0:
         out = {
             "metric": "trajectories/sec (batched replan)", "value": value, "unit": "traj/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.dtype == "f32x" else a.dtype, "data": "synthetic",
+            "dtype": a.dtype, "data": "synthetic",
+            "accepted_traj_per_s": value * main_run["accepted_frac"], "accepted_frac": main_run["accepted_frac"],
             "config": {"workload": f"{a.config}: request batches of B={B} trajectories x {M - 1} waypoints (M={M} pieces, D=3, "
                                    f"n={n}), {n_sets} batch(es) per step per GPU, {n_scenes} x {a.grid}^3 {store} ESDF per GPU "
                                    f"(trilinear, layout {a.layout}; " +
@@ -680,9 +817,13 @@ def main():
                          "evals_per_launch": float(nfev_all.sum()) / n_sets, "samples_per_launch": float(nsamp_all.sum()) / n_sets},
             "esdf_kernel": esdf,
             "optimizer": {"mean_nfev": float(nfev_all.mean()), "max_nfev": int(nfev_all.max()),
-                          "mean_nit": float(b0["nit"].float().mean().item()),
+                          "mean_nit": main_run["mean_nit"],
                           "status_hist": np.bincount(status_h & 0xff, minlength=7).tolist(),
-                          "collision_flag_frac": float(((status_h & 0x100) != 0).mean())},
+                          "collision_flag_frac": float(((status_all & 0x100) != 0).mean())},
+            "modes": {m_: mode_line(r_) for m_, r_ in mode_runs.items()},
+            "headline_mode": a.dtype,
+            "cfg1": cfg1,
+            "timed_region_s": elapsed,
             "setup_s": t_gpu0 - t_setup,
         }
         if init is not None:
@@ -710,26 +851,23 @@ def main():
                         "final_cost_frac_within_1e_4": float((rel <= 1e-4).mean()), "final_cost_rel_median": float(np.median(rel)),
                         "final_cost_frac_within_1e_2": float((rel <= 1e-2).mean()),
                         "gpu_median_cost": float(np.median(lc)), "cpu_median_cost": float(np.median(ref_cost[good]))}
-            par = {"tolerance": "north_star: final control points within 1e-4 relative of the CPU optimiser's",
-                   "gpu_timed_mode_vs_cpu_native": delta(b0["x"], b0["last"], b0["nfev"], arr["nat_idx"], arr["nat_cost"],
-                                                         arr["nat_nfev"], arr["nat_wp"]),
-                   "gpu_timed_mode_vs_numpy_port": delta(b0["x"], b0["last"], b0["nfev"], arr["np_idx"], arr["np_cost"],
-                                                         arr["np_nfev"], arr["np_wp"])}
-            if a.dtype != "f64":
-                # batch 0 once more with fp64 sampling (parity mode), outside the timed region
-                bp64 = npa.BatchPlanner(ctx=ctx, sample_dtype="f64")
-                bp64._sync()
-                b0["x"].copy_(b0["x0"])
-                torch.cuda.synchronize()
-                t64 = time.perf_counter()
-                bp64.optimize_dev(g3, b0["x"], b0["head"], b0["tail"], b0["costs"], b0["last"], b0["nit"], b0["nfev"], b0["status"])
-                torch.cuda.synchronize()
-                t64 = time.perf_counter() - t64
-                par["gpu_fp64_sampling_vs_cpu_native"] = delta(b0["x"], b0["last"], b0["nfev"], arr["nat_idx"], arr["nat_cost"],
-                                                               arr["nat_nfev"], arr["nat_wp"])
-                par["gpu_fp64_sampling_vs_numpy_port"] = delta(b0["x"], b0["last"], b0["nfev"], arr["np_idx"], arr["np_cost"],
-                                                               arr["np_nfev"], arr["np_wp"])
-                par["gpu_fp64_sampling_traj_per_s_one_batch_at_a_time"] = B / t64
+            par = {"tolerance": "north_star: final control points within 1e-4 relative of the CPU optimiser's"}
+            for m_, r_ in mode_runs.items():
+                rb = r_["b0"]
+                pm_ = {"vs_cpu_native": delta(rb["x"], rb["last"], rb["nfev"], arr["nat_idx"], arr["nat_cost"], arr["nat_nfev"],
+                                             arr["nat_wp"]),
+                       "vs_numpy_port": delta(rb["x"], rb["last"], rb["nfev"], arr["np_idx"], arr["np_cost"], arr["np_nfev"],
+                                              arr["np_wp"])}
+                out["modes"][m_]["parity"] = pm_
+                if m_ == a.dtype:
+                    par["gpu_timed_mode_vs_cpu_native"] = pm_["vs_cpu_native"]
+                    par["gpu_timed_mode_vs_numpy_port"] = pm_["vs_numpy_port"]
+            if cfg1 is not None and "cfg1" in cpu_out:
+                cfg1.update(cpu_out["cfg1"])
+            par["per_evaluation_and_decision_replay"] = (
+                "tests/test_gpu_replay.py: every point every run of a 256-trajectory cfg2 batch evaluates is re-evaluated by "
+                "the fp64 CPU oracle (value 4e-5 / gradient 2e-4 in the all-fp32 mode, 2e-5 / 2e-4 mixed, 1e-10 / 1e-8 fp64) "
+                "and every L-BFGS-B decision is re-derived on the host from the recorded values; profiles/r03_replay_*.json")
             par["control"] = cpu_out["parity_control"]
             par["reading"] = ("the objective is discontinuous (int(T/dt) sample counts): two faithful CPU implementations "
                               "part at the rates under `control`; the GPU rows are to be read against those, not against 1.0")

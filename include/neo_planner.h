@@ -117,6 +117,10 @@ typedef struct neo_params {
  * fp64 solve to ~1e-5 instead of 2e-6; the optimiser's statistics (evaluations, final costs) are those of the default
  * mode.  Opt-in throughput mode. */
 #define NEO_FLAG_F32_SOLVE 2048
+/* neo_sampled_terms_batch on a yz-quad field with fp32 sampling runs a workgroup of two wavefronts per trajectory with
+ * the field gathers staged through LDS (csrc/neo_sample_wg.hpp); this flag selects the one-wavefront kernel instead
+ * (the form the fused kernels use; results differ in the last bits through the order of the per-piece sums). */
+#define NEO_FLAG_ONE_WAVE_PER_TRAJECTORY 4096
 /* bits 1..16 switch phases off for timing experiments (tools/): leave them 0 */
 
 /* ---- lifetime ------------------------------------------------------------- */
@@ -219,6 +223,13 @@ int neo_optimize_batch_dev(neo_ctx *ctx, int scene_id, const int32_t *scene_ids,
                            int D, double *x, const double *head, const double *tail,
                            double *costs4, double *costs4_last, int32_t *nit, int32_t *nfev,
                            int32_t *status);
+/* the same with separate start points: x0[B][n] is only read, the results go to x[B][n] (x0 == x is the in-place
+ * form above).  A caller that optimises the same requests again (benchmarks, re-planning from a stored guess) keeps
+ * x0 resident and needs no copy per launch. */
+int neo_optimize_batch_from_dev(neo_ctx *ctx, int scene_id, const int32_t *scene_ids, int B, int M,
+                                int D, const double *x0, double *x, const double *head,
+                                const double *tail, double *costs4, double *costs4_last, int32_t *nit,
+                                int32_t *nfev, int32_t *status);
 /* slot of a scene in the device-side map table, -1 if it has no map.  Slots change
  * whenever a map is uploaded or dropped. */
 int neo_scene_slot(neo_ctx *ctx, int scene_id);
@@ -246,6 +257,12 @@ int neo_optimize_sample_counter(neo_ctx *ctx, int64_t *dev_counts);
  * can be laid beside the CPU optimiser's evaluation by evaluation (tools/classify_divergence.py); NULL switches it off.
  * Not supported by the lane-group kernel. */
 int neo_optimize_trace(neo_ctx *ctx, double *dev_trace, int cap);
+/* diagnostics: optional DEVICE array [B][cap][2][n] that receives, per counted evaluation, the evaluated point x_k
+ * and its gradient g_k (as doubles, whatever arithmetic the kernel ran in).  With neo_optimize_trace's (f, step, ...)
+ * records this is everything needed to re-evaluate a device run point by point on the CPU oracle and to re-derive
+ * every line-search / restart decision on the host (tests/test_gpu_replay.py).  `cap` must equal neo_optimize_trace's
+ * when both are on; NULL switches it off.  Not supported by the lane-group kernel. */
+int neo_optimize_trace_xg(neo_ctx *ctx, double *dev_xg, int cap);
 /* optional DEVICE permutation [B] for the next neo_optimize_batch_dev launches: workgroup i works on
  * trajectory order[i].  Results stay in the caller's order.  Workgroups start in index order, so
  * putting the runs expected to be long first shortens the launch (a late long run is its tail);

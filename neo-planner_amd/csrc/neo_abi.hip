@@ -986,9 +986,17 @@ size_t neo_optimize_workspace_bytes(int, int, int) { return 0; }
 int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, int B, int M, int D, double *x,
                            const double *head, const double *tail, double *costs4, double *costs4_last, int32_t *nit,
                            int32_t *nfev, int32_t *status) {
+  return neo_optimize_batch_from_dev(c, scene_id, scene_ids, B, M, D, x, x, head, tail, costs4, costs4_last, nit, nfev,
+                                     status);
+}
+
+int neo_optimize_batch_from_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, int B, int M, int D, const double *x0,
+                                double *x, const double *head, const double *tail, double *costs4, double *costs4_last,
+                                int32_t *nit, int32_t *nfev, int32_t *status) {
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
-  if (!x || !head || !tail || !costs4 || !nit || !nfev || !status) return fail_locked(c, NEO_ERR_INVALID, "null buffer");
+  if (!x0 || !x || !head || !tail || !costs4 || !nit || !nfev || !status)
+    return fail_locked(c, NEO_ERR_INVALID, "null buffer");
   std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   if (B == 0) return NEO_OK;
@@ -1024,7 +1032,7 @@ int neo_optimize_batch_dev(neo_ctx *c, int scene_id, const int32_t *scene_ids, i
     table = base + (size_t)it->second.slot * (kind == 0 ? sizeof(Map2D) : sizeof(Map3D));
   }
   ProfScope ps(c, NEO_KERNEL_OPTIMIZE);
-  const OptArgs oa{B, M, table, slots, nmaps, x, head, tail, costs4, costs4_last, nit, nfev, status};
+  const OptArgs oa{B, M, table, slots, nmaps, x0, x, head, tail, costs4, costs4_last, nit, nfev, status};
   rc = dispatch_opt(c, kind, elem, layout, D, oa);
   if (rc) return rc;
   HIPCHK(c, hipGetLastError());
@@ -1141,8 +1149,22 @@ int neo_optimize_sample_counter(neo_ctx *c, int64_t *dev_counts) {
 int neo_optimize_trace(neo_ctx *c, double *dev_trace, int cap) {
   if (!c || cap < 0) return NEO_ERR_INVALID;
   std::lock_guard<std::recursive_mutex> g(c->mu);
+  if (dev_trace && cap > 0 && c->trace_xg && c->trace_cap != cap)
+    return fail(c, NEO_ERR_INVALID, "neo_optimize_trace: cap differs from neo_optimize_trace_xg's");
   c->trace = (dev_trace && cap > 0) ? dev_trace : nullptr;
-  c->trace_cap = c->trace ? cap : 0;
+  if (c->trace) c->trace_cap = cap;
+  if (!c->trace_xg && !c->trace) c->trace_cap = 0;
+  return NEO_OK;
+}
+
+int neo_optimize_trace_xg(neo_ctx *c, double *dev_xg, int cap) {
+  if (!c || cap < 0) return NEO_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> g(c->mu);
+  if (dev_xg && cap > 0 && c->trace && c->trace_cap != cap)
+    return fail(c, NEO_ERR_INVALID, "neo_optimize_trace_xg: cap differs from neo_optimize_trace's");
+  c->trace_xg = (dev_xg && cap > 0) ? dev_xg : nullptr;
+  if (c->trace_xg) c->trace_cap = cap;
+  if (!c->trace_xg && !c->trace) c->trace_cap = 0;
   return NEO_OK;
 }
 

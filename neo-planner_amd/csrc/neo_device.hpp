@@ -477,6 +477,47 @@ struct Lookup3D {
     }
     return q;
   }
+  // ---- the gathers of load() as LDS-DMA (yz-quad layout only): the 32 (fp32) / 16 (fp16) bytes of a lookup go from
+  // HBM / L2 straight into LDS -- `buffer_load_dwordx4 ... offen lds`, no destination registers -- so a lane can have as
+  // many lookups in flight as the wavefront has landing room, instead of as many as it has spare VGPRs.  One
+  // wave-instruction lands lane-linear: piece k of the wavefront's 64 lookups at land + k * 1024 + lane * 16.
+  static constexpr int kAsyncPieces = sizeof(E) == 4 ? 2 : 1;   // 16-byte pieces per lookup
+  static constexpr int kAsyncBytes = kAsyncPieces * 1024;       // landing bytes per wavefront and lookup round
+  typedef __attribute__((address_space(3))) void *LdsPtr;
+  __device__ __forceinline__ void load_async(const Addr &a, char *land /*wave-uniform LDS address*/) const {
+    static_assert(LAYOUT == 1, "LDS-DMA gathers are written for the yz-quad layout");
+    const unsigned int cell = __umul24(__umul24((unsigned)a.i0[2], (unsigned)m.ny) + (unsigned)a.i0[1], (unsigned)m.nx) +
+                              (unsigned)a.i0[0];
+    if constexpr (sizeof(E) == 4) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)land, 16, (int)(cell * 16u), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(land + 1024), 16, (int)(cell * 16u), 0, 16, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)land, 16, (int)(cell * 8u), 0, 0, 0);
+    }
+  }
+  // the lane's own lookup back out of the landing area (after the wavefront has waited for its LDS-DMA loads)
+  __device__ __forceinline__ Raw read_staged(const char *land) const {
+    typedef unsigned int U4 __attribute__((ext_vector_type(4)));
+    Raw q;
+    const U4 lo = *reinterpret_cast<const U4 *>(land + lane_id() * 16);
+    if constexpr (sizeof(E) == 4) {
+      const U4 hi = *reinterpret_cast<const U4 *>(land + 1024 + lane_id() * 16);
+      q.c[0][0][0] = __uint_as_float(lo[0]); q.c[0][1][0] = __uint_as_float(lo[1]);
+      q.c[1][0][0] = __uint_as_float(lo[2]); q.c[1][1][0] = __uint_as_float(lo[3]);
+      q.c[0][0][1] = __uint_as_float(hi[0]); q.c[0][1][1] = __uint_as_float(hi[1]);
+      q.c[1][0][1] = __uint_as_float(hi[2]); q.c[1][1][1] = __uint_as_float(hi[3]);
+    } else {
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz) {
+          const unsigned int u = lo[2 * dx + dz];
+          q.c[dz][0][dx] = __half2float(__ushort_as_half((unsigned short)(u & 0xffffu)));
+          q.c[dz][1][dx] = __half2float(__ushort_as_half((unsigned short)(u >> 16)));
+        }
+    }
+    return q;
+  }
   template <int D>
   __device__ __forceinline__ Real finish(const Addr &a, const Raw &q, Real (&g)[D]) const {
 #pragma clang fp contract(on)  // fuse a*b+c only as written: the same arithmetic whatever the unrolling around it
@@ -888,9 +929,12 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
   {
     const Num tau = act ? t.tau : Num(0.0);
     if (-tau > Num(709.782712893384)) bad = 1;
+    // (fp32: expf overflows to +inf beyond 88.72 -- T is then T_min exactly, as it is in fp64 to rounding from -tau = 37
+    //  on; the statuses stay those of the fp64 modes because the range tests are made on tau, not on exp(-tau))
     const Num ex = exp(-tau);
     t.T = (Num(prm.T_max) - Num(prm.T_min)) / (Num(1.0) + ex) + Num(prm.T_min);
-    t.tau = ex;  // get_grad_T2tau needs exp(-tau) again (:490): keep it instead of tau
+    // get_grad_T2tau needs exp(-tau) again (:490): fp64 keeps it instead of tau; fp32 keeps -tau (exp(-tau) may be inf)
+    if constexpr (sizeof(Num) == 8) t.tau = ex; else t.tau = -tau;
   }
   if (LG::any(bad)) return 4;
   t.i1 = Num(1.0) / t.T;
@@ -1138,6 +1182,58 @@ __device__ __forceinline__ void fold_piece_segments(Real (&v)[N], int r, int L, 
   }
 }
 
+// One quadrature sample's contribution to the two sampled cost terms and their partials (:404-466): j = sample index in
+// its piece (of ns), s = its local time, vel = velocity there, vv = |vel|^2 - v_max^2, vd = safe_dis - d(pos); the map
+// gradient is taken from the lookup only when the collision penalty is active.  One source for every sampling kernel
+// (fused, stand-alone, workgroup-per-trajectory): the same arithmetic sample by sample.
+template <typename Real, int D, class LookupT>
+__device__ __forceinline__ void sample_accumulate(const Real (&c)[6][D], int j, int ns, Real s, Real inv_ns, const Real (&vel)[D],
+                                                  Real vv, Real vd, const LookupT &lk, const typename LookupT::Addr &ad,
+                                                  const typename LookupT::Raw &rw, Real dt, Real w2, Real w3, Real (&aC)[6][D],
+                                                  Real &aT, Real &aF, Real &aK) {
+#pragma clang fp contract(on)  // fuse a*b+c only as written: the same arithmetic whatever the unrolling around it
+  const Real omg = (j == 0 || j == ns - 1) ? Real(0.5) : Real(1);
+  const Real s2 = s * s, s3 = s2 * s, s4 = s2 * s2, s5 = s4 * s;
+  // dynamic feasibility
+  if (vv > Real(0)) {
+    const Real vq = vv;
+    aF += omg * dt * vq * vq * vq;
+    Real av = Real(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const Real acc = Real(2) * c[2][d] + s * (Real(6) * c[3][d] + s * (Real(12) * c[4][d] + s * (Real(20) * c[5][d])));
+      av += acc * vel[d];
+    }
+    const Real dK = Real(3) * dt * omg * vq * vq;
+    const Real b1[6] = {Real(0), Real(1), Real(2) * s, Real(3) * s2, Real(4) * s3, Real(5) * s4};
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const Real uu = w2 * dK * Real(2) * vel[d];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) aC[k][d] += b1[k] * uu;
+    }
+    aT += w2 * (omg * vq * vq * vq * inv_ns + dK * Real(2) * av * (Real)j * inv_ns);
+  }
+  // collision
+  if (vd > Real(0)) {
+    Real g[D];
+    (void)lk.template finish<D>(ad, rw, g);
+    const Real vq = vd;
+    aK += omg * dt * vq * vq * vq;
+    const Real dK = Real(3) * dt * omg * vq * vq;
+    const Real b0[6] = {Real(1), s, s2, s3, s4, s5};
+    Real gv = Real(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      gv += g[d] * vel[d];
+      const Real uu = -(w3 * dK * g[d]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) aC[k][d] += b0[k] * uu;
+    }
+    aT += w3 * (omg * vq * vq * vq * inv_ns + dK * (-gv) * (Real)j * inv_ns);
+  }
+}
+
 // sampled feasibility + collision terms (:392-466), SAMPLE layout.
 // SAMPLE_IO = false (fused kernels): in (PIECE layout) cp = coefficients of the lane's piece, ns_in = its sample
 //   count; out (PIECE layout) gC, gT = weighted partials of the two sampled terms.
@@ -1241,48 +1337,8 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (!on[u]) continue;
-        const int j = r + (it0 + u) * L;
-        const Real s = sv[u];
-        const Real omg = (j == 0 || j == ns - 1) ? Real(0.5) : Real(1);
-        const Real s2 = s * s, s3 = s2 * s, s4 = s2 * s2, s5 = s4 * s;
-        // dynamic feasibility
-        if (vv[u] > Real(0)) {
-          const Real vq = vv[u];
-          aF += omg * dt * vq * vq * vq;
-          Real av = Real(0);
-#pragma unroll
-          for (int d = 0; d < D; ++d) {
-            const Real acc = Real(2) * c[2][d] + s * (Real(6) * c[3][d] + s * (Real(12) * c[4][d] + s * (Real(20) * c[5][d])));
-            av += acc * vel[u][d];
-          }
-          const Real dK = Real(3) * dt * omg * vq * vq;
-          const Real b1[6] = {Real(0), Real(1), Real(2) * s, Real(3) * s2, Real(4) * s3, Real(5) * s4};
-#pragma unroll
-          for (int d = 0; d < D; ++d) {
-            const Real uu = w2 * dK * Real(2) * vel[u][d];
-#pragma unroll
-            for (int k = 1; k < 6; ++k) aC[k][d] += b1[k] * uu;
-          }
-          aT += w2 * (omg * vq * vq * vq * inv_ns + dK * Real(2) * av * (Real)j * inv_ns);
-        }
-        // collision
-        if (vd[u] > Real(0)) {
-          Real g[D];
-          (void)lk.template finish<D>(ad[u], rw[u], g);
-          const Real vq = vd[u];
-          aK += omg * dt * vq * vq * vq;
-          const Real dK = Real(3) * dt * omg * vq * vq;
-          const Real b0[6] = {Real(1), s, s2, s3, s4, s5};
-          Real gv = Real(0);
-#pragma unroll
-          for (int d = 0; d < D; ++d) {
-            gv += g[d] * vel[u][d];
-            const Real uu = -(w3 * dK * g[d]);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) aC[k][d] += b0[k] * uu;
-          }
-          aT += w3 * (omg * vq * vq * vq * inv_ns + dK * (-gv) * (Real)j * inv_ns);
-        }
+        sample_accumulate<Real, D, LookupT>(c, r + (it0 + u) * L, ns, sv[u], inv_ns, vel[u], vv[u], vd[u], lk, ad[u], rw[u], dt, w2,
+                                            w3, aC, aT, aF, aK);
       }
     }
   }
@@ -1417,7 +1473,13 @@ __device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D), Num> &t, 
     jerk_end[d] = Num(6.0) * c3 + Num(24.0) * T * c4 + Num(60.0) * T2 * c5;
     snap_end[d] = Num(24.0) * c4 + Num(120.0) * T * c5;
     crackle[d] = Num(120.0) * c5;
-    if (lane < M && fabs(jerk_end[d]) > Num(1.3407807929942596e154)) pow_overflow = 1;  // sqrt(DBL_MAX)
+    // `(...).item()**2` (:382) raises beyond sqrt(DBL_MAX); fp32 cannot hold such a value: there the flag goes up when
+    // the jerk itself has left the fp32 range (inf / NaN), which is where its square would poison the gradient
+    if constexpr (sizeof(Num) == 8) {
+      if (lane < M && fabs(jerk_end[d]) > Num(1.3407807929942596e154)) pow_overflow = 1;  // sqrt(DBL_MAX)
+    } else {
+      if (lane < M && !(fabs(jerk_end[d]) <= Num(3.4028234663852886e38))) pow_overflow = 1;
+    }
     gT += w0 * jerk_end[d] * jerk_end[d];
   }
   // gz = H(T)^T gC : sensitivity wrt the end states Z = (p0, v0, a0, p1, v1, a1)
@@ -1527,10 +1589,21 @@ __device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D), Num> &t, 
     }
   }
   // get_grad_T2tau (:485-492)
-  const Num ex = t.tau;  // exp(-tau), left there by minco_forward
   // `(1 + math.exp(-tau))**2` (:490) is a Python-float power too: OverflowError beyond sqrt(DBL_MAX)
-  if (lane < M && (Num(1.0) + ex) > Num(1.3407807929942596e154)) pow_overflow = 1;
-  gtau = LG::sum_dims(gTt) * (Num(prm.T_max) - Num(prm.T_min)) * ex / ((Num(1.0) + ex) * (Num(1.0) + ex));  // (valid in the piece's first lane)
+  if constexpr (sizeof(Num) == 8) {
+    const Num ex = t.tau;  // exp(-tau), left there by minco_forward
+    if (lane < M && (Num(1.0) + ex) > Num(1.3407807929942596e154)) pow_overflow = 1;
+    gtau = LG::sum_dims(gTt) * (Num(prm.T_max) - Num(prm.T_min)) * ex / ((Num(1.0) + ex) * (Num(1.0) + ex));  // (valid in the piece's first lane)
+  } else {
+    // fp32: minco_forward left -tau.  The same range test on tau itself (1 + exp(-tau) > sqrt(DBL_MAX) <=> -tau >
+    // 354.89), and the factor exp(-tau) / (1 + exp(-tau))^2 as (e s) s with s = 1 / (1 + e), e = exp(-tau) clamped to
+    // FLT_MAX: a value below 1e-38 (as in fp64) instead of inf / inf once expf overflows (-tau > 88.72)
+    const Num nt = t.tau;
+    if (lane < M && nt > Num(354.891356446692)) pow_overflow = 1;
+    const Num ex = fmin(exp(nt), Num(3.4028234663852886e38));
+    const Num s = Num(1.0) / (Num(1.0) + ex);
+    gtau = LG::sum_dims(gTt) * (Num(prm.T_max) - Num(prm.T_min)) * ((ex * s) * s);
+  }
   return LG::any(pow_overflow) ? 4 : 0;
 }
 

@@ -19,7 +19,7 @@ int launch_group_w(neo_ctx *c, const OptArgs &a) {
   const size_t dyn = (size_t)G * 2 * NEO_LBFGS_M * n * sizeof(Num);
   const int waves = std::min((a.B + G - 1) / G, 4096);  // persistent groups: they draw trajectories off the ticket
   hipLaunchKernelGGL((optimize_group_kernel<D, Real, Map3D, LookupT, W, NS, Num>), dim3(waves), dim3(kWave), dyn, c->stream,
-                     a.B, a.M, c->dev, static_cast<const Map3D *>(a.table), a.x, a.head, a.tail, a.costs4, a.costs4_last,
+                     a.B, a.M, c->dev, static_cast<const Map3D *>(a.table), a.x0 ? a.x0 : a.x, a.x, a.head, a.tail, a.costs4, a.costs4_last,
                      a.nit, a.nfev, a.status, c->sample_counter, (c->order_B == a.B ? c->dispatch_order : nullptr),
                      ticket);
   return NEO_OK;

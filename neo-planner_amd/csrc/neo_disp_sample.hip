@@ -1,8 +1,36 @@
 // neo_disp_sample.hip -- sample_kernel family: the ESDF-lookup kernel (expert_planner.py:392-466)
 #include "neo_host.hpp"
 #include "neo_kernels.hpp"
+#include "neo_sample_wg.hpp"
+
+#include <cstdlib>
 
 namespace neo {
+
+// workgroup-per-trajectory form with LDS-staged gathers (neo_sample_wg.hpp): fp32 sampling on yz-quad fields
+template <class LookupT, int WPT, int PF, int OCC>
+int launch_sample_wg(neo_ctx *c, const Map3D &map, const SampleArgs &a) {
+  hipLaunchKernelGGL((sample_wg_kernel<LookupT, WPT, PF, OCC>), dim3(a.B), dim3(kWave * WPT), 0, c->stream, a.B, a.M, c->dev,
+                     map, a.coeffs, a.ts, a.costs2, a.grad_C, a.grad_T);
+  return NEO_OK;
+}
+// variant = 100 * (wavefronts per SIMD) + 10 * (wavefronts per trajectory) + (rounds of gathers in flight per lane)
+template <class LookupT>
+int dispatch_sample_wg(neo_ctx *c, const Map3D &map, const SampleArgs &a, int variant) {
+  switch (variant) {
+#ifdef NEO_SAMPLE_EXPERIMENTS
+    case 412: return launch_sample_wg<LookupT, 1, 2, 4>(c, map, a);
+    case 414: return launch_sample_wg<LookupT, 1, 4, 4>(c, map, a);
+    case 423: return launch_sample_wg<LookupT, 2, 3, 4>(c, map, a);
+    case 443: return launch_sample_wg<LookupT, 4, 3, 4>(c, map, a);
+    case 314: return launch_sample_wg<LookupT, 1, 4, 3>(c, map, a);
+    case 316: return launch_sample_wg<LookupT, 1, 6, 3>(c, map, a);
+    case 323: return launch_sample_wg<LookupT, 2, 3, 3>(c, map, a);
+    case 343: return launch_sample_wg<LookupT, 4, 3, 3>(c, map, a);
+#endif
+    default: return launch_sample_wg<LookupT, 2, 5, 3>(c, map, a);
+  }
+}
 
 template <int D, typename Real, class MapT, class LookupT>
 int launch_sample(neo_ctx *c, const MapT &map, const SampleArgs &a) {
@@ -26,6 +54,15 @@ int dispatch_sample(neo_ctx *c, const MapEntry &e, int D, const SampleArgs &a) {
                : launch_sample<3, double, Map2D, Lookup2D<double>>(c, e.m2, a);
   }
   if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
+  {
+    // experiments: NEO_SAMPLE_VARIANT (dispatch_sample_wg; 0 = the one-wavefront kernel)
+    const char *ev = std::getenv("NEO_SAMPLE_VARIANT");
+    const int variant = ev ? std::atoi(ev) : 325;
+    if (f32 && e.m3.layout == NEO_LAYOUT_YZ4 && variant != 0 && !(c->params.flags & NEO_FLAG_ONE_WAVE_PER_TRAJECTORY)) {
+      if (e.elem == NEO_F32) return dispatch_sample_wg<Lookup3D<float, float, 1>>(c, e.m3, a, variant);
+      return dispatch_sample_wg<Lookup3D<float, __half, 1>>(c, e.m3, a, variant);
+    }
+  }
 #define NEO_3D(LAY)                                                                                  \
   if (e.elem == NEO_F32)                                                                             \
     return f32 ? launch_sample<3, float, Map3D, Lookup3D<float, float, LAY>>(c, e.m3, a)             \

@@ -95,7 +95,7 @@ struct GroupBackend {
   __device__ __forceinline__ double uni(double v) const { return v; }  // (uniform per group only)
   __device__ __forceinline__ LineSearch &ls() { return *lsp; }
   __device__ __forceinline__ double *cost_store() { return cst; }
-  __device__ __forceinline__ void note_eval(int, int, double, double) {}  // (no trace in the lane-group kernel)
+  __device__ __forceinline__ void note_eval(int, int, double, double, const Vec &, const Vec &) {}  // (no trace in the lane-group kernel)
   __device__ __forceinline__ void sm_stamp(int) {}
 
   // one evaluation (get_cost + get_grad, :539-585); costs into registers, nsamp = samples visited
@@ -176,7 +176,7 @@ struct GroupBackend {
 #endif
 template <int D, typename Real, class MapT, class LookupT, int W, int NS, typename Num = double>
 __global__ __launch_bounds__(kWave, (sizeof(Num) == 4 ? NEO_GRP_OCC_F32 : NEO_GRP_OCC)) void optimize_group_kernel(int B, int M, DevParams prm, const MapT *maps,
-                                                                   double *__restrict__ x,
+                                                                   const double *x0, double *x,
                                                                    const double *__restrict__ head,
                                                                    const double *__restrict__ tail,
                                                                    double *__restrict__ costs4,
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kWave, (sizeof(Num) == 4 ? NEO_GRP_OCC_F32 : NEO_GR
     be.t.head = head + (size_t)b * 3 * D;
     be.t.tail = tail + (size_t)b * 3 * D;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) mach.x.v[k] = (k * W + gl < n) ? x[(size_t)b * n + k * W + gl] : 0.0;
+    for (int k = 0; k < NS; ++k) mach.x.v[k] = (k * W + gl < n) ? x0[(size_t)b * n + k * W + gl] : 0.0;
     mach.begin();
     samples = 0;
   };

@@ -60,6 +60,7 @@ struct neo_ctx {
   const int *dispatch_order = nullptr;  // optional device permutation [B] (neo_optimize_dispatch_order)
   int order_B = 0;                      // batch size the permutation was given for (ignored for any other B)
   double *trace = nullptr;              // optional device array [B][trace_cap][4] (neo_optimize_trace)
+  double *trace_xg = nullptr;           // optional device array [B][trace_cap][2][n] (neo_optimize_trace_xg)
   int trace_cap = 0;
   int *order_buf = nullptr;             // device copy of a host permutation (neo_optimize_dispatch_order_host)
   size_t order_cap = 0;
@@ -129,6 +130,7 @@ struct OptArgs {
   const void *table;
   const int *slots;  // device array [B] of map-table slots, or NULL (all trajectories use table[0])
   int nmaps;         // entries of `table` (slots are checked against it on the device)
+  const double *x0;  // start points (NULL: read from x, the in-place form)
   double *x;
   const double *head, *tail;
   double *costs4, *costs4_last;

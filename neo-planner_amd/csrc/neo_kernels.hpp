@@ -5,6 +5,8 @@
 //   optimize_kernel  plan_once: the whole L-BFGS-B run on-chip  (expert_planner.py:205-237)
 //   sample_kernel    add_sampled_cost + add_sampled_grad_CT     (expert_planner.py:392-466)
 //
+// x0 / x: the start points are read from x0 and the results written to x; the two may be the same buffer (every lane reads
+// its own elements before it writes them), which is the in-place form of neo_optimize_batch_dev.
 // One 64-lane workgroup (= one wavefront) per trajectory: the optimiser never leaves the chip,
 // finished trajectories free their slot for the next ones, no host round trips.
 #pragma once
@@ -15,12 +17,6 @@
 #include "../../include/neo_planner.h"
 #ifndef NEO_FUSED_U
 #define NEO_FUSED_U (sizeof(Real) == 4 ? 4 : 2)
-#endif
-#ifndef NEO_COMPACT_DIRECTION
-#define NEO_COMPACT_DIRECTION 0
-#endif
-#ifndef NEO_PAIRS_F32
-#define NEO_PAIRS_F32 0
 #endif
 #ifndef NEO_W2_U
 #define NEO_W2_U 1  // (one sample per lane in flight: the two-waves variant then has no VGPR spills; 2 -> 7 % slower)
@@ -62,11 +58,10 @@ __host__ __device__ constexpr int stage_doubles() {
 // cfg5): their 2 * 10 * n doubles (25.8 KB at n = 161) leave room for six wavefronts per CU, in fp32 for eight -- measured
 // at cfg5: 119 k traj/s with one wavefront per SIMD, 105 k with two and fp64 pairs, 155 k with two and fp32 pairs,
 // mean nfev 336.7 against 337.5 and the same status histogram (the rounding of the pairs is well below what the fp32
-// gradient already carries).  -DNEO_PAIRS_F32=1 stores them in fp32 in every fp32-sampling kernel (experiment: the LDS
-// half of a third wavefront per SIMD).
+// gradient already carries).
 template <typename Real, int NS, int WAVES>
 __host__ __device__ constexpr bool pairs_in_f32() {
-  return sizeof(Real) == 4 && ((NEO_PAIRS_F32 != 0) || (WAVES == 2 && NS > 2));
+  return sizeof(Real) == 4 && WAVES == 2 && NS > 2;
 }
 // PAIRS32: the L-BFGS pairs are stored in fp32
 // Num: arithmetic of the coefficient solve, the adjoint and the optimiser vectors (double; float = the all-fp32 mode)
@@ -96,6 +91,7 @@ struct DevBackend {
   long long samples = 0;  // quadrature samples visited so far (lane-uniform), for the bench's byte count
   int last_ns = 0;        // samples of the last evaluation
   double *trace = nullptr;  // optional [trace_cap][4] of this trajectory: (f, step, samples, iteration) per evaluation
+  double *trace_xg = nullptr;  // optional [trace_cap][2][n]: the evaluated point and its gradient
   int trace_cap = 0;
 #ifdef NEO_STAMPS  // timing experiments (tools/gpu_straggler.py): 100 MHz wall-clock ticks per phase
   long long tk[4] = {0, 0, 0, 0};  // forward, sample, backward, evaluations
@@ -176,90 +172,6 @@ struct DevBackend {
       }
     }
   }
-  // ---- compact-representation direction (neo_lbfgs_dir.hpp, fp32-sampling kernels): vectors with one entry per
-  // history slot live in lane `slot` of a register pair; S'Y and Y'Y (m x m each) in LDS
-  struct SVec {
-    double v;
-  };
-  double *mats = nullptr;  // LDS [2][m][m]
-  __device__ __forceinline__ double sv_get(const SVec &a, int k) const { return rdlane(a.v, k); }
-  __device__ __forceinline__ void sv_set(SVec &a, int k, double x) const { a.v = (lane_id() == k) ? x : a.v; }
-  __device__ __forceinline__ void sv_scale(SVec &a, double s_) const { a.v *= s_; }
-  // ps[k] = s_k . v, py[k] = y_k . v for all m slots: 2m INDEPENDENT dot products (slots that hold no pair yet give
-  // garbage in their lanes, which every consumer masks by the chronological index)
-  __device__ __forceinline__ void hist_dots(const Vec &v, SVec &ps, SVec &py) const {
-    const int lane = lane_id();
-    ps.v = 0.0;
-    py.v = 0.0;
-    // the 2m history rows (s_0..s_{m-1}, y_0..y_{m-1}) four at a time: per-lane partial products, then wave_sum4
-    static_assert((2 * NEO_LBFGS_M) % 4 == 0, "rows are reduced in groups of four");
-#pragma unroll
-    for (int g = 0; g < 2 * NEO_LBFGS_M / 4; ++g) {
-      double part[4], tot[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = 4 * g + e;  // row of `hist`: s_row for row < m, y_{row-m} beyond
-        double a = 0.0;
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-          const bool in = q * kWave + lane < t.n;
-          const double hv = in ? (double)hist[row * t.n + q * kWave + lane] : 0.0;
-          a += hv * v.v[q];
-        }
-        part[e] = a;
-      }
-      wave_sum4(part[0], part[1], part[2], part[3], tot[0], tot[1], tot[2], tot[3]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = 4 * g + e;
-        if (row < NEO_LBFGS_M)
-          ps.v = (lane == row) ? tot[e] : ps.v;
-        else
-          py.v = (lane == row - NEO_LBFGS_M) ? tot[e] : py.v;
-      }
-    }
-  }
-  __device__ __forceinline__ void mat_put_col(int slot, const SVec &sy, const SVec &yy) {
-    const int lane = lane_id();
-    if (lane < NEO_LBFGS_M) {
-      mats[lane * NEO_LBFGS_M + slot] = sy.v;
-      mats[NEO_LBFGS_M * NEO_LBFGS_M + lane * NEO_LBFGS_M + slot] = yy.v;
-      mats[NEO_LBFGS_M * NEO_LBFGS_M + slot * NEO_LBFGS_M + lane] = yy.v;
-    }
-    lds_wave_sync();
-  }
-  __device__ __forceinline__ void sv_init_w(SVec &w, const SVec &u, const SVec &b, double gamma) const {
-    const int lane = lane_id();
-    const double dii = lane < NEO_LBFGS_M ? mats[lane * NEO_LBFGS_M + lane] : 0.0;
-    w.v = dii * u.v - gamma * b.v;
-  }
-  __device__ __forceinline__ void sv_axpy_mat(SVec &u, double coef, int which, int j, int lo, int hi, int head) const {
-    const int lane = lane_id();
-    const int i = lane < NEO_LBFGS_M ? lane : 0;
-    int li = i - head;
-    li += li < 0 ? NEO_LBFGS_M : 0;  // chronological index of slot i
-    const bool on = lane < NEO_LBFGS_M && li >= lo && li < hi;
-    const int idx = which == 0 ? i * NEO_LBFGS_M + j
-                               : (which == 1 ? j * NEO_LBFGS_M + i : NEO_LBFGS_M * NEO_LBFGS_M + i * NEO_LBFGS_M + j);
-    const double mv = mats[idx];
-    u.v = on ? u.v + coef * mv : u.v;
-  }
-  __device__ __forceinline__ void hist_combine(Vec &d, const SVec &cs, const SVec &cy, int col, int head) const {
-    const int lane = lane_id();
-    for (int kk = 0; kk < col; ++kk) {
-      int k = head + kk;
-      k -= k >= m ? m : 0;
-      const double a = rdlane(cs.v, k), b = rdlane(cy.v, k);
-#pragma unroll
-      for (int q = 0; q < NS; ++q) {
-        const bool in = q * kWave + lane < t.n;
-        const double sv = in ? (double)hist[k * t.n + q * kWave + lane] : 0.0;
-        const double yv = in ? (double)hist[(m + k) * t.n + q * kWave + lane] : 0.0;
-        d.v[q] += a * sv + b * yv;
-      }
-    }
-  }
-
   // the 2m wave-uniform scalars of the two-loop recursion (rho, alpha): entry i lives in lane i of one register
   // pair, written with a select and read back with v_readlane -- no LDS round trip on the recursion's dependent chain
   Num sreg = Num(0);
@@ -274,25 +186,30 @@ struct DevBackend {
     for (int k = 0; k < NS; ++k) s += a.v[k] * b.v[k];
     return (double)(rdlane(sreg, slot) * wave_sum(s));
   }
-#ifndef NEO_LS_IN_REGS  // measured: LDS is faster (registers spill: 14.0 vs 15.5 ms at cfg2)
+  // (line-search state and cost terms in LDS: in registers they spill, measured 14.0 against 15.5 ms at cfg2)
   __device__ __forceinline__ LineSearch &ls() { return *lsp; }
   __device__ __forceinline__ double *cost_store() { return cst; }
-#else
-  // registers: with one wave per SIMD the file is not the binding constraint, LDS round trips are
-  LineSearch ls_reg;
-  double cst_reg[12];
-  __device__ __forceinline__ LineSearch &ls() { return ls_reg; }
-  __device__ __forceinline__ double *cost_store() { return cst_reg; }
-#endif
 
-  // diagnostics (neo_optimize_trace): one record per counted evaluation
-  __device__ __forceinline__ void note_eval(int nfev, int iter, double stp, double f) {
+  // diagnostics (neo_optimize_trace / neo_optimize_trace_xg): one record per counted evaluation -- (f, step, samples,
+  // iteration) and, when asked for, the evaluated point and its gradient (replay tests: every evaluation of a run is laid
+  // beside the CPU oracle's at the same point)
+  __device__ __forceinline__ void note_eval(int nfev, int iter, double stp, double f, const Vec &x, const Vec &g) {
     if (trace != nullptr && nfev <= trace_cap && lane_id() == 0) {
       double *r = trace + (size_t)(nfev - 1) * 4;
       r[0] = f;
       r[1] = stp;
       r[2] = (double)last_ns;
       r[3] = (double)iter;
+    }
+    if (trace_xg != nullptr && nfev <= trace_cap) {
+      const int lane = lane_id();
+      double *r = trace_xg + (size_t)(nfev - 1) * 2 * t.n;
+#pragma unroll
+      for (int k = 0; k < NS; ++k)
+        if (k * kWave + lane < t.n) {
+          r[k * kWave + lane] = (double)x.v[k];
+          r[t.n + k * kWave + lane] = (double)g.v[k];
+        }
     }
   }
 
@@ -479,7 +396,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
 template <int D, int NS, typename Real, class MapT, class LookupT, int WAVES, class LG = WaveLanes, typename Num = double>
 __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ? NEO_X_OCC : NEO_W2_OCC) : 1)) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
                                                           const int *__restrict__ scene_slot, int nmaps,
-                                                          double *__restrict__ x,
+                                                          const double *x0, double *x,
                                                           const double *__restrict__ head,
                                                           const double *__restrict__ tail,
                                                           double *__restrict__ costs4,
@@ -488,19 +405,11 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
                                                           int *__restrict__ status,
                                                           long long *__restrict__ nsamples,
                                                           const int *__restrict__ order, double *__restrict__ trace,
-                                                          int trace_cap, int stage) {
-  // The direction d = -H g is the two-loop recursion, the form pinned to SciPy's iterates (neo_lbfgs_dir.hpp).
-  // -DNEO_COMPACT_DIRECTION=1 builds the fp32-sampling kernels with the compact representation instead (its two m x m
-  // matrices in LDS).  Measured on MI355X at cfg2 (two waves per SIMD, per evaluation): 28.4 us with one reduction per
-  // history row, 24.3 us with the rows reduced four at a time (wave_sum4), against 21.7 us for the two-loop recursion
-  // -- with two waves sharing a SIMD the 2*col extra dot products of the pair update and the 3*col steps of the
-  // triangular solves cost more issue slots than the shorter dependence chain gives back; 690 k -> 551 k traj/s.
-  constexpr bool kCompact = NEO_COMPACT_DIRECTION && sizeof(Real) == 4;
+                                                          double *__restrict__ trace_xg, int trace_cap, int stage) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
   __shared__ double sc[2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm;
   __shared__ double cst[12];
-  __shared__ double mats[kCompact ? 2 * NEO_LBFGS_M * NEO_LBFGS_M : 1];
   if ((int)blockIdx.x >= B) return;
   // workgroups are dispatched in index order: `order` lets the caller start the runs it expects to
   // be long first (list scheduling: a long run that starts last sets the duration of the launch)
@@ -527,10 +436,10 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   be.lsp = &lsm;
   be.cst = cst;
   be.m = NEO_LBFGS_M;
-  be.mats = mats;
   be.coeff_out = nullptr;
   be.trace = trace ? trace + (size_t)b * trace_cap * 4 : nullptr;
   be.trace_cap = trace_cap;
+  be.trace_xg = trace_xg ? trace_xg + (size_t)b * trace_cap * 2 * (D * (M - 1) + M) : nullptr;
   load_boundary(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
   const int n = be.t.n;
   be.npad = NS * kWave;
@@ -538,7 +447,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   const int lane = lane_id();
   typename BE::Vec xv;
 #pragma unroll
-  for (int k = 0; k < NS; ++k) xv.v[k] = (k * kWave + lane < n) ? x[(size_t)b * n + k * kWave + lane] : 0.0;
+  for (int k = 0; k < NS; ++k) xv.v[k] = (k * kWave + lane < n) ? x0[(size_t)b * n + k * kWave + lane] : 0.0;
   LbfgsOpts o{prm.ftol, prm.gtol, prm.maxls, prm.maxiter, prm.maxfun, NEO_LBFGS_M};
   LbfgsResult res;
 #ifdef NEO_STAMPS
@@ -549,7 +458,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   // two-waves kernel.  Four FLAT slots (n > 128, cfg5): the compiler keeps the machine's vectors in private memory
   // (1 KB of scratch, 3x slower), so those instantiations run the straight-line form.
   if constexpr (NS <= 2) {
-    LbfgsMachine<BE, kCompact> mach(be, o);
+    LbfgsMachine<BE> mach(be, o);
     mach.x = xv;
     mach.begin();
     while (mach.need_eval()) {
@@ -559,7 +468,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
     mach.result(res);
     xv = mach.x;
   } else {
-    lbfgs_minimize<BE, kCompact>(be, xv, o, res);
+    lbfgs_minimize<BE>(be, xv, o, res);
   }
 #ifdef NEO_STAMPS
   if (lane == 0 && nsamples) {  // the counter buffer is [B][8] in this build

@@ -22,9 +22,9 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
     const int stage = pairs + (size_t)full * 8 <= lds_share ? full : small;                                   \
     hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES, LG, Num>), grid, blk,                   \
                        pairs + (size_t)stage * 8, c->stream, a.B, a.M, c->dev,                                \
-                       static_cast<const MapT *>(a.table), a.slots, a.nmaps, a.x, a.head, a.tail, a.costs4,   \
+                       static_cast<const MapT *>(a.table), a.slots, a.nmaps, a.x0 ? a.x0 : a.x, a.x, a.head, a.tail, a.costs4,   \
                        a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter,                             \
-                       (c->order_B == a.B ? c->dispatch_order : nullptr), c->trace, c->trace_cap, stage);     \
+                       (c->order_B == a.B ? c->dispatch_order : nullptr), c->trace, c->trace_xg, c->trace_cap, stage);     \
   } while (0)
   // lane = (piece, dimension) whenever D * M fits the wavefront (cfg2: 63 lanes busy in the PIECE-layout phases
   // instead of 21, a third of the per-dimension state per lane); lane = piece otherwise.  flags bit 512 forces the
@@ -41,7 +41,11 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
     case 1: NEO_OPT(1); break;
     case 2: NEO_OPT(2); break;
     default:
-      if constexpr (WAVES == 1 || NEO_W2_MAX_SLOTS >= 4) NEO_OPT_LG(4, WaveLanes);  // (two waves only up to NEO_W2_MAX_SLOTS)
+      if constexpr (WAVES == 1 || NEO_W2_MAX_SLOTS >= 4)
+        NEO_OPT_LG(4, WaveLanes);  // (two waves only up to NEO_W2_MAX_SLOTS)
+      else
+        return fail(c, NEO_ERR_INVALID, "n > 128 variables: this build has no two-waves kernel for four FLAT slots "
+                                        "(NEO_W2_MAX_SLOTS < 4)");
       break;
   }
 #undef NEO_OPT_LG

@@ -58,9 +58,10 @@ struct LbfgsResult {
 //   LineSearch& ls(); double* cost_store();   storage for the search state and 3 x 4 cost terms
 //       (on the GPU both live in LDS: wave-uniform data that would otherwise pin ~50 VGPRs)
 //   int  eval(const Vec& x, double& f, Vec& g, double* costs4);   0 = ok
-//   void note_eval(int nfev, int iter, double stp, double f);     diagnostics hook after every counted evaluation
-//       (a no-op in the product unless a trace buffer was given: neo_optimize_trace)
-template <class Backend, bool COMPACT = false>
+//   void note_eval(int nfev, int iter, double stp, double f, const Vec& x, const Vec& g);   diagnostics hook after every
+//       counted evaluation: the point just evaluated, its value and gradient (a no-op in the product unless a trace
+//       buffer was given: neo_optimize_trace / neo_optimize_trace_xg)
+template <class Backend>
 NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpts &o,
                            LbfgsResult &res) {
   using Vec = typename Backend::Vec;
@@ -87,7 +88,7 @@ NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpt
 
   int est = be.eval(x, f, g, costs);
   nfev++;
-  be.note_eval(nfev, 0, 0.0, f);
+  be.note_eval(nfev, 0, 0.0, f, x, g);
   for (int k = 0; k < 4; ++k) cur[k] = costs[k];
   if (est != 0) return finish(est);
   if (!(f - f == 0.0)) return finish(TERM_NONFINITE);
@@ -95,7 +96,7 @@ NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpt
 
   for (;;) {
     // ---- search direction
-    lbfgs_direction<COMPACT>(be, g, d, tmp, tmp2, col, head, o.m, theta);
+    lbfgs_direction(be, g, d, tmp, tmp2, col, head, o.m, theta);
 
     // ---- line search (lnsrlb)
     be.copy(t, x);
@@ -141,7 +142,7 @@ NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpt
         be.lincomb(x, t, stp, d);
         est = be.eval(x, f, g, costs);
         nfev++;
-        be.note_eval(nfev, iter, stp, f);
+        be.note_eval(nfev, iter, stp, f, x, g);
         if (est != 0) {
           term = est;
           break;
@@ -205,7 +206,6 @@ NEO_HD void lbfgs_minimize(Backend &be, typename Backend::Vec &x, const LbfgsOpt
     be.hist_put(slot, d, r);
     be.sput(slot, 1.0 / dr);
     theta = rr / dr;
-    lbfgs_pair_stored<COMPACT>(be, slot, r);
   }
 }
 

@@ -22,7 +22,7 @@
 
 namespace neo {
 
-template <class Backend, bool COMPACT = false>
+template <class Backend>
 struct LbfgsMachine {
   using Vec = typename Backend::Vec;
   enum : int { PH_FIRST = 0, PH_LS = 1, PH_DONE = 2 };
@@ -72,7 +72,7 @@ struct LbfgsMachine {
     int next;
     if (phase == PH_FIRST) {
       nfev++;
-      be.note_eval(nfev, 0, 0.0, f);
+      be.note_eval(nfev, 0, 0.0, f, x, g);
       for (int k = 0; k < 4; ++k) cur()[k] = costs()[k];
       if (est != 0) return finish(est);
       if (!(f - f == 0.0)) return finish(TERM_NONFINITE);
@@ -82,7 +82,7 @@ struct LbfgsMachine {
     } else {
       // an evaluation inside the line search
       nfev++;
-      be.note_eval(nfev, iter, stp, f);
+      be.note_eval(nfev, iter, stp, f, x, g);
       if (est != 0) {
         for (int k = 0; k < 4; ++k) cur()[k] = costs()[k];
         return finish(est);
@@ -100,7 +100,7 @@ struct LbfgsMachine {
       if (next == DO_START_ITER) {
         // ---- search direction
         NEO_SM_STAMP(0);
-        lbfgs_direction<COMPACT>(be, g, d, tmp, tmp2, col, head, o.m, theta);
+        lbfgs_direction(be, g, d, tmp, tmp2, col, head, o.m, theta);
         NEO_SM_STAMP(1);
         // ---- line search set-up (lnsrlb)
         be.copy(t, x);
@@ -195,7 +195,6 @@ struct LbfgsMachine {
         be.hist_put(slot, d, r);
         be.sput(slot, 1.0 / dr);
         theta = be.uni(rr / dr);
-        lbfgs_pair_stored<COMPACT>(be, slot, r);
       }
     }
   }

@@ -18,6 +18,7 @@ NEO_TRAJ_FLAG_COLLISION = 0x100
 NEO_KERNEL_EVAL, NEO_KERNEL_OPTIMIZE, NEO_KERNEL_ESDF_BUILD, NEO_KERNEL_ESDF_SAMPLE = 0, 1, 2, 3
 NEO_FLAG_ONE_WAVE_PER_SIMD, NEO_FLAG_TWO_WAVES_PER_SIMD, NEO_FLAG_LANE_GROUPS = 32, 64, 128
 NEO_FLAG_F32_SOLVE = 2048
+NEO_FLAG_ONE_WAVE_PER_TRAJECTORY = 4096
 
 # every symbol include/neo_planner.h declares (tests check the library exports them all)
 EXPORTS = [
@@ -29,6 +30,7 @@ EXPORTS = [
     "neo_profile_reset", "neo_optimize_sample_counter", "neo_optimize_dispatch_order",
     "neo_sampled_terms_batch", "neo_sampled_terms_batch_dev", "neo_esdf_build_3d",
     "neo_optimize_dispatch_order_host", "neo_ctx_set_stream", "neo_optimize_trace",
+    "neo_optimize_batch_from_dev", "neo_optimize_trace_xg",
 ]
 
 
@@ -85,6 +87,7 @@ def load():
     L.neo_cost_grad_batch_dev.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 8
     L.neo_optimize_batch.argtypes = [c_p, c_i, c_p, c_i, c_i, c_i] + [c_p] * 8
     L.neo_optimize_batch_dev.argtypes = [c_p, c_i, c_p, c_i, c_i, c_i] + [c_p] * 8
+    L.neo_optimize_batch_from_dev.argtypes = [c_p, c_i, c_p, c_i, c_i, c_i] + [c_p] * 9
     L.neo_scene_slot.argtypes = [c_p, c_i]
     L.neo_optimize_workspace_bytes.argtypes = [c_i, c_i, c_i]
     L.neo_optimize_workspace_bytes.restype = ctypes.c_size_t
@@ -94,6 +97,7 @@ def load():
     L.neo_profile_reset.argtypes = [c_p]
     L.neo_optimize_sample_counter.argtypes = [c_p, c_p]
     L.neo_optimize_trace.argtypes = [c_p, c_p, c_i]
+    L.neo_optimize_trace_xg.argtypes = [c_p, c_p, c_i]
     L.neo_optimize_dispatch_order.argtypes = [c_p, c_p, c_i]
     L.neo_optimize_dispatch_order_host.argtypes = [c_p, c_p, c_i]
     L.neo_sampled_terms_batch.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 5

@@ -3,6 +3,7 @@
 The library is several translation units -- the C ABI plus one unit per kernel family (neo_disp_*.hip) -- compiled
 in parallel and linked into one shared object; objects are cached under csrc/build/ by source time stamps."""
 import concurrent.futures
+import hashlib
 import os
 import shutil
 import subprocess
@@ -16,7 +17,8 @@ OBJDIR = os.path.join(CSRC, "build")
 SOURCES = ["neo_abi.hip", "neo_disp_eval.hip", "neo_disp_sample.hip", "neo_disp_opt2d.hip", "neo_disp_opt3d_f32.hip",
            "neo_disp_opt3d_f64.hip", "neo_disp_opt3d_w2.hip", "neo_disp_opt3d_x.hip", "neo_disp_group.hip"]
 HEADERS = ["neo_device.hpp", "neo_kernels.hpp", "neo_host.hpp", "neo_launch_opt.hpp", "neo_lbfgs.hpp",
-           "neo_linesearch.hpp", "neo_lbfgs_sm.hpp", "neo_lbfgs_dir.hpp", "neo_group_kernel.hpp"]
+           "neo_linesearch.hpp", "neo_lbfgs_sm.hpp", "neo_lbfgs_dir.hpp", "neo_group_kernel.hpp", "neo_sample_wg.hpp"]
+STAMP = LIB + ".stamp"    # key of the command lines the library was built with (travels with the library)
 
 
 def _hipcc():
@@ -54,18 +56,28 @@ def _compile(src, obj, verbose):
     os.replace(obj + ".tmp", obj)
 
 
+def _key(src=None):
+    """hash of everything besides the sources that decides what the compiler produces: this file (options, per-unit
+    options, source list) and the experiment definitions -- an object or library built with other options is not
+    reused"""
+    h = hashlib.sha256()
+    h.update(open(os.path.abspath(__file__), "rb").read())
+    h.update(" ".join(_flags() + (UNIT_FLAGS.get(src, []) if src else [])).encode())
+    return h.hexdigest()[:12]
+
+
 def build(force=False, verbose=False, jobs=None):
     """compile the translation units that are missing or older than their sources (in parallel), link; returns the
     library's path"""
     src_t = max([_newest_header()] + [os.path.getmtime(os.path.join(CSRC, s)) for s in SOURCES])
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= src_t:
+    stamp = open(STAMP).read().strip() if os.path.exists(STAMP) else ""
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= src_t and stamp == _key():
         return LIB          # (the GPU box receives the built library without the object cache)
     os.makedirs(OBJDIR, exist_ok=True)
-    tag = "_".join(os.environ.get("NEO_BUILD_DEFS", "").split()).replace("-D", "").replace("=", "-")
     hdr_t = _newest_header()
     todo, objs = [], []
     for s in SOURCES:
-        obj = os.path.join(OBJDIR, s.replace(".hip", (("." + tag) if tag else "") + ".o"))
+        obj = os.path.join(OBJDIR, s.replace(".hip", "." + _key(s) + ".o"))
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(os.path.join(CSRC, s))):
             todo.append((s, obj))
@@ -78,6 +90,8 @@ def build(force=False, verbose=False, jobs=None):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    with open(STAMP, "w") as f:
+        f.write(_key() + "\n")
     return LIB
 
 

@@ -483,13 +483,15 @@ class BatchPlanner:
         slack = ts.sum(axis=1) * self.cfg.v_max / np.maximum(dist, 1e-9)
         return np.argsort(-slack, kind="stable").astype(np.int32)
 
-    def optimize_dev(self, map, x, head, tail, costs, costs_last, nit, nfev, status, slots=None):
+    def optimize_dev(self, map, x, head, tail, costs, costs_last, nit, nfev, status, slots=None, x0=None):
         """torch CUDA tensors (float64 / int32), asynchronous on the context's stream.
-        `slots`: optional int32 device tensor of map-table slots (Context.lib.neo_scene_slot)."""
+        `slots`: optional int32 device tensor of map-table slots (Context.lib.neo_scene_slot).
+        `x0`: optional start points (only read; results go to x) -- None: x is optimised in place."""
         B, n = x.shape
         D = head.shape[2]
         M = (n + D) // (D + 1)
         c = self.ctx
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-        c.check(c.lib.neo_optimize_batch_dev(c.h, map.scene_id, p(slots), B, M, D, p(x), p(head), p(tail), p(costs),
-                                             p(costs_last), p(nit), p(nfev), p(status)))
+        c.check(c.lib.neo_optimize_batch_from_dev(c.h, map.scene_id, p(slots), B, M, D, p(x0 if x0 is not None else x),
+                                                  p(x), p(head), p(tail), p(costs), p(costs_last), p(nit), p(nfev),
+                                                  p(status)))

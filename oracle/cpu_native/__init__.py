@@ -74,6 +74,7 @@ def load():
         L.mc_grad.argtypes = [c_p, c_p, c_p, c_p, c_p, c_p, c_p]
         L.mc_optimize_batch.argtypes = [ctypes.POINTER(Params), ctypes.POINTER(Map), c_i, c_i, c_i] + [c_p] * 8 + \
                                        [c_i, c_d, c_p, c_p, c_i]
+        L.mc_eval_points.argtypes = [ctypes.POINTER(Params), ctypes.POINTER(Map), c_i, c_i, c_p, c_p, c_i] + [c_p] * 5
         _lib = L
     return _lib
 
@@ -218,6 +219,22 @@ class NativePlanner:
         self.final_cost = self.weighted_cost.sum()
         if self.weighted_cost[3] > self.collision_cost_tol:
             raise ValueError("collision cost too large")
+
+
+def eval_points(map, x, head, tail, M, D, params=None):
+    """cost / cost terms / gradient at the points x [E][n] of one trajectory (head, tail [3][D]); status 4 where the
+    reference raises OverflowError.  Returns dict(f [E], costs [E][4], grad [E][n], status [E])."""
+    L = load()
+    p = params if params is not None else make_params()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    E, n = x.shape
+    head = np.ascontiguousarray(head, dtype=np.float64)
+    tail = np.ascontiguousarray(tail, dtype=np.float64)
+    f = np.zeros(E); c4 = np.zeros((E, 4)); g = np.zeros((E, n)); st = np.zeros(E, dtype=np.int32)
+    if L.mc_eval_points(ctypes.byref(p), ctypes.byref(map.c), M, D, head.ctypes.data, tail.ctypes.data, E, x.ctypes.data,
+                        f.ctypes.data, c4.ctypes.data, g.ctypes.data, st.ctypes.data) != 0:
+        raise ValueError("bad arguments")
+    return dict(f=f, costs=c4, grad=g, status=st)
 
 
 def optimize_batch(map, x0, head, tail, M, D, params=None, threads=1, limit_s=0.0, trace_cap=0):

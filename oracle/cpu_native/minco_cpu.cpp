@@ -549,60 +549,11 @@ struct HostBackend {
     hist_get_y(slot, y);
   }
 
-  // ---- compact-form direction (csrc/neo_lbfgs_dir.hpp): one entry per history slot, S'Y and Y'Y as m x m arrays
-  struct SVec {
-    double v[16];
-  };
-  std::vector<double> SYm, YYm;
-  double sv_get(const SVec &a, int k) const { return a.v[k]; }
-  void sv_set(SVec &a, int k, double x) const { a.v[k] = x; }
-  void sv_scale(SVec &a, double s) const {
-    for (int k = 0; k < m; ++k) a.v[k] *= s;
-  }
-  void hist_dots(const Vec &x, SVec &ps, SVec &py) const {
-    for (int k = 0; k < m; ++k) {
-      double a = 0, b = 0;
-      for (int i = 0; i < n; ++i) {
-        a += S[size_t(k) * n + i] * x[i];
-        b += Y[size_t(k) * n + i] * x[i];
-      }
-      ps.v[k] = a;
-      py.v[k] = b;
-    }
-  }
-  void mat_put_col(int slot, const SVec &sy, const SVec &yy) {
-    if (SYm.empty()) {
-      SYm.assign(size_t(m) * m, 0.0);
-      YYm.assign(size_t(m) * m, 0.0);
-    }
-    for (int i = 0; i < m; ++i) {
-      SYm[size_t(i) * m + slot] = sy.v[i];
-      YYm[size_t(i) * m + slot] = yy.v[i];
-      YYm[size_t(slot) * m + i] = yy.v[i];
-    }
-  }
-  void sv_init_w(SVec &w, const SVec &u, const SVec &b, double gamma) const {
-    for (int i = 0; i < m; ++i) w.v[i] = SYm[size_t(i) * m + i] * u.v[i] - gamma * b.v[i];
-  }
-  void sv_axpy_mat(SVec &u, double coef, int which, int j, int lo, int hi, int head) const {
-    for (int i = 0; i < m; ++i) {
-      const int li = (i - head + m) % m;
-      if (li < lo || li >= hi) continue;
-      const double mv = which == 0 ? SYm[size_t(i) * m + j] : (which == 1 ? SYm[size_t(j) * m + i] : YYm[size_t(i) * m + j]);
-      u.v[i] += coef * mv;
-    }
-  }
-  void hist_combine(Vec &d, const SVec &cs, const SVec &cy, int col, int head) const {
-    for (int kk = 0; kk < col; ++kk) {
-      const int k = (head + kk) % m;
-      for (int i = 0; i < n; ++i) d[i] += cs.v[k] * S[size_t(k) * n + i] + cy.v[k] * Y[size_t(k) * n + i];
-    }
-  }
   void sput(int i, double v) { scal[i] = v; }
   double sget(int i) const { return scal[i]; }
   double *trace = nullptr;  // optional [trace_cap][4]: (f, step, samples, iteration) per counted evaluation
   int trace_cap = 0;
-  void note_eval(int nfev, int iter, double stp, double f) {
+  void note_eval(int nfev, int iter, double stp, double f, const Vec &, const Vec &) {
     if (trace && nfev <= trace_cap) {
       double *r = trace + (size_t)(nfev - 1) * 4;
       int ns = 0;
@@ -679,6 +630,23 @@ int mc_grad(void *h, const double *x, double *grad, double *coeffs, double *grad
   if (grad_T) memcpy(grad_T, pl->gradT.data(), pl->gradT.size() * sizeof(double));
   if (ts) memcpy(ts, pl->ts.data(), pl->ts.size() * sizeof(double));
   return st;
+}
+
+// cost, cost terms and gradient at E given points x[E][n] of ONE trajectory (head, tail): what the replay tests lay beside
+// every point a GPU run evaluated.  st[E] = 0 or 4 (the reference's OverflowError).
+int mc_eval_points(const mc_params *p, const mc_map *m, int M, int D, const double *head, const double *tail, int E,
+                   const double *x, double *f, double *costs4, double *grad, int32_t *st) {
+  if (!p || !m || M < 1 || M > 64 || D < 2 || D > 3 || E < 0) return -1;
+  const int n = D * (M - 1) + M;
+  Planner pl(*p, *m, M, D, head, tail);
+  for (int e = 0; e < E; ++e) {
+    pl.evals++;
+    int s_ = pl.cost(x + (size_t)e * n, f + e);
+    for (int k = 0; k < 4; ++k) costs4[(size_t)e * 4 + k] = pl.costs[k];
+    if (!s_) s_ = pl.grad(x + (size_t)e * n, grad + (size_t)e * n);
+    st[e] = s_;
+  }
+  return 0;
 }
 
 // plan_once for B trajectories on `threads` host threads, optimiser = csrc/neo_lbfgs.hpp on plain arrays.

@@ -67,62 +67,13 @@ struct HostBackend {
     hist_get_y(slot, y);
   }
 
-  // ---- compact-form direction (csrc/neo_lbfgs_dir.hpp): one entry per history slot, S'Y and Y'Y as m x m arrays
-  struct SVec {
-    double v[16];
-  };
-  std::vector<double> SYm, YYm;
-  double sv_get(const SVec &a, int k) const { return a.v[k]; }
-  void sv_set(SVec &a, int k, double x) const { a.v[k] = x; }
-  void sv_scale(SVec &a, double s) const {
-    for (int k = 0; k < m; ++k) a.v[k] *= s;
-  }
-  void hist_dots(const Vec &x, SVec &ps, SVec &py) const {
-    for (int k = 0; k < m; ++k) {
-      double a = 0, b = 0;
-      for (int i = 0; i < n; ++i) {
-        a += S[size_t(k) * n + i] * x[i];
-        b += Y[size_t(k) * n + i] * x[i];
-      }
-      ps.v[k] = a;
-      py.v[k] = b;
-    }
-  }
-  void mat_put_col(int slot, const SVec &sy, const SVec &yy) {
-    if (SYm.empty()) {
-      SYm.assign(size_t(m) * m, 0.0);
-      YYm.assign(size_t(m) * m, 0.0);
-    }
-    for (int i = 0; i < m; ++i) {
-      SYm[size_t(i) * m + slot] = sy.v[i];
-      YYm[size_t(i) * m + slot] = yy.v[i];
-      YYm[size_t(slot) * m + i] = yy.v[i];
-    }
-  }
-  void sv_init_w(SVec &w, const SVec &u, const SVec &b, double gamma) const {
-    for (int i = 0; i < m; ++i) w.v[i] = SYm[size_t(i) * m + i] * u.v[i] - gamma * b.v[i];
-  }
-  void sv_axpy_mat(SVec &u, double coef, int which, int j, int lo, int hi, int head) const {
-    for (int i = 0; i < m; ++i) {
-      const int li = (i - head + m) % m;
-      if (li < lo || li >= hi) continue;
-      const double mv = which == 0 ? SYm[size_t(i) * m + j] : (which == 1 ? SYm[size_t(j) * m + i] : YYm[size_t(i) * m + j]);
-      u.v[i] += coef * mv;
-    }
-  }
-  void hist_combine(Vec &d, const SVec &cs, const SVec &cy, int col, int head) const {
-    for (int kk = 0; kk < col; ++kk) {
-      const int k = (head + kk) % m;
-      for (int i = 0; i < n; ++i) d[i] += cs.v[k] * S[size_t(k) * n + i] + cy.v[k] * Y[size_t(k) * n + i];
-    }
-  }
   void sput(int i, double v) { scal[i] = v; }
   double sget(int i) { return scal[i]; }
   int eval(const Vec &x, double &f, Vec &g, double *costs) {
     fit(g, n);
     return cb(x.data(), n, &f, g.data(), costs, user);
   }
-  void note_eval(int, int, double, double) {}
+  void note_eval(int, int, double, double, const Vec &, const Vec &) {}
 };
 }  // namespace
 
@@ -137,50 +88,6 @@ int lbfgs_host_minimize(int n, double *x, double ftol, double gtol, int maxls, i
   neo::LbfgsResult res;
   neo::lbfgs_minimize(be, xv, o, res);
   memcpy(x, xv.data(), n * sizeof(double));
-  *f_out = res.f;
-  *nit = res.nit;
-  *nfev = res.nfev;
-  *status = res.status;
-  memcpy(costs, res.costs, sizeof(res.costs));
-  memcpy(costs_last, res.costs_last, sizeof(res.costs_last));
-  return 0;
-}
-
-// the loop form with the compact-representation direction (what the fp32-sampling kernels run)
-int lbfgs_host_minimize_compact(int n, double *x, double ftol, double gtol, int maxls, int maxiter,
-                                int maxfun, int m, eval_cb cb, void *user, double *f_out, int *nit,
-                                int *nfev, int *status, double *costs, double *costs_last) {
-  HostBackend be(n, m, cb, user);
-  HostBackend::Vec xv(x, x + n);
-  neo::LbfgsOpts o{ftol, gtol, maxls, maxiter, maxfun, m};
-  neo::LbfgsResult res;
-  neo::lbfgs_minimize<HostBackend, true>(be, xv, o, res);
-  memcpy(x, xv.data(), n * sizeof(double));
-  *f_out = res.f;
-  *nit = res.nit;
-  *nfev = res.nfev;
-  *status = res.status;
-  memcpy(costs, res.costs, sizeof(res.costs));
-  memcpy(costs_last, res.costs_last, sizeof(res.costs_last));
-  return 0;
-}
-
-// ... and through the state machine
-int lbfgs_host_minimize_sm_compact(int n, double *x, double ftol, double gtol, int maxls, int maxiter,
-                                   int maxfun, int m, eval_cb cb, void *user, double *f_out, int *nit,
-                                   int *nfev, int *status, double *costs, double *costs_last) {
-  HostBackend be(n, m, cb, user);
-  neo::LbfgsOpts o{ftol, gtol, maxls, maxiter, maxfun, m};
-  neo::LbfgsMachine<HostBackend, true> mach(be, o);
-  mach.x.assign(x, x + n);
-  mach.begin();
-  while (mach.need_eval()) {
-    const int est = be.eval(mach.x, mach.f, mach.g, mach.costs());
-    mach.advance(est);
-  }
-  neo::LbfgsResult res;
-  mach.result(res);
-  memcpy(x, mach.x.data(), n * sizeof(double));
   *f_out = res.f;
   *nit = res.nit;
   *nfev = res.nfev;
@@ -213,6 +120,55 @@ int lbfgs_host_minimize_sm(int n, double *x, double ftol, double gtol, int maxls
   memcpy(costs, res.costs, sizeof(res.costs));
   memcpy(costs_last, res.costs_last, sizeof(res.costs_last));
   return 0;
+}
+
+// REPLAY of a recorded run (tests/test_gpu_replay.py).  A device run recorded, per counted evaluation k < E, the point
+// it evaluated xr[k], the value fr[k], the gradient gr[k] and the cost terms cr[k] (neo_optimize_trace +
+// neo_optimize_trace_xg).  This runs the product's L-BFGS-B control flow (the state machine of csrc/neo_lbfgs_sm.hpp)
+// in fp64 on the host with those recorded values as its objective: at every evaluation the host's own trial point is
+// compared with the device's (x_dev[k] = max |x_host - x_dev| / max(1, max |x_dev|)), then REPLACED by it, so that
+// every step is judged on the device's own history and errors do not accumulate.  Outputs per evaluation: the host's
+// line-search step and iteration counter (to be laid beside the device's trace); per run: nit / nfev / status as the
+// host decides them, and `overrun` = 1 when the host asks for an evaluation the device never made.
+// last_est: the status the device's last evaluation returned (4 = NUMERIC_RANGE ends the run there).
+int lbfgs_host_replay(int n, int E, const double *xr, const double *fr, const double *gr, const double *cr, int last_est,
+                      double ftol, double gtol, int maxls, int maxiter, int maxfun, int m, double *x_dev,
+                      double *stp_host, int *iter_host, int *nit, int *nfev, int *status, int *overrun) {
+  HostBackend be(n, m, nullptr, nullptr);
+  neo::LbfgsOpts o{ftol, gtol, maxls, maxiter, maxfun, m};
+  neo::LbfgsMachine<HostBackend> mach(be, o);
+  mach.x.assign(xr, xr + n);
+  mach.g.assign(n, 0.0);
+  mach.begin();
+  int k = 0;
+  *overrun = 0;
+  while (mach.need_eval()) {
+    if (k >= E) {
+      *overrun = 1;
+      break;
+    }
+    const double *xk = xr + (size_t)k * n;
+    double dmax = 0.0, xmax = 1.0;
+    for (int i = 0; i < n; ++i) {
+      dmax = fmax(dmax, fabs(mach.x[i] - xk[i]));
+      xmax = fmax(xmax, fabs(xk[i]));
+    }
+    x_dev[k] = dmax / xmax;
+    stp_host[k] = k == 0 ? 0.0 : mach.stp;
+    iter_host[k] = mach.iter;
+    mach.x.assign(xk, xk + n);
+    mach.f = fr[k];
+    mach.g.assign(gr + (size_t)k * n, gr + (size_t)(k + 1) * n);
+    for (int q = 0; q < 4; ++q) mach.costs()[q] = cr ? cr[(size_t)k * 4 + q] : 0.0;
+    mach.advance(k == E - 1 ? last_est : 0);
+    ++k;
+  }
+  neo::LbfgsResult res;
+  mach.result(res);
+  *nit = res.nit;
+  *nfev = res.nfev;
+  *status = mach.need_eval() ? -1 : res.status;
+  return k;
 }
 
 // reverse-communication line search, state kept in a caller-provided 20-double blob

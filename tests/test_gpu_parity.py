@@ -263,6 +263,38 @@ def test_numeric_range_status_like_math_exp():
     assert out["status"][0] == 0 and np.isfinite(out["cost"][0]) and np.all(np.isfinite(out["grad"][0]))
 
 
+def test_all_fp32_mode_keeps_the_fp64_statuses_and_a_finite_gradient_for_runaway_tau():
+    """in the all-fp32 mode (Num = float) expf(-tau) overflows from -tau = 88.72 on; T is then T_min exactly
+    (as in fp64 to rounding), the gradient must stay finite (no inf / inf), and NUMERIC_RANGE must be raised where the
+    fp64 modes raise it (the tests are made on tau: -tau > 354.89 for the gradient, > 709.78 for the cost), not earlier
+    and not never.  The optimiser started there must end with a finite result and the same status as the mixed mode."""
+    rng = np.random.default_rng(11)
+    n = 40
+    dist = np.full((n, n, n), 5.0, np.float32)
+    dist[:, :, :4] = np.linspace(0.0, 1.0, 4)[None, None, :]
+    g3 = npa.ESDF3D(dist, 0.25, (0.0, -5.0, 0.0), store="f32", layout="yz4")
+    M, B = 5, 4
+    head, tail, wp, ts = _random_requests(rng, B, M, 3, (np.array([1.5, -4.0, 1.0]), np.array([8.5, 4.0, 8.0])))
+    for dtype in ("f32x", "f32", "f64"):
+        bp = npa.BatchPlanner(sample_dtype=dtype)
+        x = bp.pack_x(wp, ts)
+        nq = 3 * (M - 1)
+        for tau, want in ((-80.0, 0), (-100.0, 0), (-300.0, 0), (-354.0, 0), (-356.0, 4), (-400.0, 4), (-711.0, 4)):
+            xx = x.copy()
+            xx[:, nq + 1] = tau
+            out = bp.cost_grad(g3, xx, head, tail)
+            assert np.all(out["status"] == want), (dtype, tau, out["status"])
+            if want == 0:
+                assert np.all(np.isfinite(out["cost"])) and np.all(np.isfinite(out["grad"])), (dtype, tau)
+                # the duration sits on T_min: its tau entry of the gradient is (numerically) zero
+                assert np.all(np.abs(out["grad"][:, nq + 1]) <= 1e-20 * np.abs(out["grad"]).max(axis=1)), (dtype, tau)
+        xx = x.copy()
+        xx[:, nq + 1] = -100.0
+        r = bp.optimize(g3, xx, head, tail)
+        assert np.all(np.isfinite(r["x"])) and np.all(np.isfinite(r["final_cost"])), dtype
+        assert set(np.unique(r["status"])) <= {0, 1, 2}, (dtype, r["status"])
+
+
 # ----------------------------------------------------------------------------- the optimiser
 def _run_entry(pl, d, m):
     entry = str(d["entry"])
@@ -294,6 +326,11 @@ def _run_entry(pl, d, m):
 KNOWN_PARTED = {
     "g3_trace_replan_s4.npz": dict(x_rel_max=2e-4, cost_rel_max=1e-5, nfev=(40, 37)),
     "g3_trace_replan_s5.npz": dict(x_rel_max=2e-4, cost_rel_max=1e-5, nfev=(35, 39)),
+    # a converging M = 21 run of 331 evaluations, far beyond the horizon over which ANY two implementations stay together
+    # (the product's own L-BFGS-B on the host, with a bit-identical objective, leaves SciPy's path at evaluation ~134:
+    # tests/test_lbfgs_host.py LONG_RUNS).  Asserted: the device follows the reference's recorded evaluations for at least
+    # the first 100 (test_parted_runs_first_divergence) and converges to a comparable minimum.
+    "g3_trace_once_M21_c0.npz": dict(x_rel_max=5e-2, cost_rel_max=2e-2, long_run=True),
 }
 
 
@@ -310,12 +347,14 @@ def test_planner_reproduces_reference_runs_g3_g5():
         pl = npa.MinJerkPlanner(npa.PlannerConfig())
         err = _run_entry(pl, d, m)
         assert err.split(":")[0] == str(d["error"]).split(":")[0], path
-        assert pl.iter_num == int(d["iter_num"]) and pl.opt_running_times == int(d["opt_running_times"]), path
+        known = KNOWN_PARTED.get(os.path.basename(path))
+        if not (known or {}).get("long_run"):
+            assert pl.iter_num == int(d["iter_num"]), path
+        assert pl.opt_running_times == int(d["opt_running_times"]), path
         last = int(d["n_runs"]) - 1
         exact = last < 0 or pl.last_nfev == int(d[f"r{last}_nfev"])
         n += 1
         n_exact += exact
-        known = KNOWN_PARTED.get(os.path.basename(path))
         if known is None:
             assert exact, (path, pl.last_nfev)
         if exact:
@@ -328,7 +367,7 @@ def test_planner_reproduces_reference_runs_g3_g5():
             assert abs(pl.final_cost - d["final_cost"]) <= ctol * abs(d["final_cost"]), path
             if "weighted_cost" in d.files and exact and str(d["entry"]) != "batch":
                 assert rel_err(pl.weighted_cost, d["weighted_cost"]) < 1e-9
-        if "state_cmd_60" in d.files:
+        if "state_cmd_60" in d.files and not (known or {}).get("long_run"):
             hz = int(d["state_cmd_hz"])
             st = pl.get_full_state_cmd(hz)
             assert st.shape == d["state_cmd_60"].shape
@@ -336,6 +375,53 @@ def test_planner_reproduces_reference_runs_g3_g5():
             assert rel_err(pl.get_pos_array(), d["pos_array"]) < max(tol, 1e-9) * 10
             assert rel_err(pl.get_vel_array(), d["vel_array"]) < max(tol, 1e-9) * 10
     assert n >= 18 and n_exact >= n - len(KNOWN_PARTED), (n_exact, n)
+
+
+def test_parted_runs_first_divergence():
+    """for every recorded reference run the device does not follow to its last evaluation
+    (KNOWN_PARTED), the LAST L-BFGS-B run is traced on the device (neo_optimize_trace_xg) and laid beside SciPy's
+    recorded evaluations: printed per run -- the first evaluation at which the evaluated points differ by more than 1e-7
+    -- and asserted: every evaluation before it agrees in f to 1e-9, and the first divergence is late (the parted flat
+    tails of the replan scenarios; evaluation >= 100 of 331 for the long converging run)."""
+    import ctypes
+    import os
+    from neo_planner_amd import _lib
+    for name, known in KNOWN_PARTED.items():
+        d = load(golden(name)[0])
+        m = _gpu_map(d)
+        last = int(d["n_runs"]) - 1
+        x0 = d[f"r{last}_x0"]
+        ref_x, ref_f = d[f"r{last}_eval_x"], d[f"r{last}_eval_f"]
+        M = (len(x0) + 2) // 3
+        hs = np.zeros((1, 3, 2)); tl = np.zeros((1, 3, 2))
+        hs[0, :d["head"].shape[0]] = d["head"]; tl[0, :d["tail"].shape[0]] = d["tail"]
+        import torch
+        dev = torch.device("cuda", 0)
+        ctx = m.ctx
+        cap = 512
+        tr = torch.zeros(1, cap, 4, dtype=torch.float64, device=dev)
+        xg = torch.zeros(1, cap, 2, len(x0), dtype=torch.float64, device=dev)
+        ctx.check(ctx.lib.neo_optimize_trace(ctx.h, ctypes.c_void_p(tr.data_ptr()), cap))
+        ctx.check(ctx.lib.neo_optimize_trace_xg(ctx.h, ctypes.c_void_p(xg.data_ptr()), cap))
+        try:
+            r = npa.BatchPlanner(ctx=ctx).optimize(m, x0[None], hs, tl)
+        finally:
+            ctx.check(ctx.lib.neo_optimize_trace(ctx.h, None, 0))
+            ctx.check(ctx.lib.neo_optimize_trace_xg(ctx.h, None, 0))
+        E = int(r["nfev"][0])
+        gx, gf = xg[0, :E, 0].cpu().numpy(), tr[0, :E, 0].cpu().numpy()
+        # SciPy records fun(x) calls; the point evaluated again from its cache does not appear twice there either
+        k = min(E, len(ref_x))
+        scale = np.maximum(np.abs(ref_x[:k]).max(axis=1), 1.0)
+        err = np.abs(gx[:k] - ref_x[:k]).max(axis=1) / scale
+        bad = np.flatnonzero(err > 1e-7)
+        first = int(bad[0]) if len(bad) else k
+        ferr = np.abs(gf[:first] - ref_f[:first]) / np.abs(ref_f[:first])
+        print(f"{name}: device {E} evaluations, SciPy {len(ref_x)}; evaluated points agree to 1e-7 up to evaluation {first} "
+              f"(max f deviation before it {ferr.max():.1e}); point deviation at 25/50/75/100 %% of the common run: "
+              f"{[float(err[int(q * (k - 1))]) for q in (0.25, 0.5, 0.75, 1.0)]}")
+        assert first >= (100 if known.get("long_run") else 0.8 * len(ref_x)), (name, first)
+        assert ferr.max() <= 1e-9, (name, ferr.max())
 
 
 def _oracle_plan_once(o_map, head, tail, wp, ts):

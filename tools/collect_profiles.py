@@ -24,6 +24,17 @@ PMC_GROUPS = [
     ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAVES"],
     ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES"],
     ["TCC_HIT_sum", "TCC_MISS_sum", "TCP_TCC_READ_REQ_sum"],
+    # which pipe is busy: cycles with an instruction of the type executing, per SIMD (quad-cycles,
+    # MI355X_MICROARCH.md "s_memtime tick vs SQ PMC units"), next to the CUs' busy cycles
+    ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_MISC",
+     "SQ_BUSY_CU_CYCLES", "SQ_CYCLES"],
+    ["SQ_INST_CYCLES_SALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_LDS_BANK_CONFLICT",
+     "SQ_LDS_IDX_ACTIVE"],
+    ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
+     "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32"],
+    ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
+     "SQ_INSTS_VALU_INT64", "SQ_INSTS_SMEM"],
+    ["GRBM_GUI_ACTIVE"],
 ]
 KERNELS = ["optimize_group_kernel", "optimize_kernel", "sample_kernel", "eval_kernel", "edt3_x", "edt3_y", "edt3_z", "pack3d"]
 
@@ -42,14 +53,31 @@ def main():
     extra = sys.argv[2:]
     os.makedirs(out, exist_ok=True)
     os.environ["TMPDIR"] = "/tmp"
-    bench = ["python3", "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu"] + extra
+    bench = ["python3", "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-modes"] + extra
     d = os.path.join(out, "trace")
     rc = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + bench,
              os.path.join(out, "trace.log"), 420)
     stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(stats[0], os.path.join(out, "kernel_stats.csv"))
-    print("kernel trace rc", rc, "stats", bool(stats))
+    # the same trace split by launch shape (rocprofv3's own stats merge every launch of a kernel name)
+    traces = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    if traces:
+        by = {}
+        with open(traces[0]) as f:
+            for row in csv.DictReader(f):
+                name = row["Kernel_Name"]
+                k = next((k for k in KERNELS if k in name), None)
+                if k is None:
+                    continue
+                wg = max(int(row["Workgroup_Size_X"]) if "Workgroup_Size_X" in row else int(row.get("Workgroup_Size", 64)), 1)
+                gs = int(row["Grid_Size_X"]) if "Grid_Size_X" in row else int(row.get("Grid_Size", 0))
+                by.setdefault(f"{k}@{gs // wg}", []).append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+        with open(os.path.join(out, "kernel_stats_by_grid.csv"), "w") as f:
+            f.write("kernel@workgroups,calls,avg_ns,min_ns,max_ns,total_ns\n")
+            for k, v in sorted(by.items()):
+                f.write(f"{k},{len(v)},{sum(v) / len(v):.1f},{min(v):.0f},{max(v):.0f},{sum(v):.0f}\n")
+    print("kernel trace rc", rc, "stats", bool(stats), "trace", bool(traces))
     agg = {}
     for gi, group in enumerate(PMC_GROUPS):
         d = os.path.join(out, f"pmc{gi}")
@@ -64,12 +92,22 @@ def main():
                     k = next((k for k in KERNELS if k in name), None)
                     if k is None:
                         continue
+                    # one entry per launch SHAPE: the stand-alone ESDF kernel runs on 4096 and on 65536 trajectories
+                    # in one bench run, and a mean over both belongs to neither
+                    wg = max(int(row["Workgroup_Size"]), 1)
+                    k = f"{k}@{int(row['Grid_Size']) // wg}"
+                    if "duration_ns" not in agg.setdefault(k, {}):
+                        agg[k]["duration_ns"] = [0.0, 0]
+                    if row["Counter_Name"] == group[0]:
+                        agg[k]["duration_ns"][0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                        agg[k]["duration_ns"][1] += 1
                     e = agg.setdefault(k, {}).setdefault(row["Counter_Name"], [0.0, 0])
                     e[0] += float(row["Counter_Value"])
                     e[1] += 1
         shutil.rmtree(d, ignore_errors=True)
     res = {"command": "rocprofv3 --pmc <group> --output-format csv -- " + " ".join(bench) + "  (one run per group)",
            "groups": PMC_GROUPS,
+           "keys": "kernel@workgroups of the launch; duration_ns = mean dispatch duration under the counter passes",
            "units": {"FETCH_SIZE": "KB per dispatch (raw counter; the 8-byte gathers are an uncalibrated access shape, "
                                    "no gfx950 correction applied)", "WRITE_SIZE": "KB per dispatch",
                      "SQ_*": "summed over the dispatch"},

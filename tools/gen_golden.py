@@ -379,8 +379,139 @@ def gen_g4():
     print("g4 done")
 
 
+# ---------------------------------------------------------------- G3b: converging M = 21 runs
+def gen_g3b(want=4, min_evals=60):
+    """`plan_once` at M = 21 from jittered straight lines, keeping the first `want` requests on which the reference
+    CONVERGES (no exception) after at least `min_evals` evaluations: long recorded runs at the benchmark's size.
+    (g3_trace_once_M21_s0/s1 of the original family both end in `collision cost too large`.)"""
+    cfg = yaml_config()
+    found = 0
+    for seed in range(2, 60):
+        if found >= want:
+            break
+        occ = synth.occupancy_2d(seed % 8)
+        m = ref_map(occ)
+        head, tail, wpts, ts = synth.replan_requests(1900 + seed, 1, 20, D=2)
+        out, _ = run_traced("once", cfg, m, head[0][:2], tail[0][:2], wpts[0], ts[0])
+        ok = (not out["error"]) and int(out["r0_nfev"]) >= min_evals
+        print(f"g3b candidate seed {seed}: nit {out['r0_nit']} nfev {out['r0_nfev']} err '{out['error']}' keep {ok}")
+        if not ok:
+            continue
+        out.update(occ=occ, res=synth.RES, origin=np.array([0.0, -15.0]), head=head[0][:2], tail=tail[0][:2],
+                   init_wpts=wpts[0], init_ts=ts[0], entry="once", np_seed=-1, request_seed=1900 + seed)
+        np.savez_compressed(os.path.join(OUT, f"g3_trace_once_M21_c{found}.npz"), **out)
+        found += 1
+    assert found == want, found
+
+
+# ---------------------------------------------------------------- G6: the reference against itself (VERDICT r2, item 1c)
+G6_REQUESTS = 64
+G6_ENVS = [("blas_threads_1", {"OPENBLAS_NUM_THREADS": "1", "OMP_NUM_THREADS": "1"}),
+           ("blas_threads_8", {"OPENBLAS_NUM_THREADS": "8", "OMP_NUM_THREADS": "8"}),
+           ("blas_coretype_haswell", {"OPENBLAS_NUM_THREADS": "1", "OMP_NUM_THREADS": "1", "OPENBLAS_CORETYPE": "Haswell"}),
+           ("blas_coretype_sandybridge", {"OPENBLAS_NUM_THREADS": "1", "OMP_NUM_THREADS": "1",
+                                          "OPENBLAS_CORETYPE": "Sandybridge"})]
+
+
+def g6_requests():
+    reqs = []
+    for k in range(G6_REQUESTS):
+        head, tail, wpts, ts = synth.replan_requests(2600 + k, 1, 20, D=2)
+        reqs.append((k % 8, head[0][:2], tail[0][:2], wpts[0], ts[0]))
+    return reqs
+
+
+def g6_child(path):
+    """runs the REAL plan_once on the G6 requests in THIS process' BLAS environment and stores the finals"""
+    cfg = yaml_config()
+    maps = {}
+    out = {}
+    for k, (ms, head, tail, wpts, ts) in enumerate(g6_requests()):
+        if ms not in maps:
+            maps[ms] = ref_map(synth.occupancy_2d(ms))
+        planner = _RefPlanner(cfg)
+        planner.read_planning_conditions(maps[ms], head, tail, wpts, ts)
+        err = ""
+        rec = _Recorder()
+        ref_ep.opt = rec
+        try:
+            planner.plan_once()
+        except Exception as ex:
+            err = f"{type(ex).__name__}:{ex}"
+        finally:
+            ref_ep.opt = scipy.optimize
+        if rec.runs:
+            res = rec.runs[0]["res"]
+            out[f"q{k}_x"] = res.x
+            out[f"q{k}_nfev"] = res.nfev
+            out[f"q{k}_nit"] = res.nit
+            out[f"q{k}_fun"] = np.float64(res.fun)
+        else:       # minimize() itself was left through an exception (OverflowError inside a callback)
+            out[f"q{k}_x"] = np.full(20 * 2 + 21, np.nan)
+            out[f"q{k}_nfev"] = -1
+            out[f"q{k}_nit"] = -1
+            out[f"q{k}_fun"] = np.float64(np.nan)
+        out[f"q{k}_error"] = err
+        out[f"q{k}_costs"] = np.array(planner.costs)
+    import numpy
+    try:
+        from threadpoolctl import threadpool_info
+        info = [f"{d.get('internal_api')} {d.get('version')} {d.get('architecture')} threads={d.get('num_threads')}"
+                for d in threadpool_info()]
+    except Exception:
+        info = []
+    out["blas_info"] = "; ".join(info)
+    np.savez_compressed(path, **out)
+
+
+def gen_g6():
+    """The same 64 M = 21 requests through the REAL reference under different BLAS environments (environment
+    variables only, no source change): how often does expert_planner.py part from ITSELF?  """
+    import subprocess
+    import tempfile
+    out = {"n_requests": G6_REQUESTS, "envs": np.array([e[0] for e in G6_ENVS])}
+    for k, (ms, head, tail, wpts, ts) in enumerate(g6_requests()):
+        out[f"q{k}_map_seed"] = ms
+        out[f"q{k}_head"] = head
+        out[f"q{k}_tail"] = tail
+        out[f"q{k}_init_wpts"] = wpts
+        out[f"q{k}_init_ts"] = ts
+    for s in range(8):
+        out[f"occ{s}"] = synth.occupancy_2d(s)
+    out["res"] = synth.RES
+    out["origin"] = np.array([0.0, -15.0])
+    with tempfile.TemporaryDirectory() as td:
+        for name, env in G6_ENVS:
+            e = dict(os.environ)
+            e.update(env)
+            path = os.path.join(td, name + ".npz")
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "g6child", path], env=e)
+            d = np.load(path)
+            for key in d.files:
+                out[f"{name}__{key}"] = d[key]
+            print(f"g6 {name}: {str(d['blas_info'])}")
+    base = G6_ENVS[0][0]
+    for name, _ in G6_ENVS[1:]:
+        nq = 40
+        dx = np.array([np.abs(out[f"{name}__q{k}_x"][:nq] - out[f"{base}__q{k}_x"][:nq]).max() /
+                       np.abs(out[f"{base}__q{k}_x"][:nq]).max() for k in range(G6_REQUESTS)])
+        dx = np.where(np.isnan(dx), np.inf, dx)
+        same = np.array([int(out[f"{name}__q{k}_nfev"]) == int(out[f"{base}__q{k}_nfev"]) for k in range(G6_REQUESTS)])
+        bit = np.array([np.array_equal(out[f"{name}__q{k}_x"], out[f"{base}__q{k}_x"]) for k in range(G6_REQUESTS)])
+        print(f"g6 {name} vs {base}: bit-identical finals {bit.mean():.3f}, same nfev {same.mean():.3f}, "
+              f"control points within 1e-4 {(dx <= 1e-4).mean():.3f}, median rel diff {np.median(dx):.2e}")
+    np.savez_compressed(os.path.join(OUT, "g6_reference_vs_itself.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "g6child":
+        g6_child(sys.argv[2])
+        sys.exit(0)
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4"]
+    if "g3b" in which:
+        gen_g3b()
+    if "g6" in which:
+        gen_g6()
     if "g1" in which:
         gen_g1()
     if "g2" in which:
