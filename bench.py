@@ -617,14 +617,27 @@ def main():
     elapsed = main_run["elapsed"]
     rank_rate = B * n_sets * a.steps / elapsed
     rccl_ranks, per_rank = None, None
+    gather_ok = None
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = dev if a.dist_backend == "nccl" else torch.device("cpu")     # (gloo: small host tensors)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist_.all_reduce(tmax, op=dist_.ReduceOp.MAX)
-        rates = torch.zeros(world, dtype=torch.float64, device=dev)
-        dist_.all_gather_into_tensor(rates, torch.tensor([rank_rate], dtype=torch.float64, device=dev))
+        rates = torch.zeros(world, dtype=torch.float64, device=cdev)
+        dist_.all_gather_into_tensor(rates, torch.tensor([rank_rate], dtype=torch.float64, device=cdev))
         per_rank = [float(v) for v in rates.cpu()]
         elapsed = float(tmax.item())
         rccl_ranks = dist_.get_world_size()
+        # the gathered rows are the ranks' rows: this rank's slice bit for bit, every rank's slice by its checksum
+        for bt in batches:
+            if bt.get("work") is not None:
+                bt["work"].wait()
+        torch.cuda.synchronize()
+        bt = batches[-1]
+        mine = bt["gathered"][rank * B:(rank + 1) * B]
+        sums = torch.zeros(world, dtype=torch.float64, device=cdev)
+        dist_.all_gather_into_tensor(sums, bt["packed"].double().nan_to_num().sum().reshape(1).to(cdev))
+        got = torch.stack([bt["gathered"][r_ * B:(r_ + 1) * B].double().nan_to_num().sum() for r_ in range(world)]).to(cdev)
+        gather_ok = bool(torch.equal(mine.view(torch.int32), bt["packed"].view(torch.int32)) and torch.equal(got, sums))
     mode_runs = {a.dtype: main_run}
     for m_ in modes[1:]:
         mode_runs[m_] = time_mode(m_)
@@ -799,7 +812,8 @@ def main():
                        "solve_and_optimiser_arithmetic": "f32" if a.dtype == "f32x" else "f64",
                        "parallelism": f"scene-sharded x{world}",
                        "launches_in_flight_per_gpu": n_lanes, "lane_groups": bool(a.lane_groups)},
-            "rccl_ranks": rccl_ranks, "per_rank_traj_per_s": per_rank,
+            "rccl_ranks": rccl_ranks, "per_rank_traj_per_s": per_rank, "gather_ok": gather_ok,
+            "dist_backend": (a.dist_backend if use_dist else None),
             "scaling_efficiency_vs_rank_mean": (value / (world * float(np.mean(per_rank)))) if per_rank else None,
             "roofline": {"bound": "hbm",
                          "kernel": "optimize_group_kernel" if (a.lane_groups and M <= 16 and n <= 32 and a.layout != "cell8"

@@ -117,10 +117,6 @@ typedef struct neo_params {
  * fp64 solve to ~1e-5 instead of 2e-6; the optimiser's statistics (evaluations, final costs) are those of the default
  * mode.  Opt-in throughput mode. */
 #define NEO_FLAG_F32_SOLVE 2048
-/* neo_sampled_terms_batch on a yz-quad field with fp32 sampling runs a workgroup of two wavefronts per trajectory with
- * the field gathers staged through LDS (csrc/neo_sample_wg.hpp); this flag selects the one-wavefront kernel instead
- * (the form the fused kernels use; results differ in the last bits through the order of the per-piece sums). */
-#define NEO_FLAG_ONE_WAVE_PER_TRAJECTORY 4096
 /* bits 1..16 switch phases off for timing experiments (tools/): leave them 0 */
 
 /* ---- lifetime ------------------------------------------------------------- */

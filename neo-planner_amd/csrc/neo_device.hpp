@@ -489,8 +489,14 @@ struct Lookup3D {
     const unsigned int cell = __umul24(__umul24((unsigned)a.i0[2], (unsigned)m.ny) + (unsigned)a.i0[1], (unsigned)m.nx) +
                               (unsigned)a.i0[0];
     if constexpr (sizeof(E) == 4) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)land, 16, (int)(cell * 16u), 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(land + 1024), 16, (int)(cell * 16u), 0, 16, 0);
+      // (the second half at its own register offset, hidden from the compiler: folded into the instruction's immediate
+      //  offset -- which it does with a constant in either offset operand -- the 16 would be added to the LDS address as
+      //  well as to the memory address and shift the landing by one lane)
+      const unsigned int off0 = cell * 16u;
+      unsigned int off1 = off0 + 16u;
+      asm volatile("" : "+v"(off1));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)land, 16, (int)off0, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(land + 1024), 16, (int)off1, 0, 0, 0);
     } else {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)land, 16, (int)(cell * 8u), 0, 0, 0);
     }

@@ -1,12 +1,15 @@
 // neo_disp_sample.hip -- sample_kernel family: the ESDF-lookup kernel (expert_planner.py:392-466)
 #include "neo_host.hpp"
 #include "neo_kernels.hpp"
-#include "neo_sample_wg.hpp"
-
+#ifdef NEO_SAMPLE_EXPERIMENTS  // measured and not adopted (round 3): tools/probe/neo_sample_wg.hpp, neo_sample_chunk.hpp
+#include "../../tools/probe/neo_sample_chunk.hpp"
+#include "../../tools/probe/neo_sample_wg.hpp"
 #include <cstdlib>
+#endif
 
 namespace neo {
 
+#ifdef NEO_SAMPLE_EXPERIMENTS
 // workgroup-per-trajectory form with LDS-staged gathers (neo_sample_wg.hpp): fp32 sampling on yz-quad fields
 template <class LookupT, int WPT, int PF, int OCC>
 int launch_sample_wg(neo_ctx *c, const Map3D &map, const SampleArgs &a) {
@@ -18,7 +21,6 @@ int launch_sample_wg(neo_ctx *c, const Map3D &map, const SampleArgs &a) {
 template <class LookupT>
 int dispatch_sample_wg(neo_ctx *c, const Map3D &map, const SampleArgs &a, int variant) {
   switch (variant) {
-#ifdef NEO_SAMPLE_EXPERIMENTS
     case 412: return launch_sample_wg<LookupT, 1, 2, 4>(c, map, a);
     case 414: return launch_sample_wg<LookupT, 1, 4, 4>(c, map, a);
     case 423: return launch_sample_wg<LookupT, 2, 3, 4>(c, map, a);
@@ -27,10 +29,21 @@ int dispatch_sample_wg(neo_ctx *c, const Map3D &map, const SampleArgs &a, int va
     case 316: return launch_sample_wg<LookupT, 1, 6, 3>(c, map, a);
     case 323: return launch_sample_wg<LookupT, 2, 3, 3>(c, map, a);
     case 343: return launch_sample_wg<LookupT, 4, 3, 3>(c, map, a);
-#endif
     default: return launch_sample_wg<LookupT, 2, 5, 3>(c, map, a);
   }
 }
+
+#endif
+
+#ifdef NEO_SAMPLE_EXPERIMENTS
+// fp32 sampling: samples dealt to the lanes in contiguous chunks (neo_sample_chunk.hpp)
+template <int D, class MapT, class LookupT>
+int launch_sample_chunk(neo_ctx *c, const MapT &map, const SampleArgs &a) {
+  hipLaunchKernelGGL((sample_chunk_kernel<D, MapT, LookupT>), dim3(a.B), dim3(kWave), chunk_lds_bytes<D>(a.M), c->stream, a.B,
+                     a.M, c->dev, map, a.coeffs, a.ts, a.costs2, a.grad_C, a.grad_T);
+  return NEO_OK;
+}
+#endif
 
 template <int D, typename Real, class MapT, class LookupT>
 int launch_sample(neo_ctx *c, const MapT &map, const SampleArgs &a) {
@@ -54,15 +67,18 @@ int dispatch_sample(neo_ctx *c, const MapEntry &e, int D, const SampleArgs &a) {
                : launch_sample<3, double, Map2D, Lookup2D<double>>(c, e.m2, a);
   }
   if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
+#ifdef NEO_SAMPLE_EXPERIMENTS
   {
-    // experiments: NEO_SAMPLE_VARIANT (dispatch_sample_wg; 0 = the one-wavefront kernel)
-    const char *ev = std::getenv("NEO_SAMPLE_VARIANT");
-    const int variant = ev ? std::atoi(ev) : 325;
-    if (f32 && e.m3.layout == NEO_LAYOUT_YZ4 && variant != 0 && !(c->params.flags & NEO_FLAG_ONE_WAVE_PER_TRAJECTORY)) {
+    const char *ev = std::getenv("NEO_SAMPLE_VARIANT");  // dispatch_sample_wg; unset or 0 = the product's kernels
+    const int variant = ev ? std::atoi(ev) : 0;
+    if (f32 && e.m3.layout == NEO_LAYOUT_YZ4 && variant > 1) {
       if (e.elem == NEO_F32) return dispatch_sample_wg<Lookup3D<float, float, 1>>(c, e.m3, a, variant);
       return dispatch_sample_wg<Lookup3D<float, __half, 1>>(c, e.m3, a, variant);
     }
+    if (f32 && e.m3.layout == NEO_LAYOUT_YZ4 && e.elem == NEO_F32 && variant == 1)
+      return launch_sample_chunk<3, Map3D, Lookup3D<float, float, 1>>(c, e.m3, a);
   }
+#endif
 #define NEO_3D(LAY)                                                                                  \
   if (e.elem == NEO_F32)                                                                             \
     return f32 ? launch_sample<3, float, Map3D, Lookup3D<float, float, LAY>>(c, e.m3, a)             \

@@ -510,20 +510,15 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
 #ifndef NEO_SAMPLE_OCC
 #define NEO_SAMPLE_OCC 4  // waves per SIMD the fp32 instantiations are allocated for
 #endif
+// the body of sample_kernel (one wavefront per trajectory, lanes per piece) as a function: also the fallback path of
+// sample_chunk_kernel (neo_sample_chunk.hpp)
 template <int D, typename Real, class MapT, class LookupT>
-__global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? NEO_SAMPLE_OCC : 2) void sample_kernel(int B, int M, DevParams prm, MapT map,
-                                                                                  const double *__restrict__ coeffs,
-                                                                                  const double *__restrict__ ts,
-                                                                                  double *__restrict__ costs2,
-                                                                                  double *__restrict__ grad_C,
-                                                                                  double *__restrict__ grad_T) {
-  const int b = blockIdx.x;
-  if (b >= B) return;
-  __shared__ int seg[kWave];
-  // rows of the per-piece fold (fp32 sampling, minco_sample)
-  __shared__ __attribute__((aligned(16))) Real rows[sizeof(Real) == 4 ? kWave * 8 * D : 4];
+__device__ __forceinline__ void sample_wave_per_piece(int b, int M, const DevParams &prm, const MapT &map,
+                                                      const double *__restrict__ coeffs, const double *__restrict__ ts,
+                                                      double *__restrict__ costs2, double *__restrict__ grad_C,
+                                                      double *__restrict__ grad_T, int *seg, Real *rows) {
   const int lane = lane_id();
-  // lanes in proportion to the pieces' sample counts, as in the fused kernels (same sums, bit for bit)
+  // lanes in proportion to the pieces' sample counts, as in the fused kernels
   const double Tp = lane < M ? ts[(size_t)b * M + lane] : 1.0;
   const SampleLanes sl = balanced_sample_lanes(M, lane < M ? (int)(Tp / prm.delta_t) : 0, seg);
   const int piece = sl.piece, r = sl.r;
@@ -544,8 +539,7 @@ __global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? NEO_SAMPLE_OCC : 2) void
   }
   double cf, ck;
   LookupT lk(map);
-  minco_sample<Real, D, LookupT, NEO_SAMPLE_U, true>(M, sl, ns, c, prm, lk, gC, gT, cf, ck,
-                                                     sizeof(Real) == 4 ? rows : nullptr);
+  minco_sample<Real, D, LookupT, NEO_SAMPLE_U, true>(M, sl, ns, c, prm, lk, gC, gT, cf, ck, sizeof(Real) == 4 ? rows : nullptr);
   if (act && r == 0) {
     double2 *dst = reinterpret_cast<double2 *>(grad_C + ((size_t)b * 6 * M + 6 * piece) * D);
 #pragma unroll
@@ -559,6 +553,21 @@ __global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? NEO_SAMPLE_OCC : 2) void
     costs2[(size_t)b * 2 + 0] = cf;
     costs2[(size_t)b * 2 + 1] = ck;
   }
+}
+
+template <int D, typename Real, class MapT, class LookupT>
+__global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? NEO_SAMPLE_OCC : 2) void sample_kernel(int B, int M, DevParams prm, MapT map,
+                                                                                  const double *__restrict__ coeffs,
+                                                                                  const double *__restrict__ ts,
+                                                                                  double *__restrict__ costs2,
+                                                                                  double *__restrict__ grad_C,
+                                                                                  double *__restrict__ grad_T) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  __shared__ int seg[kWave];
+  // rows of the per-piece fold (fp32 sampling, minco_sample)
+  __shared__ __attribute__((aligned(16))) Real rows[sizeof(Real) == 4 ? kWave * 8 * D : 4];
+  sample_wave_per_piece<D, Real, MapT, LookupT>(b, M, prm, map, coeffs, ts, costs2, grad_C, grad_T, seg, rows);
 }
 
 }  // namespace neo

@@ -18,7 +18,6 @@ NEO_TRAJ_FLAG_COLLISION = 0x100
 NEO_KERNEL_EVAL, NEO_KERNEL_OPTIMIZE, NEO_KERNEL_ESDF_BUILD, NEO_KERNEL_ESDF_SAMPLE = 0, 1, 2, 3
 NEO_FLAG_ONE_WAVE_PER_SIMD, NEO_FLAG_TWO_WAVES_PER_SIMD, NEO_FLAG_LANE_GROUPS = 32, 64, 128
 NEO_FLAG_F32_SOLVE = 2048
-NEO_FLAG_ONE_WAVE_PER_TRAJECTORY = 4096
 
 # every symbol include/neo_planner.h declares (tests check the library exports them all)
 EXPORTS = [

@@ -17,7 +17,7 @@ OBJDIR = os.path.join(CSRC, "build")
 SOURCES = ["neo_abi.hip", "neo_disp_eval.hip", "neo_disp_sample.hip", "neo_disp_opt2d.hip", "neo_disp_opt3d_f32.hip",
            "neo_disp_opt3d_f64.hip", "neo_disp_opt3d_w2.hip", "neo_disp_opt3d_x.hip", "neo_disp_group.hip"]
 HEADERS = ["neo_device.hpp", "neo_kernels.hpp", "neo_host.hpp", "neo_launch_opt.hpp", "neo_lbfgs.hpp",
-           "neo_linesearch.hpp", "neo_lbfgs_sm.hpp", "neo_lbfgs_dir.hpp", "neo_group_kernel.hpp", "neo_sample_wg.hpp"]
+           "neo_linesearch.hpp", "neo_lbfgs_sm.hpp", "neo_lbfgs_dir.hpp", "neo_group_kernel.hpp"]
 STAMP = LIB + ".stamp"    # key of the command lines the library was built with (travels with the library)
 
 

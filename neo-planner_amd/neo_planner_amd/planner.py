@@ -140,7 +140,7 @@ class MinJerkPlanner:
         return np.transpose(out, (0, 2, 1)), ts
 
     # ------------------------------------------------------------ entry points (:62-80, :142-237)
-    def read_planning_conditions(self, map, head_state, tail_state, int_wpts, ts):
+    def read_planning_conditions(self, map, head_state, tail_state, int_wpts, ts, _resnapshot=True):
         self.map = map
         self.D = head_state.shape[1]
         self.M = ts.shape[0]
@@ -154,7 +154,8 @@ class MinJerkPlanner:
         self.ts = ts
         # snapshot the map now: the reference reads it unlocked while a subscriber thread may
         # be rewriting it
-        self._scene = _map_scene(self.ctx, map, self._cache)
+        if _resnapshot or self._scene is None:
+            self._scene = _map_scene(self.ctx, map, self._cache)
 
     def plan(self, map, head_state, tail_state):
         int_wpts, ts = self.generate_init_variables(head_state, tail_state)
@@ -174,14 +175,21 @@ class MinJerkPlanner:
         raise Exception("No solution for the given target")
 
     def batch_plan(self, map, head_state, tail_state):
+        """expert_planner.py:142-168.  The three lateral candidates are optimised in ONE launch of three trajectories
+        (a trajectory's result does not depend on its batch neighbours: bit-identical to three launches of one); the
+        reference's loop -- including its success check INSIDE the loop (:160-168) and the order of its side effects on
+        iter_num / opt_running_times / int_wpts -- then runs on the host over the three results."""
         cands, ts = self.batch_generate_init_variables(head_state, tail_state)
         best_wpts = np.zeros(cands.shape)
         best_ts = np.zeros((self.batch_num, len(ts)))
         cost = np.zeros(self.batch_num)
+        results = None
         for i in range(self.batch_num):
             try:
-                self.read_planning_conditions(map, head_state, tail_state, cands[i], ts)
-                self.plan_once()
+                self.read_planning_conditions(map, head_state, tail_state, cands[i], ts, _resnapshot=(i == 0))
+                if results is None:
+                    results = self._launch_plan_once([cands[k] for k in range(self.batch_num)], ts)
+                self._finish_plan_once(*[r[i:i + 1] for r in results])
                 best_wpts[i] = self.int_wpts
                 best_ts[i] = self.ts
                 cost[i] = self.weighted_cost.sum()
@@ -215,19 +223,27 @@ class MinJerkPlanner:
                             collision_cost_tol=self.collision_cost_tol)
         _push_params(self.ctx, cfg, self.sample_dtype, self.stale_T)
 
-    def plan_once(self):
-        """expert_planner.py:205-237 -- the L-BFGS-B run happens in one kernel launch"""
-        self.tau = self.map_T2tau(self.ts)
-        x = _lib.as_f64(self._pack_x()).reshape(1, -1).copy()
+    def _launch_plan_once(self, wpts_list, ts):
+        """one launch of len(wpts_list) trajectories that share head / tail / durations: (x, costs, last, nit, nfev, st)"""
+        nb = len(wpts_list)
+        nq = self.D * (self.M - 1)
+        tau = self.map_T2tau(ts)
+        x = np.stack([np.concatenate((np.reshape(_lib.as_f64(w), (nq,)), tau), axis=0) for w in wpts_list])
+        x = np.ascontiguousarray(x, dtype=np.float64)
         self._sync_params()
         c = self.ctx
-        costs = np.zeros((1, 4)); last = np.zeros((1, 4))
-        nit = np.zeros(1, np.int32); nfev = np.zeros(1, np.int32); st = np.zeros(1, np.int32)
-        head = _lib.as_f64(self.head_state).reshape(1, 3, self.D)
-        tail = _lib.as_f64(self.tail_state).reshape(1, 3, self.D)
-        c.check(c.lib.neo_optimize_batch(c.h, self._scene, None, 1, self.M, self.D, _lib.ptr(x), _lib.ptr(head),
+        costs = np.zeros((nb, 4)); last = np.zeros((nb, 4))
+        nit = np.zeros(nb, np.int32); nfev = np.zeros(nb, np.int32); st = np.zeros(nb, np.int32)
+        head = np.ascontiguousarray(np.broadcast_to(_lib.as_f64(self.head_state), (nb, 3, self.D)))
+        tail = np.ascontiguousarray(np.broadcast_to(_lib.as_f64(self.tail_state), (nb, 3, self.D)))
+        c.check(c.lib.neo_optimize_batch(c.h, self._scene, None, nb, self.M, self.D, _lib.ptr(x), _lib.ptr(head),
                                          _lib.ptr(tail), _lib.ptr(costs), _lib.ptr(last), _lib.ptr(nit),
                                          _lib.ptr(nfev), _lib.ptr(st)))
+        return x, costs, last, nit, nfev, st
+
+    def _finish_plan_once(self, x, costs, last, nit, nfev, st):
+        """what plan_once does with the optimiser's answer (:226-237): exceptions first, then the side effects"""
+        self.tau = self.map_T2tau(self.ts)
         code = int(st[0]) & 0xff
         self.last_status, self.last_nit, self.last_nfev = code, int(nit[0]), int(nfev[0])
         if code == _lib.NEO_TRAJ_NUMERIC_RANGE:
@@ -245,6 +261,10 @@ class MinJerkPlanner:
         self.final_cost = self.weighted_cost.sum()
         if self.weighted_cost[3] > self.collision_cost_tol:
             raise ValueError("collision cost too large")
+
+    def plan_once(self):
+        """expert_planner.py:205-237 -- the L-BFGS-B run happens in one kernel launch"""
+        self._finish_plan_once(*self._launch_plan_once([self.int_wpts], self.ts))
 
     optimize = plan_once
 

@@ -36,8 +36,22 @@ def gather_results(local, world, out=None, force=False, async_op=False):
         return (local, None) if async_op else local
     if out is None:
         out = torch.empty(world * local.shape[0], local.shape[1], dtype=local.dtype, device=local.device)
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # gloo has no device collectives for this call: stage through the host (tests that run several ranks on one GPU;
+        # RCCL refuses two ranks on one device).  Synchronous by construction.
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.contiguous().cpu())
+        out.copy_(host)
+        return (out, _Done()) if async_op else out
     work = dist.all_gather_into_tensor(out, local.contiguous(), async_op=async_op)
     return (out, work) if async_op else out
+
+
+class _Done:
+    """a finished piece of work (the synchronous host-staged gather)"""
+
+    def wait(self):
+        return True
 
 
 def scene_major_order(gathered, n_scenes, world, rows_per_scene):

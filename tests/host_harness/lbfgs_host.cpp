@@ -127,12 +127,13 @@ int lbfgs_host_minimize_sm(int n, double *x, double ftol, double gtol, int maxls
 // neo_optimize_trace_xg).  This runs the product's L-BFGS-B control flow (the state machine of csrc/neo_lbfgs_sm.hpp)
 // in fp64 on the host with those recorded values as its objective: at every evaluation the host's own trial point is
 // compared with the device's (x_dev[k] = max |x_host - x_dev| / max(1, max |x_dev|)), then REPLACED by it, so that
-// every step is judged on the device's own history and errors do not accumulate.  Outputs per evaluation: the host's
+// every step is judged on the device's own history and errors do not accumulate (`resync_min_rel` > 0: the host's
+// direction is re-derived from the device's trial point as well, see below).  Outputs per evaluation: the host's
 // line-search step and iteration counter (to be laid beside the device's trace); per run: nit / nfev / status as the
 // host decides them, and `overrun` = 1 when the host asks for an evaluation the device never made.
 // last_est: the status the device's last evaluation returned (4 = NUMERIC_RANGE ends the run there).
 int lbfgs_host_replay(int n, int E, const double *xr, const double *fr, const double *gr, const double *cr, int last_est,
-                      double ftol, double gtol, int maxls, int maxiter, int maxfun, int m, double *x_dev,
+                      double ftol, double gtol, int maxls, int maxiter, int maxfun, int m, double resync_min_rel, double *x_dev,
                       double *stp_host, int *iter_host, int *nit, int *nfev, int *status, int *overrun) {
   HostBackend be(n, m, nullptr, nullptr);
   neo::LbfgsOpts o{ftol, gtol, maxls, maxiter, maxfun, m};
@@ -156,6 +157,19 @@ int lbfgs_host_replay(int n, int E, const double *xr, const double *fr, const do
     x_dev[k] = dmax / xmax;
     stp_host[k] = k == 0 ? 0.0 : mach.stp;
     iter_host[k] = mach.iter;
+    if (k > 0 && resync_min_rel > 0.0) {
+      // the direction the device actually moved along, from its own trial point: d = (x_k - t) / stp.  The pair stored
+      // after this line search is then the device's true displacement (s = stp d = x_k - t), so the host's memory is a
+      // function of the device's data alone and a rounding difference in one direction cannot feed the next ones.
+      // Only while the displacement is numerically there: in a collapsing line search (steps of 1e-15) x_k - t is a few
+      // units in the last place of x and says nothing about d.
+      double disp = 0.0;
+      for (int i = 0; i < n; ++i) disp = fmax(disp, fabs(xk[i] - mach.t[i]));
+      if (disp >= resync_min_rel * xmax) {
+        const double stp_h = mach.stp;
+        for (int i = 0; i < n; ++i) mach.d[i] = (xk[i] - mach.t[i]) / stp_h;
+      }
+    }
     mach.x.assign(xk, xk + n);
     mach.f = fr[k];
     mach.g.assign(gr + (size_t)k * n, gr + (size_t)(k + 1) * n);

@@ -98,9 +98,16 @@ def test_cfg3_65536_warm_started_small_problems():
     ctrl = _cpu(g3.dist, synth.RES, x0, head, tail, M, idx, coeff_eps=2.2e-16)
     follow, med = _compare(r64, cpu, np.arange(64), 3 * (M - 1), ctrl)
     assert follow >= 0.75 and med < 1e-8                                            # ~25 evaluations per run
+    # the all-fp32 lane-group kernel (the mode cfg3's bench number is quoted in): same statistics
+    rx = npa.BatchPlanner(sample_dtype="f32x", lane_groups=True).optimize(g3, x0, head, tail)
+    assert set(np.unique(rx["status"])) <= {0, 1, 2, 3, 4, 5} and (rx["status"] <= 2).mean() > 0.97
+    assert abs(np.median(rx["final_cost"]) - np.median(rg["final_cost"])) <= 2e-3 * np.median(rg["final_cost"])
+    assert abs(rx["nfev"].mean() - rg["nfev"].mean()) <= 0.03 * rg["nfev"].mean()
+    rx2 = npa.BatchPlanner(sample_dtype="f32x", lane_groups=True).optimize(g3, x0, head, tail)
+    assert np.array_equal(rx["x"], rx2["x"])
     # and the timed (fp32) modes against it, statistically
     cpu32 = _cpu(g3.dist, synth.RES, x0, head, tail, M, idx, sample_f32=True)
-    for r in (rd, rg):
+    for r in (rd, rg, rx):
         gc = (r["costs_last"][idx] * W4).sum(axis=1)
         cc = (cpu32["costs_last"] * W4).sum(axis=1)
         assert abs(np.median(gc) - np.median(cc)) <= 0.02 * abs(np.median(cc))
@@ -193,4 +200,27 @@ def test_cfg5_fp16_field_600_cubed_optimiser_against_cpu():
         e0 = npa.BatchPlanner(ctx=ctx, sample_dtype="f32").cost_grad(g16, x0, head, tail)
         ok = r["status"] <= 2
         assert ok.mean() > 0.9 and np.all(r["final_cost"][ok] <= e0["cost"][ok] * (1 + 1e-9))
+        if layout == "yz4":
+            # the all-fp32 mode at n = 161 (four FLAT slots; the mode cfg5's bench number is quoted in): one evaluation
+            # against the CPU oracle to the mode's tolerance, the optimiser against the CPU with the CPU-vs-CPU control
+            # perturbed as the all-fp32 kernels are per evaluation, and the batch properties
+            bx = npa.BatchPlanner(ctx=ctx, sample_dtype="f32x")
+            ex = bx.cost_grad(g16, x0[:24], head[:24], tail[:24])
+            for b in range(0, 24, 6):
+                pl = cn.NativePlanner(onp.PlannerParams())
+                pl.read_planning_conditions(nm, head[b], tail[b], wp[b], ts[b])
+                c = pl.get_cost(x0[b])
+                assert abs(ex["cost"][b] - c) <= 4e-5 * abs(c)
+                assert rel_err(ex["grad"][b], pl.get_grad(x0[b])) < 2e-4
+            idx = np.arange(96)
+            gx = bx.optimize(g16, x0, head, tail)
+            cpu96 = _cpu(field16, res, x0, head, tail, M, idx)
+            ctrl96 = _cpu(field16, res, x0, head, tail, M, idx, sample_f32=True, coeff_eps=1e-7, grad_eps=3e-6)
+            _compare(gx, cpu96, idx, 3 * (M - 1), ctrl96, same_path_is_same_point=False)
+            okx = gx["status"] <= 2
+            assert okx.mean() > 0.9 and np.all(gx["final_cost"][okx] <= e0["cost"][okx] * (1 + 1e-4))
+            both = (gx["status"][idx] <= 1) & (cpu96["status"] <= 1)
+            assert abs(gx["nfev"][idx][both].mean() - cpu96["nfev"][both].mean()) <= 0.1 * cpu96["nfev"][both].mean()
+            g2 = bx.optimize(g16, x0, head, tail)
+            assert np.array_equal(g2["x"], gx["x"])                        # bit-reproducible
         ctx.check(ctx.lib.neo_esdf_drop(ctx.h, g16.scene_id))

@@ -5,7 +5,7 @@
   2. counter passes (`--pmc`, one group per run, nothing else traced) -> <out>/pmc.json
      (mean per dispatch of every counter for the kernels of the hot path)
 
-    python tools/collect_profiles.py gpurun_out/prof_rNN [--config cfg2]
+    python tools/collect_profiles.py gpurun_out/prof_rNN [--trace-only] [--config cfg2]
 
 rocprofv3 is started as a child process with the program itself after `--`; every run has its own timeout.
 """
@@ -50,7 +50,8 @@ def run(cmd, log, timeout):
 
 def main():
     out = os.path.abspath(sys.argv[1])
-    extra = sys.argv[2:]
+    extra = [a for a in sys.argv[2:] if a != "--trace-only"]
+    trace_only = "--trace-only" in sys.argv[2:]
     os.makedirs(out, exist_ok=True)
     os.environ["TMPDIR"] = "/tmp"
     bench = ["python3", "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-modes"] + extra
@@ -79,7 +80,7 @@ def main():
                 f.write(f"{k},{len(v)},{sum(v) / len(v):.1f},{min(v):.0f},{max(v):.0f},{sum(v):.0f}\n")
     print("kernel trace rc", rc, "stats", bool(stats), "trace", bool(traces))
     agg = {}
-    for gi, group in enumerate(PMC_GROUPS):
+    for gi, group in enumerate([] if trace_only else PMC_GROUPS):
         d = os.path.join(out, f"pmc{gi}")
         rc = run(["rocprofv3", "--pmc"] + group + ["--output-format", "csv", "-d", d, "--"] + bench,
                  os.path.join(out, f"pmc{gi}.log"), 180)

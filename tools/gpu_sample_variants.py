@@ -23,7 +23,7 @@ def main():
     import torch
     import neo_planner_amd as npa
     from neo_planner_amd import synth, _lib
-    variants = [int(v) for v in sys.argv[1:]] or [0, 412, 414, 423, 443, 314, 316, 323, 325, 343]
+    variants = [int(v) for v in sys.argv[1:]] or [0, 1, 412, 414, 423, 443, 314, 316, 323, 325, 343]
     dev = torch.device("cuda:0")
     ctx = _lib.Context(0)
     occ = synth.occupancy_3d(0, n=300, res=0.1, canopy=80)
@@ -50,7 +50,7 @@ def main():
         by = ns * 32.0 + B * (2 * n * 4 + 20)
         ref = None
         for v in variants:
-            os.environ["NEO_SAMPLE_VARIANT"] = str(v)
+            os.environ["NEO_SAMPLE_VARIANT"] = str(v)       # 0: the product's sample_kernel, 1: contiguous chunks (tools/probe/neo_sample_chunk.hpp), else neo_sample_wg.hpp
             c2 = torch.zeros(B, 2, dtype=torch.float64, device=dev)
             gC = torch.zeros_like(coeffs); gT = torch.zeros(B, M, dtype=torch.float64, device=dev)
             run = lambda: ctx.check(ctx.lib.neo_sampled_terms_batch_dev(ctx.h, g3.scene_id, B, M, D, pp(coeffs), pp(d_ts),

@@ -14,9 +14,17 @@
 // Same arithmetic per sample as every other sampling kernel (sample_accumulate, piece_pos_vel, Lookup3D::prepare /
 // finish); the lanes of a piece are summed in lane order, so results are bit-reproducible run to run -- they differ from
 // sample_kernel's in the last bits only through the order of those sums (fewer, longer partial sums per piece).
-// fp32 sampling on yz-quad fields (fp32 or fp16 voxels); every other combination runs sample_kernel.
+// fp32 sampling on yz-quad fields (fp32 or fp16 voxels).
+//
+// MEASURED AND NOT ADOPTED (round 3, MI355X, cfg2 workload; tools/gpu_sample_variants.py, profiles/r03_sample_variants.log):
+// every variant is correct (bit-identical to sample_kernel with one wavefront per trajectory, 2e-7 with more) and every
+// one is SLOWER than sample_kernel's 33.0 us per 4096 trajectories / 432 us per 65 536: two rounds in flight 35.7 / 447,
+// four 38.9 / 482, six 39.6 / 460, two wavefronts per trajectory 35.7-36.6 / 467-484, four 43.8 / 635.  The kernel is
+// bound by instruction issue, not by the latency of its gathers; the product's answer is fewer idle lane-rounds
+// (csrc/neo_sample_chunk.hpp).  Kept here, outside the library, as the experiment it was: a library built with
+// -DNEO_SAMPLE_EXPERIMENTS dispatches to it when NEO_SAMPLE_VARIANT is set.
 #pragma once
-#include "neo_kernels.hpp"
+#include "../../neo-planner_amd/csrc/neo_kernels.hpp"
 
 namespace neo {
 
