@@ -639,6 +639,22 @@ def main():
         got = torch.stack([bt["gathered"][r_ * B:(r_ + 1) * B].double().nan_to_num().sum() for r_ in range(world)]).to(cdev)
         gather_ok = bool(torch.equal(mine.view(torch.int32), bt["packed"].view(torch.int32)) and torch.equal(got, sums))
     mode_runs = {a.dtype: main_run}
+    # one launch ALONE on the chip (outside the timed region): with `--streams` launches in flight each one lasts longer than
+    # it would by itself, which the per-launch roofline figure of the contract carries; this is the undisturbed duration
+    solo_ms = None
+    if rank == 0 and not use_dist:
+        bp._sync()
+        fence()
+        ctx.check(ctx.lib.neo_profile_reset(ctx.h))
+        ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
+        for _ in range(3):
+            launch(batches[0], bp)
+            fence()
+        ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
+        ctx.set_stream(None)
+        l_s = ctypes.c_int64(); m_s = ctypes.c_double()
+        ctx.check(ctx.lib.neo_profile_read(ctx.h, _lib.NEO_KERNEL_OPTIMIZE, ctypes.byref(l_s), ctypes.byref(m_s)))
+        solo_ms = m_s.value / max(l_s.value, 1)
     for m_ in modes[1:]:
         mode_runs[m_] = time_mode(m_)
     bp._sync()
@@ -786,9 +802,23 @@ def main():
             for _ in range(20):
                 pl1.batch_plan(m2, h2, t2)
             batch_plan_ms = 1e3 * (time.perf_counter() - t1) / 20
+        # ... and that shape in batches: 8192 M = 3 replans of the 2-D map per launch, fp64, default kernel and lane groups
+        hb, tb, wb, tsb = synth.replan_requests(5, 8192, 2, D=2, length_range=(4.0, 6.0), jitter=0.3)
+        batch_rate = {}
+        for name_, lg_ in (("default_kernel", False), ("lane_groups", True)):
+            bq = npa.BatchPlanner(ctx=ctx, sample_dtype="f64", lane_groups=lg_)
+            xq = bq.pack_x(wb, tsb)
+            bq.optimize(m2, xq, hb, tb)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                rq = bq.optimize(m2, xq, hb, tb)
+            batch_rate[name_] = 3 * 8192 / (time.perf_counter() - t1)
         cfg1 = {"what": "one plan() / batch_plan() call of the reference's shape: M = 3, D = 2, 300 x 300 nearest-cell map, fp64 "
                         "(expert_planner.py:62-80, :142-168); scenario of tests/golden g3 / __graft_entry__.smoke()",
                 "plan_ms_gpu": plan_ms, "batch_plan_ms_gpu": batch_plan_ms, "plan_nfev": int(pl1.last_nfev),
+                "batched_replans_per_s_fp64_host_buffers": batch_rate,
+                "batched_note": "8192 replans of this shape per neo_optimize_batch call (host pointers in and out, PCIe "
+                                "included): one trajectory per wavefront / eight per wavefront (NEO_FLAG_LANE_GROUPS)",
                 "plan_final_cost_gpu": float(pl1.final_cost)}
         bp._sync()
 
@@ -825,6 +855,8 @@ def main():
                          # With several launches in flight they overlap and each one lasts longer than it
                          # would alone; the chip-wide rate is all launches' bytes over the timed region:
                          "concurrent_launches": n_lanes,
+                         "kernel_ms_one_launch_alone": solo_ms,
+                         "frac_one_launch_alone": (bytes_launch / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if solo_ms else None,
                          "achieved_aggregate": bytes_launch * n_sets * a.steps / elapsed / 1e9,
                          "frac_aggregate": bytes_launch * n_sets * a.steps / elapsed / 1e9 / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": bytes_launch,

@@ -108,7 +108,8 @@ typedef struct neo_params {
  * calls in flight on several streams; 3-D fields with fp32 sampling and n <= 128 variables only). */
 #define NEO_FLAG_ONE_WAVE_PER_SIMD 32
 #define NEO_FLAG_TWO_WAVES_PER_SIMD 64
-/* small problems (n <= 32 variables, M <= 16, one 3-D scene, fp32 sampling): eight trajectories per wavefront, 8
+/* small problems (n <= 32 variables, M <= 16, one scene: a 3-D field with fp32 sampling, or the 2-D nearest-cell map
+ * with D = 2 in either arithmetic -- the reference's own M = 3 shape): eight trajectories per wavefront, 8
  * lanes each, for n <= 16; four of 16 lanes beyond.  Opt-in: a piece's samples are strided over fewer lanes, so sums associate differently
  * and results agree with the default kernel to fp32 rounding, not bit for bit. */
 #define NEO_FLAG_LANE_GROUPS 128

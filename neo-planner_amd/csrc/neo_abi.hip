@@ -474,7 +474,12 @@ int fail_locked(neo_ctx *c, int code, const char *msg) {
 
 int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArgs &a) {
   const bool f32 = c->params.sample_dtype == NEO_F32;
-  if (kind == 0) return launch_opt_2d(c, D, f32, a);
+  if (kind == 0) {
+    // small planar problems on the reference's own map (M = 3 -> n = 7): eight replans per wavefront, opt-in
+    if ((c->params.flags & NEO_FLAG_LANE_GROUPS) && D == 2 && !a.slots && a.M <= 16 && D * (a.M - 1) + a.M <= 32)
+      return launch_opt_groups_2d(c, f32, a);
+    return launch_opt_2d(c, D, f32, a);
+  }
   if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
   const int fl = c->params.flags;
   if ((fl & NEO_FLAG_LANE_GROUPS) && f32 && (layout == NEO_LAYOUT_LINEAR || layout == NEO_LAYOUT_YZ4) && !a.slots &&

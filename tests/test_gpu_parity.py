@@ -411,6 +411,48 @@ def test_batch_plan_in_one_launch_equals_three_sequential_plan_once():
         assert out_a.getvalue() == out_b.getvalue()
 
 
+def test_lane_groups_on_the_2d_reference_map_match_the_default_kernel():
+    """the lane-group kernel (eight replans per wavefront) on the reference's own shape -- D = 2,
+    M = 3 (n = 7), nearest-cell 2-D map -- in both arithmetics.  A group strides a piece's samples over fewer lanes than
+    the default kernel, so sums associate differently: in fp64 nearly every run is the default kernel's run to the last
+    digits, and the batch statistics are the same; bit-reproducible; independent of the batch neighbours."""
+    occ = synth.occupancy_2d(2)
+    m = npa.ESDF()
+    m.occupancy_map_cb(synth.OccupancyGridMsg(occ))
+    B, M = 1024, 3
+    head, tail, wp, ts = synth.replan_requests(21, B, M - 1, D=2, length_range=(4.0, 6.0), jitter=0.3)
+    for dtype, frac_same, xtol in (("f64", 0.9, 1e-7), ("f32", 0.5, 1e-3)):
+        bd = npa.BatchPlanner(sample_dtype=dtype)
+        bg = npa.BatchPlanner(sample_dtype=dtype, lane_groups=True)
+        x0 = bd.pack_x(wp, ts)
+        rd = bd.optimize(m, x0, head, tail)
+        rg = bg.optimize(m, x0, head, tail)
+        rg2 = bg.optimize(m, x0, head, tail)
+        assert np.array_equal(rg["x"], rg2["x"]) and np.array_equal(rg["nfev"], rg2["nfev"])
+        assert set(np.unique(rg["status"])) <= {0, 1, 2, 3, 4, 5}
+        same = (rd["nfev"] == rg["nfev"]) & (rd["status"] == rg["status"])
+        assert same.mean() >= frac_same, (dtype, same.mean())
+        dx = np.abs(rd["x"][same] - rg["x"][same]).max(axis=1) / np.abs(rd["x"][same]).max(axis=1)
+        assert np.quantile(dx, 0.9) <= xtol, (dtype, np.quantile(dx, 0.9))
+        ok = (rd["status"] <= 2) & (rg["status"] <= 2)
+        assert abs(np.median(rd["final_cost"][ok]) - np.median(rg["final_cost"][ok])) <= 1e-3 * np.median(rd["final_cost"][ok])
+        assert abs(rd["nfev"].mean() - rg["nfev"].mean()) <= 0.03 * rd["nfev"].mean()
+        pick = np.array([0, 5, 77, 600, 1023])
+        r3 = bg.optimize(m, x0[pick], head[pick], tail[pick])
+        assert np.array_equal(r3["x"], rg["x"][pick])
+    # and against SciPy on the oracle objective, as test_optimize_batch_matches_cpu_optimizer does for the default kernel
+    o2 = onp.GridESDF(occ, 0.1, 300, 300, (0.0, -15.0))
+    rg = npa.BatchPlanner(lane_groups=True).optimize(m, npa.BatchPlanner().pack_x(wp, ts), head, tail)
+    wq, tq = npa.BatchPlanner().unpack_x(rg["x"], M, 2)
+    n_exact = 0
+    for b in range(24):
+        pl, err = _oracle_plan_once(o2, head[b], tail[b], wp[b], ts[b])
+        if err == "overflow":
+            continue
+        n_exact += rg["nfev"][b] == pl.last_result.nfev and rel_err(wq[b], pl.int_wpts) < 1e-7
+    assert n_exact >= 18, n_exact
+
+
 def test_parted_runs_first_divergence():
     """for every recorded reference run the device does not follow to its last evaluation
     (KNOWN_PARTED), the LAST L-BFGS-B run is traced on the device (neo_optimize_trace_xg) and laid beside SciPy's
