@@ -494,6 +494,50 @@ class BatchPlanner:
         return dict(x=x, costs=costs, costs_last=last, nit=nit, nfev=nfev, status=st & 0xff,
                     collision=(st & _lib.NEO_TRAJ_FLAG_COLLISION) != 0, final_cost=(costs * w).sum(axis=1))
 
+    def init_guess(self, head, tail, count, rng=None, noise=0.0):
+        """generate_init_variables (:82-101) for a batch: `count` waypoints on the straight line from start to target,
+        durations init_T with the first and last piece 1.5 times as long; noise > 0 adds the N(0, noise) jitter of the
+        reference's re-seeded attempts (:94; a numpy Generator here, the reference draws from the global RNG)"""
+        head = np.asarray(head, dtype=np.float64); tail = np.asarray(tail, dtype=np.float64)
+        start, target = head[:, 0], tail[:, 0]
+        f = (np.arange(1, count + 1) / (count + 1))[None, None, :]
+        wp = start[:, :, None] + (target - start)[:, :, None] * f                     # (B, D, count)
+        if noise > 0.0:
+            wp = wp + (rng if rng is not None else np.random.default_rng()).normal(0.0, noise, wp.shape)
+        ts = np.full((head.shape[0], count + 1), float(self.cfg.init_T))
+        ts[:, 0] *= 1.5
+        ts[:, -1] *= 1.5
+        return wp, ts
+
+    def plan(self, map, head, tail, int_wpts=None, ts=None, waypoints=None, max_attempts=5, rng=None, scene_ids=None):
+        """warm_start_plan (:186-203) for a batch: every request gets up to `max_attempts` plan_once runs.  An attempt that
+        ends the way the reference raises on -- OverflowError statuses or `collision cost too large` (:235-237) -- is
+        re-seeded like the reference's retries (straight line + N(0, 0.5), :94, :201) and optimised again; only the
+        failed requests are launched again.  Returns the optimiser's dict plus `attempts` (B,) and `solved` (B,): a
+        request with solved False is one the reference answers with Exception("No solution for the given target")."""
+        head = _lib.as_f64(head); tail = _lib.as_f64(tail)
+        B, D = head.shape[0], head.shape[2]
+        if int_wpts is None:
+            int_wpts, ts = self.init_guess(head, tail, waypoints if waypoints is not None else int(self.cfg.init_wpts_num))
+        count = np.asarray(int_wpts).shape[2]
+        out = self.optimize(map, self.pack_x(int_wpts, ts), head, tail, scene_ids=scene_ids)
+        out["attempts"] = np.ones(B, dtype=np.int32)
+        failed = lambda r: (r["status"] > _lib.NEO_TRAJ_MAXITER) | r["collision"]
+        todo = np.flatnonzero(failed(out))
+        rng = rng if rng is not None else np.random.default_rng()
+        for attempt in range(1, max_attempts):
+            if todo.size == 0:
+                break
+            wp_n, ts_n = self.init_guess(head[todo], tail[todo], count, rng=rng, noise=0.5)
+            r = self.optimize(map, self.pack_x(wp_n, ts_n), head[todo], tail[todo],
+                              scene_ids=None if scene_ids is None else np.asarray(scene_ids)[todo])
+            for k in ("x", "costs", "costs_last", "nit", "nfev", "status", "collision", "final_cost"):
+                out[k][todo] = r[k]
+            out["attempts"][todo] += 1
+            todo = todo[failed(r)]
+        out["solved"] = ~failed(out)
+        return out
+
     def expected_effort_order(self, head, tail, ts):
         """permutation that starts the runs expected to be long first.  Proxy: time slack of the initial
         guess, sum(ts) * v_max / distance -- a guess that is far too slow needs many iterations to shed

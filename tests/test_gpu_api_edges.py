@@ -507,3 +507,36 @@ def test_multi_scene_calls_reject_mixed_maps_and_bad_slots():
     assert (st[5] & 0xff) == _lib.NEO_TRAJ_BAD_SCENE and torch.equal(x[5], x_in[5])
     assert ((np.delete(st, 5) & 0xff) <= 5).all()              # ordinary terminations (4: a run that left through exp overflow)
     assert np.array_equal(np.delete(x.cpu().numpy(), 5, axis=0), np.delete(one["x"], 5, axis=0))
+
+
+def test_batched_plan_with_retries_like_warm_start_plan():
+    """BatchPlanner.plan: the reference's retry loop (expert_planner.py:186-203) for a batch -- failed requests (collision
+    cost too large / overflow) are re-seeded with N(0, 0.5) jitter and launched again, the others keep their first
+    answer bit for bit; requests through a pillar need retries, free ones do not."""
+    occ = synth.occupancy_2d(3, count=40)
+    m = npa.ESDF()
+    m.occupancy_map_cb(synth.OccupancyGridMsg(occ))
+    boxes = synth.forest_boxes(3, count=40)
+    heads, tails = [], []
+    for (cx, cy, *_rest) in boxes[:24]:
+        heads.append([[cx - 2.5, cy], [0.5, 0.0]]); tails.append([[cx + 2.5, cy], [0.5, 0.0]])       # straight through a pillar
+    for k in range(24):
+        heads.append([[0.5, -14.0 + 0.1 * k], [0.0, 0.0]]); tails.append([[4.5, -14.0 + 0.1 * k], [0.6, 0.0]])   # free corridor
+    head = np.zeros((48, 3, 2)); tail = np.zeros((48, 3, 2))
+    head[:, :2] = np.array(heads); tail[:, :2] = np.array(tails)
+    free = np.array([not (m.has_collision(h[0]) or m.has_collision(t[0])) for h, t in zip(head, tail)])
+    bp = npa.BatchPlanner()
+    out = bp.plan(m, head, tail, max_attempts=5, rng=np.random.default_rng(7))
+    first = bp.optimize(m, bp.pack_x(*bp.init_guess(head, tail, 2)), head, tail)
+    assert out["attempts"].min() == 1 and out["attempts"].max() <= 5
+    once = out["attempts"] == 1
+    assert np.array_equal(out["x"][once], first["x"][once]) and once[24:].all()
+    assert (out["attempts"][:24] > 1).sum() >= 4                     # some pillar requests needed the re-seeded attempts
+    retried = out["attempts"] > 1
+    assert out["solved"][retried & free].mean() >= 0.5               # ... and most of those found a way round
+    assert np.all(out["final_cost"][out["solved"]] < 1e4)
+    # the initial guess is the reference's (generate_init_variables, fixed mode, :82-101)
+    pl = npa.MinJerkPlanner(npa.PlannerConfig())
+    w, t = pl.generate_init_variables(head[0, :2], tail[0, :2])
+    wb, tb = bp.init_guess(head[:1], tail[:1], 2)
+    assert np.allclose(wb[0], w, rtol=0, atol=1e-15) and np.array_equal(tb[0], t)

@@ -167,6 +167,50 @@ def test_cfg2_all_fp32_mode_parts_from_the_cpu_no_more_than_the_cpu_does_under_t
     assert abs(g["nfev"][ok].mean() - cpu["nfev"][ok].mean()) <= 0.05 * cpu["nfev"][ok].mean()
 
 
+def test_cfg2_fp64_mode_against_scipys_own_optimiser_on_the_cpp_objective():
+    """`cn.optimize_batch`, the checker of the tests above, runs the SAME restated L-BFGS-B as the
+    device (csrc/neo_lbfgs.hpp).  Here the checker's optimiser is SciPy's own compiled L-BFGS-B (`cn.NativePlanner`,
+    the reference's call of expert_planner.py:213-225 on the C++ objective): the device's fp64 mode must follow SciPy's
+    runs as often as the restated optimiser on the CPU does (the yardstick: same objective, SciPy's optimiser against
+    ours), and end on SciPy's control points whenever it takes SciPy's evaluation count."""
+    M, B = 21, 96
+    dev = torch.device("cuda", 0)
+    ctx = _lib.Context(0)
+    occ = synth.occupancy_3d(11, canopy=80)
+    g3 = npa.ESDF3D.from_occupancy(torch.from_numpy(occ).to(dev), synth.RES, synth.DOMAIN_ORIGIN, ctx=ctx, layout="yz4",
+                                   want_dist=True)
+    head, tail, wp, ts = synth.replan_requests(11, B, M - 1, D=3, **synth.VOLUME)
+    bp = npa.BatchPlanner(ctx=ctx, sample_dtype="f64")
+    x0 = bp.pack_x(wp, ts)
+    g = bp.optimize(g3, x0, head, tail)
+    ours = _cpu(g3.dist, synth.RES, x0, head, tail, M, np.arange(B))
+    nm = cn.NativeMap.from_field3d(g3.dist, synth.RES, synth.DOMAIN_ORIGIN)
+    sx = np.full((B, 3 * (M - 1)), np.nan); snf = np.zeros(B, dtype=int)
+    for b in range(B):
+        pl = cn.NativePlanner(onp.PlannerParams())
+        pl.read_planning_conditions(nm, head[b], tail[b], wp[b], ts[b])
+        try:
+            pl.plan_once()
+        except ValueError:
+            pass
+        except OverflowError:
+            continue
+        sx[b] = pl.last_result.x[:3 * (M - 1)]
+        snf[b] = pl.last_result.nfev
+    ok = np.isfinite(sx[:, 0])
+    assert ok.sum() >= 0.9 * B
+    dxg = np.abs(g["x"][ok][:, :3 * (M - 1)] - sx[ok]).max(axis=1) / np.abs(sx[ok]).max(axis=1)
+    dxo = np.abs(ours["x"][ok][:, :3 * (M - 1)] - sx[ok]).max(axis=1) / np.abs(sx[ok]).max(axis=1)
+    same_g = g["nfev"][ok] == snf[ok]
+    same_o = ours["nfev"][ok] == snf[ok]
+    slack = 2.5 * np.sqrt(0.25 / ok.sum()) + 1.0 / ok.sum()
+    print(f"vs SciPy's L-BFGS-B on the C++ objective, {ok.sum()} runs of ~{snf[ok].mean():.0f} evaluations: device fp64 same nfev "
+          f"{same_g.mean():.3f}, within 1e-4 {(dxg <= 1e-4).mean():.3f}; restated optimiser on the CPU {same_o.mean():.3f}, "
+          f"{(dxo <= 1e-4).mean():.3f}")
+    assert same_g.mean() >= same_o.mean() - slack and (dxg <= 1e-4).mean() >= (dxo <= 1e-4).mean() - slack
+    assert (dxg[same_g] <= 1e-4).mean() >= 0.85
+
+
 def test_cfg5_fp16_field_600_cubed_optimiser_against_cpu():
     n, M, B = 600, 41, 256
     res = 30.0 / n

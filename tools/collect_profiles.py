@@ -35,6 +35,9 @@ PMC_GROUPS = [
     ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
      "SQ_INSTS_VALU_INT64", "SQ_INSTS_SMEM"],
     ["GRBM_GUI_ACTIVE"],
+    # L2 -> fabric read requests by size: 32 n32 + 64 n64 + 128 n128 = the bytes FETCH_SIZE is derived from (it reports
+    # half of them on gfx950: tools/gpu_gather_calib.py)
+    ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"],
 ]
 KERNELS = ["optimize_group_kernel", "optimize_kernel", "sample_kernel", "eval_kernel", "edt3_x", "edt3_y", "edt3_z", "pack3d"]
 
