@@ -539,4 +539,4 @@ def test_batched_plan_with_retries_like_warm_start_plan():
     pl = npa.MinJerkPlanner(npa.PlannerConfig())
     w, t = pl.generate_init_variables(head[0, :2], tail[0, :2])
     wb, tb = bp.init_guess(head[:1], tail[:1], 2)
-    assert np.allclose(wb[0], w, rtol=0, atol=1e-15) and np.array_equal(tb[0], t)
+    assert np.allclose(wb[0], w, rtol=1e-14, atol=0) and np.array_equal(tb[0], t)
