@@ -937,17 +937,30 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
     if (-tau > Num(709.782712893384)) bad = 1;
     // (fp32: expf overflows to +inf beyond 88.72 -- T is then T_min exactly, as it is in fp64 to rounding from -tau = 37
     //  on; the statuses stay those of the fp64 modes because the range tests are made on tau, not on exp(-tau))
-    const Num ex = exp(-tau);
-    t.T = (Num(prm.T_max) - Num(prm.T_min)) / (Num(1.0) + ex) + Num(prm.T_min);
+    Num ex;
+    if constexpr (sizeof(Num) == 8) {
+      ex = exp(-tau);
+      t.T = (Num(prm.T_max) - Num(prm.T_min)) / (Num(1.0) + ex) + Num(prm.T_min);
+    } else {
+      // fp32: v_exp_f32 and v_rcp_f32 (2 + 1 instructions) instead of expf and a correctly rounded division (~30): a
+      // few units in the last place of T, the level the fp32 solve works at anyway
+      ex = __expf(-tau);
+      t.T = fmaf(Num(prm.T_max) - Num(prm.T_min), precise_rcp(Num(1.0) + ex), Num(prm.T_min));
+    }
     // get_grad_T2tau needs exp(-tau) again (:490): fp64 keeps it instead of tau; fp32 keeps -tau (exp(-tau) may be inf)
     if constexpr (sizeof(Num) == 8) t.tau = ex; else t.tau = -tau;
   }
   if (LG::any(bad)) return 4;
-  t.i1 = Num(1.0) / t.T;
+  t.i1 = sizeof(Num) == 8 ? Num(1.0) / t.T : precise_rcp(t.T);
   t.i2 = t.i1 * t.i1;
   t.i3 = t.i2 * t.i1;
   t.i4 = t.i2 * t.i2;
-  t.ns = act ? (int)(t.T / Num(prm.delta_t)) : 0;  // int(T / delta_t) (:401)
+  // int(T / delta_t) (:401); fp32: times the reciprocal formed in fp64 (10.0f exactly for delta_t = 0.1) instead of a
+  // correctly rounded fp32 division by 0.1f -- which is not 0.1 either
+  if constexpr (sizeof(Num) == 8)
+    t.ns = act ? (int)(t.T / Num(prm.delta_t)) : 0;
+  else
+    t.ns = act ? (int)(t.T * (Num)(1.0 / prm.delta_t)) : 0;
 
   if (t.M > 1) {
     Num Lo[2][2], Di[2][2], Up[2][2], E[2][2], R[2][DL], y0[2][DL], yM[2][DL], y[2][DL];
@@ -1148,10 +1161,10 @@ __device__ __forceinline__ SampleLanes balanced_sample_lanes(int M, int ns_piece
   int R = max(1, (total + kWave - 1) / kWave);
   int Lp = 0;
   for (;;) {
-    // ceil(ns / R) = floor((ns + R - 1/2) / R): the half keeps the quotient off the integers, so that the rounding of
-    // the reciprocal cannot tip it (exact for ns + R < 2^21)
+    // ceil(ns / R) = floor((ns + R - 1/2) / R): the half keeps the quotient off the integers, so that neither the rounding
+    // of the product nor the last bit of the reciprocal can tip it (exact for ns + R < 2^20)
     const float fr = (float)R;
-    Lp = mine > 0 ? (int)(((float)mine + fr - 0.5f) * __frcp_rn(fr)) : 0;
+    Lp = mine > 0 ? (int)(((float)mine + fr - 0.5f) * __builtin_amdgcn_rcpf(fr)) : 0;  // (v_rcp_f32: 1 ulp is plenty here)
     if (wave_sum(Lp) <= kWave) break;
     ++R;
   }
@@ -1280,7 +1293,12 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
 
   const Real dt = (Real)prm.delta_t, vmax2 = (Real)(prm.v_max * prm.v_max), safe = (Real)prm.safe_dis;
   const Real w2 = (Real)prm.w[2], w3 = (Real)prm.w[3];
-  const Real inv_ns = ns > 0 ? Real(1) / (Real)ns : Real(0);
+  // (fp32: v_rcp_f32 instead of the 11-instruction correctly rounded division; the fp64 parity mode divides)
+  Real inv_ns;
+  if constexpr (sizeof(Real) == 4)
+    inv_ns = ns > 0 ? __builtin_amdgcn_rcpf((float)ns) : Real(0);
+  else
+    inv_ns = ns > 0 ? Real(1) / (Real)ns : Real(0);
   Real aC[6][D];
 #pragma unroll
   for (int k = 0; k < 6; ++k)
@@ -1606,8 +1624,8 @@ __device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D), Num> &t, 
     // FLT_MAX: a value below 1e-38 (as in fp64) instead of inf / inf once expf overflows (-tau > 88.72)
     const Num nt = t.tau;
     if (lane < M && nt > Num(354.891356446692)) pow_overflow = 1;
-    const Num ex = fmin(exp(nt), Num(3.4028234663852886e38));
-    const Num s = Num(1.0) / (Num(1.0) + ex);
+    const Num ex = fmin(__expf(nt), Num(3.4028234663852886e38));
+    const Num s = precise_rcp(Num(1.0) + ex);
     gtau = LG::sum_dims(gTt) * (Num(prm.T_max) - Num(prm.T_min)) * ((ex * s) * s);
   }
   return LG::any(pow_overflow) ? 4 : 0;
