@@ -909,6 +909,117 @@ __device__ __forceinline__ void thomas_solve(int M, const Num (&Lo)[2][2], const
   }
 }
 
+// The same block-tridiagonal systems by PARALLEL CYCLIC REDUCTION (all-fp32 mode, whole-wavefront lane groups).
+// Block Thomas above walks the joints: 20 dependent steps at cfg2 in which ONE lane (three with lane = (piece, dimension))
+// does the work of an instruction every lane pays for -- 18 % of the kernel's vector instructions -- followed by two
+// Kogge-Stone scans per right-hand side (15 %).  In a kernel bound by the issue of its vector instructions that is the
+// wrong trade.  PCR eliminates, in every equation at once, the neighbours at distance s = 1, 2, 4, ...:
+//     a = -L_i D_{i-s}^-1,   g = -U_i D_{i+s}^-1,
+//     L_i' = a L_{i-s},   U_i' = g U_{i+s},   D_i' = D_i + a U_{i-s} + g L_{i+s},   R_i' = R_i + a R_{i-s} + g R_{i+s};
+// after ceil(log2(M-1)) levels the equations are uncoupled, y_i = D_i^-1 R_i.  63 vector instructions a level with
+// every lane busy: 330 per solve instead of ~540, no factors to keep between the forward and the adjoint pass (the
+// adjoint runs the reduction again on the transposed blocks: cheaper than carrying five levels of multipliers in
+// registers, and the four registers of the pivot inverses are free across the sample loop).  Neighbours' blocks come
+// through ds_bpermute (28 a level).  The systems are block diagonally dominant (|N Lo| < 1 above), so elimination without
+// pivoting is as stable here as it is for block Thomas; in fp32 the coefficients agree with the fp64 solve to the same
+// 1e-7 (tests/test_gpu_parity.py).  The fp64 modes keep block Thomas: their runs are pinned to its rounding.
+// In: L, Dg, U, R of joint p on the lanes of piece p (1 <= p <= M-1; boundary values already folded into R, L_1 = 0,
+// U_{M-1} = 0); other lanes are made identity rows here.  Out: y on those lanes.
+template <int DL, class LG, typename Num>
+__device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2], Num (&U)[2][2], Num (&R)[2][DL],
+                                          Num (&y)[2][DL]) {
+  static_assert(LG::W == kWave, "written for lane groups that span the wavefront");
+  const int p = LG::piece();
+  const bool in = p >= 1 && p < M;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      L[i][j] = in ? L[i][j] : Num(0.0);
+      U[i][j] = in ? U[i][j] : Num(0.0);
+      Dg[i][j] = in ? Dg[i][j] : Num(i == j ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int d = 0; d < DL; ++d) R[i][d] = in ? R[i][d] : Num(0.0);
+  }
+  const int lane = lane_id();
+  Num I[2][2];
+  auto invert = [&]() {
+    const Num det = fma(Dg[0][0], Dg[1][1], -(Dg[0][1] * Dg[1][0]));
+    const Num r = precise_rcp(det);
+    I[0][0] = Dg[1][1] * r;
+    I[0][1] = -Dg[0][1] * r;
+    I[1][0] = -Dg[1][0] * r;
+    I[1][1] = Dg[0][0] * r;
+  };
+  for (int s = 1; s < M - 1; s <<= 1) {
+    invert();
+    // neighbours at distance s (lanes without one read themselves: their coupling block is zero by then)
+    const int lp = lane - s * LG::S, ln = lane + s * LG::S;
+    const int sp = lp >= 0 ? lp : lane, sn = ln < kWave ? ln : lane;
+    // (the last level leaves uncoupled equations: its L' and U' -- zero -- are not formed, nor their inputs fetched)
+    const bool last = 2 * s >= M - 1;
+    Num Ip[2][2], Lp[2][2], Upv[2][2], Rp[2][DL], In[2][2], Ln[2][2], Un[2][2], Rn[2][DL];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        Ip[i][j] = __shfl(I[i][j], sp, kWave);
+        Upv[i][j] = __shfl(U[i][j], sp, kWave);
+        In[i][j] = __shfl(I[i][j], sn, kWave);
+        Ln[i][j] = __shfl(L[i][j], sn, kWave);
+        Lp[i][j] = Un[i][j] = Num(0.0);
+        if (!last) {
+          Lp[i][j] = __shfl(L[i][j], sp, kWave);
+          Un[i][j] = __shfl(U[i][j], sn, kWave);
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < DL; ++d) {
+        Rp[i][d] = __shfl(R[i][d], sp, kWave);
+        Rn[i][d] = __shfl(R[i][d], sn, kWave);
+      }
+    }
+    Num a[2][2], g[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        a[i][j] = -fma(L[i][0], Ip[0][j], L[i][1] * Ip[1][j]);
+        g[i][j] = -fma(U[i][0], In[0][j], U[i][1] * In[1][j]);
+      }
+    Num Ln2[2][2], Un2[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        Ln2[i][j] = Un2[i][j] = Num(0.0);
+        if (!last) {
+          Ln2[i][j] = fma(a[i][0], Lp[0][j], a[i][1] * Lp[1][j]);
+          Un2[i][j] = fma(g[i][0], Un[0][j], g[i][1] * Un[1][j]);
+        }
+        Dg[i][j] = fma(g[i][1], Ln[1][j], fma(g[i][0], Ln[0][j], fma(a[i][1], Upv[1][j], fma(a[i][0], Upv[0][j], Dg[i][j]))));
+      }
+#pragma unroll
+      for (int d = 0; d < DL; ++d)
+        R[i][d] = fma(g[i][1], Rn[1][d], fma(g[i][0], Rn[0][d], fma(a[i][1], Rp[1][d], fma(a[i][0], Rp[0][d], R[i][d]))));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        L[i][j] = Ln2[i][j];
+        U[i][j] = Un2[i][j];
+      }
+  }
+  invert();
+#pragma unroll
+  for (int d = 0; d < DL; ++d) {
+    y[0][d] = fma(I[0][0], R[0][d], I[0][1] * R[1][d]);
+    y[1][d] = fma(I[1][0], R[0][d], I[1][1] * R[1][d]);
+  }
+}
+
 // joint-system blocks of lane p (joint p between piece p-1 "a" and piece p "b")
 // (a1..a3 = T^-1..T^-3 of piece p-1, fetched from the neighbour lane by the caller)
 template <class TrajT, typename Num>
@@ -938,7 +1049,7 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
     // (fp32: expf overflows to +inf beyond 88.72 -- T is then T_min exactly, as it is in fp64 to rounding from -tau = 37
     //  on; the statuses stay those of the fp64 modes because the range tests are made on tau, not on exp(-tau))
     Num ex;
-    if constexpr (sizeof(Num) == 8) {
+    if constexpr (sizeof(Num) == 8 || LG::W != kWave) {
       ex = exp(-tau);
       t.T = (Num(prm.T_max) - Num(prm.T_min)) / (Num(1.0) + ex) + Num(prm.T_min);
     } else {
@@ -951,13 +1062,13 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
     if constexpr (sizeof(Num) == 8) t.tau = ex; else t.tau = -tau;
   }
   if (LG::any(bad)) return 4;
-  t.i1 = sizeof(Num) == 8 ? Num(1.0) / t.T : precise_rcp(t.T);
+  t.i1 = (sizeof(Num) == 8 || LG::W != kWave) ? Num(1.0) / t.T : precise_rcp(t.T);
   t.i2 = t.i1 * t.i1;
   t.i3 = t.i2 * t.i1;
   t.i4 = t.i2 * t.i2;
   // int(T / delta_t) (:401); fp32: times the reciprocal formed in fp64 (10.0f exactly for delta_t = 0.1) instead of a
   // correctly rounded fp32 division by 0.1f -- which is not 0.1 either
-  if constexpr (sizeof(Num) == 8)
+  if constexpr (sizeof(Num) == 8 || LG::W != kWave)
     t.ns = act ? (int)(t.T / Num(prm.delta_t)) : 0;
   else
     t.ns = act ? (int)(t.T * (Num)(1.0 / prm.delta_t)) : 0;
@@ -966,7 +1077,8 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
     Num Lo[2][2], Di[2][2], Up[2][2], E[2][2], R[2][DL], y0[2][DL], yM[2][DL], y[2][DL];
     const Num a1 = LG::prev(t.i1, Num(1.0)), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;
     joint_blocks(t, a1, a2, a3, Lo, Di, Up);
-    thomas_factor<LG, Num>((prm.dbg & (2 | 8)) ? 1 : t.M, Lo, Di, Up, t.N, E);
+    constexpr bool kPcr = sizeof(Num) == 4 && LG::W == kWave;  // all-fp32 mode: parallel cyclic reduction (pcr_solve)
+    if constexpr (!kPcr) thomas_factor<LG, Num>((prm.dbg & (2 | 8)) ? 1 : t.M, Lo, Di, Up, t.N, E);
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
       // displacement of piece p-1 and of piece p
@@ -979,7 +1091,30 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
       yM[0][d] = (Num)bstate<D, LG>(t.tail, 1, d);
       yM[1][d] = (Num)bstate<D, LG>(t.tail, 2, d);
     }
-    thomas_solve<DL, LG, Num>((prm.dbg & (2 | 16)) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);
+    if constexpr (kPcr) {
+      // the boundary states move to the right-hand sides of the first and the last joint
+#pragma unroll
+      for (int d = 0; d < DL; ++d) {
+        if (lane == 1) {
+          R[0][d] -= Lo[0][0] * y0[0][d] + Lo[0][1] * y0[1][d];
+          R[1][d] -= Lo[1][0] * y0[0][d] + Lo[1][1] * y0[1][d];
+        }
+        if (lane == t.M - 1) {
+          R[0][d] -= Up[0][0] * yM[0][d] + Up[0][1] * yM[1][d];
+          R[1][d] -= Up[1][0] * yM[0][d] + Up[1][1] * yM[1][d];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          Lo[i][j] = lane == 1 ? Num(0.0) : Lo[i][j];
+          Up[i][j] = lane == t.M - 1 ? Num(0.0) : Up[i][j];
+        }
+      pcr_solve<DL, LG, Num>(t.M, Lo, Di, Up, R, y);
+    } else {
+      thomas_solve<DL, LG, Num>((prm.dbg & (2 | 16)) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);
+    }
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
       t.V0[d] = lane == 0 ? (Num)bstate<D, LG>(t.head, 1, d) : y[0][d];
@@ -1295,7 +1430,7 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
   const Real w2 = (Real)prm.w[2], w3 = (Real)prm.w[3];
   // (fp32: v_rcp_f32 instead of the 11-instruction correctly rounded division; the fp64 parity mode divides)
   Real inv_ns;
-  if constexpr (sizeof(Real) == 4)
+  if constexpr (sizeof(Real) == 4 && LG::W == kWave)
     inv_ns = ns > 0 ? __builtin_amdgcn_rcpf((float)ns) : Real(0);
   else
     inv_ns = ns > 0 ? Real(1) / (Real)ns : Real(0);
@@ -1530,7 +1665,36 @@ __device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D), Num> &t, 
   Num lam[2][DL];
 #pragma unroll
   for (int d = 0; d < DL; ++d) lam[0][d] = lam[1][d] = Num(0.0);
-  if (M > 1) {
+  constexpr bool kPcr = sizeof(Num) == 4 && LG::W == kWave;  // all-fp32 mode: the transposed system by pcr_solve, too
+  if constexpr (kPcr) {
+    if (M > 1) {
+      Num LoT[2][2], DiT[2][2], UpT[2][2], R[2][DL], y[2][DL];
+      LoT[0][0] = Num(24.0) * a2;  LoT[0][1] = -Num(168.0) * a3;   // Up_{p-1}^T (piece p-1 = "a")
+      LoT[1][0] = -Num(3.0) * a1;  LoT[1][1] = Num(24.0) * a2;
+      DiT[0][0] = -Num(36.0) * a2 + Num(36.0) * t.i2;  DiT[0][1] = -Num(192.0) * a3 - Num(192.0) * t.i3;  // Di_p^T
+      DiT[1][0] = Num(9.0) * a1 + Num(9.0) * t.i1;     DiT[1][1] = Num(36.0) * a2 - Num(36.0) * t.i2;
+      UpT[0][0] = -Num(24.0) * t.i2;  UpT[0][1] = -Num(168.0) * t.i3;  // Lo_{p+1}^T (piece p = "b")
+      UpT[1][0] = -Num(3.0) * t.i1;   UpT[1][1] = -Num(24.0) * t.i2;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          LoT[i][j] = lane == 1 ? Num(0.0) : LoT[i][j];        // (zero boundary values: nothing to fold)
+          UpT[i][j] = lane == M - 1 ? Num(0.0) : UpT[i][j];
+        }
+#pragma unroll
+      for (int d = 0; d < DL; ++d) {
+        R[0][d] = S[1][d];
+        R[1][d] = S[2][d];
+      }
+      pcr_solve<DL, LG, Num>(M, LoT, DiT, UpT, R, y);
+#pragma unroll
+      for (int d = 0; d < DL; ++d) {
+        lam[0][d] = (lane >= 1 && lane < M) ? y[0][d] : Num(0.0);
+        lam[1][d] = (lane >= 1 && lane < M) ? y[1][d] : Num(0.0);
+      }
+    }
+  } else if (M > 1) {
     // transposed system: row p of K^T has Up_{p-1}^T, Di_p^T, Lo_{p+1}^T; pivot inverses are N^T
     Num LoT[2][2], NT[2][2], ET[2][2], R[2][DL], z0[2][DL], y[2][DL];
     LoT[0][0] = Num(24.0) * a2;  LoT[0][1] = -Num(168.0) * a3;   // Up_{p-1}^T (piece p-1 = "a")
@@ -1624,8 +1788,14 @@ __device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D), Num> &t, 
     // FLT_MAX: a value below 1e-38 (as in fp64) instead of inf / inf once expf overflows (-tau > 88.72)
     const Num nt = t.tau;
     if (lane < M && nt > Num(354.891356446692)) pow_overflow = 1;
-    const Num ex = fmin(__expf(nt), Num(3.4028234663852886e38));
-    const Num s = precise_rcp(Num(1.0) + ex);
+    Num ex, s;
+    if constexpr (LG::W == kWave) {
+      ex = fmin(__expf(nt), Num(3.4028234663852886e38));
+      s = precise_rcp(Num(1.0) + ex);
+    } else {
+      ex = fmin(exp(nt), Num(3.4028234663852886e38));
+      s = Num(1.0) / (Num(1.0) + ex);
+    }
     gtau = LG::sum_dims(gTt) * (Num(prm.T_max) - Num(prm.T_min)) * ((ex * s) * s);
   }
   return LG::any(pow_overflow) ? 4 : 0;

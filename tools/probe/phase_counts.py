@@ -10,7 +10,7 @@ import csv, glob, json, os, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out = os.path.abspath(sys.argv[1]); os.makedirs(out, exist_ok=True)
 os.environ["TMPDIR"] = "/tmp"
-for flags in (0, 1, 8, 16, 24, 4):
+for flags in (0, 1):
     env = dict(os.environ, NEO_BENCH_FLAGS_OR=str(flags))
     d = os.path.join(out, f"pmc_{flags}")
     log = os.path.join(out, f"{flags}.log")
