@@ -1035,7 +1035,10 @@ __device__ __forceinline__ void joint_blocks(const TrajT &t, Num a1, Num a2, Num
 
 // forward pass.  Inputs (PIECE layout): t.tau, t.P0, t.P1 set by the caller, head/tail uniform.
 // Returns 0 or NUMERIC_RANGE (4) when exp(-tau) overflows like math.exp does (:481).
-template <int D, class LG = WaveLanes, typename Num = double>
+// PCR: solve the joint system by parallel cyclic reduction (pcr_solve) instead of block Thomas -- the all-fp32 mode on a
+// wavefront-wide lane group; fp64 solves keep block Thomas (the parity mode's recorded runs are pinned to that rounding,
+// and the mixed mode measured slower with the reduction in fp64).  The caller passes the same value to minco_backward.
+template <int D, class LG = WaveLanes, typename Num = double, bool PCR = (sizeof(Num) == 4 && LG::W == kWave)>
 __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const DevParams &prm, double &energy,
                                              double &time_sum) {
   constexpr int DL = LG::dl(D);
@@ -1077,7 +1080,7 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
     Num Lo[2][2], Di[2][2], Up[2][2], E[2][2], R[2][DL], y0[2][DL], yM[2][DL], y[2][DL];
     const Num a1 = LG::prev(t.i1, Num(1.0)), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;
     joint_blocks(t, a1, a2, a3, Lo, Di, Up);
-    constexpr bool kPcr = sizeof(Num) == 4 && LG::W == kWave;  // all-fp32 mode: parallel cyclic reduction (pcr_solve)
+    constexpr bool kPcr = PCR;  // fp32-sampling modes: parallel cyclic reduction (pcr_solve)
     if constexpr (!kPcr) thomas_factor<LG, Num>((prm.dbg & (2 | 8)) ? 1 : t.M, Lo, Di, Up, t.N, E);
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
@@ -1609,7 +1612,7 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
 // Returns 0, or 4 where the reference would leave through OverflowError: it raises Python floats to
 // a power in two places, `(np.dot(c, beta3).item())**2` (:382) and `(1+math.exp(-tau))**2` (:490),
 // and Python raises once such a result exceeds the double range instead of returning inf.
-template <int D, class LG = WaveLanes, typename Num = double>
+template <int D, class LG = WaveLanes, typename Num = double, bool PCR = (sizeof(Num) == 4 && LG::W == kWave)>
 __device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D), Num> &t, const DevParams &prm,
                                               Num (&gC)[6][LG::dl(D)], Num gT, Num (&gq)[LG::dl(D)], Num &gtau) {
   constexpr int DL = LG::dl(D);
@@ -1665,7 +1668,7 @@ __device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D), Num> &t, 
   Num lam[2][DL];
 #pragma unroll
   for (int d = 0; d < DL; ++d) lam[0][d] = lam[1][d] = Num(0.0);
-  constexpr bool kPcr = sizeof(Num) == 4 && LG::W == kWave;  // all-fp32 mode: the transposed system by pcr_solve, too
+  constexpr bool kPcr = PCR;  // the transposed system by pcr_solve, too
   if constexpr (kPcr) {
     if (M > 1) {
       Num LoT[2][2], DiT[2][2], UpT[2][2], R[2][DL], y[2][DL];

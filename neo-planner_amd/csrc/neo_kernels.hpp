@@ -69,6 +69,11 @@ template <int D, int NS, typename Real, class MapT, class LookupT, int SU = NEO_
           bool PAIRS32 = false, typename Num = double>
 struct DevBackend {
   static constexpr int DL = LG::dl(D);
+  // joint systems by parallel cyclic reduction in the all-fp32 mode (neo_device.hpp pcr_solve).  Block Thomas wherever the
+  // solve is fp64: the parity mode's recorded runs are pinned to its rounding, and in the mixed mode the reduction was
+  // measured SLOWER (fp64: 744 k against 778 k traj/s at cfg2, 142 k against 156 k at cfg5 -- five levels of 63 fp64
+  // instructions with ~60 live doubles spill where block Thomas does not)
+  static constexpr bool kPcr = sizeof(Num) == 4 && LG::W == kWave;
   // FLAT layout with NS slots: n <= 64 * NS
   struct Vec {
     Num v[NS];
@@ -244,7 +249,7 @@ struct DevBackend {
     scatter_x(x);
     Num *xn = reinterpret_cast<Num *>(xs);
     double energy, tsum;
-    const int st = minco_forward<D, LG, Num>(t, prm, energy, tsum);
+    const int st = minco_forward<D, LG, Num, kPcr>(t, prm, energy, tsum);
 #ifdef NEO_STAMPS
     const long long s1 = wall_clock64();
 #endif
@@ -303,7 +308,7 @@ struct DevBackend {
     costs[3] = uniform(ck);
     f = uniform(costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3]);
     Num gq[DL], gtau;
-    const int bst = minco_backward<D, LG, Num>(t, prm, gC, gT, gq, gtau);
+    const int bst = minco_backward<D, LG, Num, kPcr>(t, prm, gC, gT, gq, gtau);
     if (bst != 0) return bst;
     // PIECE -> FLAT
     lds_wave_sync();
