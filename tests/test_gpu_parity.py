@@ -209,6 +209,31 @@ def test_cost_grad_trilinear_matches_oracle():
                     assert rel_err(out["grad"][b], g) < tol * 5
 
 
+def test_all_fp32_joint_solve_by_cyclic_reduction_for_every_piece_count():
+    """The all-fp32 mode solves the joint systems by parallel cyclic reduction (csrc/neo_device.hpp pcr_solve): zero levels
+    at M = 2, one at M = 3, ... six at M = 64, lane = (piece, dimension) up to M = 21 and lane = piece beyond.  For every
+    piece count the coefficients, the cost and the gradient agree with the fp64 kernels (block Thomas) to fp32 round-off
+    of the solve, on durations spread over [T_min, T_max]."""
+    rng = np.random.default_rng(23)
+    n = 32
+    dist = np.full((n, n, n), 4.0, np.float32)
+    dist[:, :, :6] = np.linspace(0.0, 1.2, 6)[None, None, :]
+    dist[10:14, 12:18, :] = 0.05
+    g3 = npa.ESDF3D(dist, 0.4, (0.0, -6.4, 0.0), store="f32", layout="yz4")
+    for M in (1, 2, 3, 4, 5, 8, 9, 16, 17, 21, 22, 33, 41, 63, 64):
+        B = 3
+        head, tail, wp, _ = _random_requests(rng, B, M, 3, (np.array([1.0, -5.0, 1.0]), np.array([11.5, 5.0, 10.0])))
+        ts = rng.uniform(0.55, 4.8, (B, M))
+        x = npa.BatchPlanner().pack_x(wp, ts)
+        ref = npa.BatchPlanner(sample_dtype="f64").cost_grad(g3, x, head, tail, want_coeffs=True)
+        got = npa.BatchPlanner(sample_dtype="f32x").cost_grad(g3, x, head, tail, want_coeffs=True)
+        assert np.all(got["status"] == 0) and np.all(ref["status"] == 0), M
+        for b in range(B):
+            assert rel_err(got["coeffs"][b], ref["coeffs"][b]) < (2e-5 if M <= 41 else 1e-4), (M, b, rel_err(got["coeffs"][b], ref["coeffs"][b]))
+            assert abs(got["cost"][b] - ref["cost"][b]) <= 1e-4 * abs(ref["cost"][b]), (M, b)
+            assert rel_err(got["grad"][b], ref["grad"][b]) < 5e-4, (M, b, rel_err(got["grad"][b], ref["grad"][b]))
+
+
 def test_sampled_terms_kernel_matches_oracle():
     """the ESDF-lookup kernel alone: add_sampled_cost + add_sampled_grad_CT (:392-466)"""
     d = load(golden("g1_eval_s1.npz")[0])
