@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kWave) void traj_state_kernel(int B, int M, DevPara
   be.hist = nullptr;
   be.m = NEO_LBFGS_M;
   be.coeff_out = nullptr;
-  load_boundary<D>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
+  load_boundary(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
   const int n = be.t.n;
   const int lane = lane_id();
   typename DevBackend<D, kSlots, double, NoMap, NoLookup>::Vec xv;
@@ -395,6 +395,7 @@ void fill_dev_params(neo_ctx *c) {
   d.maxfun = p.maxfun;
   d.stale_T = p.bugcompat_stale_T;
   d.dbg = p.flags;
+  d.derive();
 }
 
 int ensure_scratch(neo_ctx *c, size_t bytes) {

@@ -39,7 +39,43 @@ struct DevParams {
   double ftol, gtol;
   int maxls, maxiter, maxfun, stale_T;
   int dbg;  // timing experiments only (neo_params.flags): 1 skip sample loop, 2 skip joint sweeps, 4 no history
+  // fp32 forms of what the fp32 arithmetic uses, derived on the host (derive()): kernel arguments arrive in scalar
+  // registers, whereas a (float)prm.x inside a kernel is a vector conversion whose (wave-uniform) result the compiler
+  // hoists and then keeps in a vector register across the whole optimiser loop -- nine of them, spilled to scratch in the
+  // three-waves-per-SIMD kernels
+  struct F32 {
+    float T_min, T_span;  // (float)T_max - (float)T_min, rounded as the device expression was
+    float dt, inv_dt;     // (float)delta_t, (float)(1 / delta_t)
+    float vmax2, safe;
+    float w[4];
+  } f;
+  __host__ __device__ void derive() {
+    f.T_min = (float)T_min;
+    f.T_span = (float)T_max - (float)T_min;
+    f.dt = (float)delta_t;
+    f.inv_dt = (float)(1.0 / delta_t);
+    f.vmax2 = (float)(v_max * v_max);
+    f.safe = (float)safe_dis;
+    for (int k = 0; k < 4; ++k) f.w[k] = (float)w[k];
+  }
 };
+// a parameter in the arithmetic N: the double itself, or its fp32 form from DevParams::f
+#define NEO_PARAM(name, dexpr, fexpr)                                                  \
+  template <typename N>                                                                \
+  __device__ __forceinline__ N name(const DevParams &p) {                              \
+    if constexpr (sizeof(N) == 4) return (fexpr); else return (N)(dexpr);              \
+  }
+NEO_PARAM(par_T_min, p.T_min, p.f.T_min)
+NEO_PARAM(par_T_span, N(p.T_max) - N(p.T_min), p.f.T_span)
+NEO_PARAM(par_dt, p.delta_t, p.f.dt)
+NEO_PARAM(par_inv_dt, 1.0 / p.delta_t, p.f.inv_dt)
+NEO_PARAM(par_vmax2, p.v_max * p.v_max, p.f.vmax2)
+NEO_PARAM(par_safe, p.safe_dis, p.f.safe)
+NEO_PARAM(par_w0, p.w[0], p.f.w[0])
+NEO_PARAM(par_w1, p.w[1], p.f.w[1])
+NEO_PARAM(par_w2, p.w[2], p.f.w[2])
+NEO_PARAM(par_w3, p.w[3], p.f.w[3])
+#undef NEO_PARAM
 
 // 2-D reference map: one 32-byte record per cell {dist, grad_x, grad_y, 0}
 struct Map2D {
@@ -89,6 +125,9 @@ __device__ __forceinline__ double uniform(double v) {
   int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
   int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
   return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float uniform(float v) {
+  return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
 }
 // ---- DPP cross-lane moves (no LDS round trip).  ctrl: 0x110+n = row_shr:n (lane i <- lane i-n inside
 // its row of 16), 0x142 / 0x143 = row_bcast:15 / row_bcast:31, 0x130 / 0x138 = wave_shl:1 / wave_shr:1.
@@ -356,16 +395,24 @@ struct Lookup3D {
   const Map3D &m;
   __amdgpu_buffer_rsrc_t rsrc;
   // fp32 arithmetic: cell coordinate minus one half in ONE fma, um = pos * inv + off (all wave-uniform operands)
-  float inv, off[3], hi[3];
+  float inv, off[3], mid[3], half[3], top[3];
   __device__ __forceinline__ explicit Lookup3D(const Map3D &m_)
       : m(m_), rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(m_.data), 0, (int)m_.bytes, 0x00020000)) {
     inv = (float)(1.0 / m_.res);
     off[0] = (float)(-m_.ox / m_.res - 0.5);
     off[1] = (float)(-m_.oy / m_.res - 0.5);
     off[2] = (float)(-m_.oz / m_.res - 0.5);
-    hi[0] = (float)m_.nx - 0.5f;
-    hi[1] = (float)m_.ny - 0.5f;
-    hi[2] = (float)m_.nz - 0.5f;
+    const int nn[3] = {m_.nx, m_.ny, m_.nz};
+    // (the constants are the same in every lane but come out of vector conversions: v_readfirstlane puts them in
+    // scalar registers, of which each instruction below can name one, instead of twelve vector registers held across the
+    // optimiser loop -- the three-waves-per-SIMD kernels have none to spare)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      off[k] = uniform(off[k]);
+      mid[k] = uniform(0.5f * (float)nn[k] - 0.5f);  // centre and half width of [-0.5, n - 0.5)
+      half[k] = uniform(0.5f * (float)nn[k]);
+      top[k] = uniform(__uint_as_float(__float_as_uint((float)(nn[k] - 1)) - 1u));  // the float just below n - 1
+    }
   }
   struct Addr {
     int i0[3];
@@ -387,13 +434,26 @@ struct Lookup3D {
     Addr a;
     a.inside = on;
     if constexpr (sizeof(Real) == 4) {
+      // fp32: 7 instructions an axis.  The cell coordinate is clamped into [0, n - 1) first (v_med3_f32; `top` is the largest
+      // float below n - 1), so that truncation is the floor and the base corner needs no integer clamps; the fraction is
+      // what is left -- 0 in the half cell below the first voxel centre, one float spacing of n - 1 short of 1 in the
+      // half cell above the last.  Inside <=> -0.5 <= um < n - 0.5 <=> |um - mid| < half (the closed lower end differs from the open one on
+      // a set of measure zero; the fp64 parity path below keeps the oracle's comparisons).
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const float um = fmaf(pos[k], inv, off[k]);
-        if (!(um >= -0.5f && um < hi[k])) a.inside = false;
+#if defined(NEO_T1)
+        if (!(um >= -0.5f && um < (float)n[k] - 0.5f)) a.inside = false;
         const int i = min(max((int)floorf(um), 0), n[k] - 2);
         a.i0[k] = i;
         a.fr[k] = __builtin_amdgcn_fmed3f(um - (float)i, 0.0f, 1.0f);
+#else
+        if (!(fabsf(um - mid[k]) < half[k])) a.inside = false;
+        const float tc = __builtin_amdgcn_fmed3f(um, 0.0f, top[k]);
+        const int i = (int)tc;
+        a.i0[k] = i;
+        a.fr[k] = tc - (float)i;
+#endif
       }
       if (!a.inside) a.i0[0] = a.i0[1] = a.i0[2] = 0;
       return a;
@@ -735,21 +795,6 @@ struct WaveLanesPD {
   static __host__ __device__ __forceinline__ int lanes_per_piece(int M) { return sample_lanes_per_piece_fwd(M); }
 };
 
-// element (row k, dimension of this lane's local index dl) of a boundary state [3][D] in global memory: a uniform
-// scalar load when the lane holds all dimensions, a select among the D scalars when it holds one
-template <int D, class LG>
-__device__ __forceinline__ double bstate(const double *p, int k, int dl) {
-  if constexpr (LG::S == 1) {
-    return p[k * D + dl];
-  } else {
-    const int d = LG::dim0();
-    double v = p[k * D];
-#pragma unroll
-    for (int j = 1; j < D; ++j) v = (d == j) ? p[k * D + j] : v;
-    return v;
-  }
-}
-
 // ------------------------------------------------------------------ per-trajectory state
 // DL = dimensions held per lane: D (PIECE layout: lane = piece) or 1 (lane = (piece, dimension), WaveLanesPD)
 template <int D, int DL = D, typename Num = double>
@@ -765,7 +810,32 @@ struct Traj {
   int ns;                         // samples of this piece: int(T / delta_t)
   Num N[2][2];                 // pivot-block inverse of the joint system (lane = joint)
   const double *head, *tail;      // boundary states [3][D] in global memory (wave-uniform scalar loads)
+  const Num *bnd;                 // lane = (piece, dimension): head [3][D] then tail [3][D] in LDS (stage_boundary)
 };
+
+// element (row k, dimension of this lane's local index dl) of the head (TAIL = false) or tail boundary state: a uniform
+// scalar load when the lane holds all dimensions.  When it holds one, an LDS read of the copy stage_boundary() made
+// once per trajectory: read through the global pointers at every evaluation, the compiler keeps one 64-bit address per
+// lane and row alive across the optimiser loop (12 registers, all spilled in the three-waves-per-SIMD kernels) and the
+// loads queue behind the other wavefronts' field gathers -- measured 1.06 M -> 1.20 M traj/s at cfg2 without them.
+template <int D, class LG, bool TAIL, int DL, typename Num>
+__device__ __forceinline__ Num bstate(const Traj<D, DL, Num> &t, int k, int dl) {
+  if constexpr (LG::S == 1)
+    return (Num)(TAIL ? t.tail : t.head)[k * D + dl];
+  else
+    return t.bnd[((TAIL ? 3 : 0) + k) * D + LG::dim0()];
+}
+// lds: 6 * D elements of the wavefront's own
+template <int D, class LG, int DL, typename Num>
+__device__ __forceinline__ void stage_boundary(Traj<D, DL, Num> &t, Num *lds) {
+  if constexpr (LG::S > 1) {
+    const int lane = lane_id();
+    if (lane < 3 * D) lds[lane] = (Num)t.head[lane];
+    if (lane < 3 * D) lds[3 * D + lane] = (Num)t.tail[lane];
+    lds_wave_sync();
+    t.bnd = lds;
+  }
+}
 
 // Block-tridiagonal systems with 2x2 blocks on the interior joints p = 1..M-1 (blocks on lane p):
 //     Lo_p y_{p-1} + Di_p y_p + Up_p y_{p+1} = R_p,      y_0 and y_M given.
@@ -1054,12 +1124,12 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
     Num ex;
     if constexpr (sizeof(Num) == 8 || LG::W != kWave) {
       ex = exp(-tau);
-      t.T = (Num(prm.T_max) - Num(prm.T_min)) / (Num(1.0) + ex) + Num(prm.T_min);
+      t.T = par_T_span<Num>(prm) / (Num(1.0) + ex) + par_T_min<Num>(prm);
     } else {
       // fp32: v_exp_f32 and v_rcp_f32 (2 + 1 instructions) instead of expf and a correctly rounded division (~30): a
       // few units in the last place of T, the level the fp32 solve works at anyway
       ex = __expf(-tau);
-      t.T = fmaf(Num(prm.T_max) - Num(prm.T_min), precise_rcp(Num(1.0) + ex), Num(prm.T_min));
+      t.T = fmaf(par_T_span<Num>(prm), precise_rcp(Num(1.0) + ex), par_T_min<Num>(prm));
     }
     // get_grad_T2tau needs exp(-tau) again (:490): fp64 keeps it instead of tau; fp32 keeps -tau (exp(-tau) may be inf)
     if constexpr (sizeof(Num) == 8) t.tau = ex; else t.tau = -tau;
@@ -1072,9 +1142,9 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
   // int(T / delta_t) (:401); fp32: times the reciprocal formed in fp64 (10.0f exactly for delta_t = 0.1) instead of a
   // correctly rounded fp32 division by 0.1f -- which is not 0.1 either
   if constexpr (sizeof(Num) == 8 || LG::W != kWave)
-    t.ns = act ? (int)(t.T / Num(prm.delta_t)) : 0;
+    t.ns = act ? (int)(t.T / par_dt<Num>(prm)) : 0;
   else
-    t.ns = act ? (int)(t.T * (Num)(1.0 / prm.delta_t)) : 0;
+    t.ns = act ? (int)(t.T * par_inv_dt<Num>(prm)) : 0;
 
   if (t.M > 1) {
     Num Lo[2][2], Di[2][2], Up[2][2], E[2][2], R[2][DL], y0[2][DL], yM[2][DL], y[2][DL];
@@ -1089,10 +1159,10 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
       const Num dPa = LG::prev(dPb, Num(0.0));
       R[0][d] = -(Num(60.0) * a3 * dPa - Num(60.0) * t.i3 * dPb);
       R[1][d] = -(Num(360.0) * a4 * dPa + Num(360.0) * t.i4 * dPb);
-      y0[0][d] = (Num)bstate<D, LG>(t.head, 1, d);
-      y0[1][d] = (Num)bstate<D, LG>(t.head, 2, d);
-      yM[0][d] = (Num)bstate<D, LG>(t.tail, 1, d);
-      yM[1][d] = (Num)bstate<D, LG>(t.tail, 2, d);
+      y0[0][d] = bstate<D, LG, false>(t, 1, d);
+      y0[1][d] = bstate<D, LG, false>(t, 2, d);
+      yM[0][d] = bstate<D, LG, true>(t, 1, d);
+      yM[1][d] = bstate<D, LG, true>(t, 2, d);
     }
     if constexpr (kPcr) {
       // the boundary states move to the right-hand sides of the first and the last joint
@@ -1120,21 +1190,21 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
     }
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
-      t.V0[d] = lane == 0 ? (Num)bstate<D, LG>(t.head, 1, d) : y[0][d];
-      t.A0[d] = lane == 0 ? (Num)bstate<D, LG>(t.head, 2, d) : y[1][d];
+      t.V0[d] = lane == 0 ? bstate<D, LG, false>(t, 1, d) : y[0][d];
+      t.A0[d] = lane == 0 ? bstate<D, LG, false>(t, 2, d) : y[1][d];
     }
   } else {
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
-      t.V0[d] = (Num)bstate<D, LG>(t.head, 1, d);
-      t.A0[d] = (Num)bstate<D, LG>(t.head, 2, d);
+      t.V0[d] = bstate<D, LG, false>(t, 1, d);
+      t.A0[d] = bstate<D, LG, false>(t, 2, d);
     }
   }
 #pragma unroll
   for (int d = 0; d < DL; ++d) {
     const Num v1 = LG::next(t.V0[d], Num(0.0)), a1 = LG::next(t.A0[d], Num(0.0));
-    t.V1[d] = (lane == t.M - 1) ? (Num)bstate<D, LG>(t.tail, 1, d) : v1;
-    t.A1[d] = (lane == t.M - 1) ? (Num)bstate<D, LG>(t.tail, 2, d) : a1;
+    t.V1[d] = (lane == t.M - 1) ? bstate<D, LG, true>(t, 1, d) : v1;
+    t.A1[d] = (lane == t.M - 1) ? bstate<D, LG, true>(t, 2, d) : a1;
   }
   // Hermite form of the quintic
   Num e = Num(0.0);
@@ -1429,8 +1499,8 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
   }
   const int iters = (prm.dbg & 1) ? 0 : (sl.rounds >= 0 ? sl.rounds : wave_max_nonneg((ns + L - 1) / L));
 
-  const Real dt = (Real)prm.delta_t, vmax2 = (Real)(prm.v_max * prm.v_max), safe = (Real)prm.safe_dis;
-  const Real w2 = (Real)prm.w[2], w3 = (Real)prm.w[3];
+  const Real dt = par_dt<Real>(prm), vmax2 = par_vmax2<Real>(prm), safe = par_safe<Real>(prm);
+  const Real w2 = par_w2<Real>(prm), w3 = par_w3<Real>(prm);
   // (fp32: v_rcp_f32 instead of the 11-instruction correctly rounded division; the fp64 parity mode divides)
   Real inv_ns;
   if constexpr (sizeof(Real) == 4 && LG::W == kWave)
@@ -1460,7 +1530,17 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
     for (int u = 0; u < U; ++u) {
       const int j = r + (it0 + u) * L;
       on[u] = j < ns;
-      const Real s = (Real)((double)j * prm.delta_t);  // beta_full row j: t = j * delta_t (:251)
+      // beta_full row j: t = j * delta_t (:251); fp32 sampling forms the product in fp32 (two instructions instead of
+      // three with two fp64 ones: the result differs from the rounded fp64 product by at most one unit in the last place)
+      Real s;
+#if defined(NEO_T2)
+      if constexpr (false)
+#else
+      if constexpr (sizeof(Real) == 4)
+#endif
+        s = (float)j * dt;
+      else
+        s = (Real)((double)j * prm.delta_t);
       sv[u] = s;
       Real pos[D];
       if constexpr (kVelLate) {
@@ -1621,11 +1701,11 @@ __device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D), Num> &t, 
   int pow_overflow = 0;
   const Num a1 = LG::prev(t.i1, Num(1.0)), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;  // piece p-1
   const Num T = t.T, T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
-  const Num w0 = Num(prm.w[0]);
+  const Num w0 = par_w0<Num>(prm);
   Num jerk_end[DL], snap_end[DL], crackle[DL];
   // add_energy_grad_CT (:361-384), add_time_grad_CT (:389-390)
   // (gT: the sampled partial and the time weight enter once per piece -- in the lane of its first dimension)
-  gT = (LG::dim0() == 0) ? gT + Num(prm.w[1]) : Num(0.0);
+  gT = (LG::dim0() == 0) ? gT + par_w1<Num>(prm) : Num(0.0);
 #pragma unroll
   for (int d = 0; d < DL; ++d) {
     const Num c3 = t.c[3][d], c4 = t.c[4][d], c5 = t.c[5][d];
@@ -1799,7 +1879,7 @@ __device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D), Num> &t, 
       ex = fmin(exp(nt), Num(3.4028234663852886e38));
       s = Num(1.0) / (Num(1.0) + ex);
     }
-    gtau = LG::sum_dims(gTt) * (Num(prm.T_max) - Num(prm.T_min)) * ((ex * s) * s);
+    gtau = LG::sum_dims(gTt) * par_T_span<Num>(prm) * ((ex * s) * s);
   }
   return LG::any(pow_overflow) ? 4 : 0;
 }

@@ -234,8 +234,8 @@ struct DevBackend {
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
       const int dg = LG::dim0() + d;  // the dimension: compile-time when the lane holds all of them
-      t.P0[d] = (p == 0 || !act) ? (Num)bstate<D, LG>(t.head, 0, d) : xn[dg * (M - 1) + (p > 0 ? p - 1 : 0)];
-      t.P1[d] = (p >= M - 1) ? (Num)bstate<D, LG>(t.tail, 0, d) : xn[dg * (M - 1) + p];
+      t.P0[d] = (p == 0 || !act) ? bstate<D, LG, false>(t, 0, d) : xn[dg * (M - 1) + (p > 0 ? p - 1 : 0)];
+      t.P1[d] = (p >= M - 1) ? bstate<D, LG, true>(t, 0, d) : xn[dg * (M - 1) + p];
     }
   }
 
@@ -331,14 +331,17 @@ struct DevBackend {
   }
 };
 
-template <int D, int DL, typename Num>
-__device__ __forceinline__ void load_boundary(Traj<D, DL, Num> &t, const double *head, const double *tail, int M) {
+// bnd_lds: 6 * D elements of LDS for the layouts with one dimension per lane (stage_boundary), unused otherwise
+template <class LG = WaveLanes, int D, int DL, typename Num>
+__device__ __forceinline__ void load_boundary(Traj<D, DL, Num> &t, const double *head, const double *tail, int M,
+                                              Num *bnd_lds = nullptr) {
   t.M = M;
   t.nq = D * (M - 1);
   t.n = t.nq + M;
   t.L = sample_lanes_per_piece(M);
   t.head = head;
   t.tail = tail;
+  stage_boundary<D, LG>(t, bnd_lds);
 }
 
 struct MapTable {
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
   __shared__ double sc[2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm;
   __shared__ double cst[12];
+  __shared__ Num bnd[6 * D];
   const int b = blockIdx.x;
   if (b >= B) return;
   using BE = DevBackend<D, NS, Real, MapT, LookupT, NEO_FUSED_U, LG, false, Num>;
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
   be.cst = cst;
   be.hist = nullptr;
   be.m = NEO_LBFGS_M;
-  load_boundary(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
+  load_boundary<LG>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M, bnd);
   const int n = be.t.n;
   be.npad = NS * kWave;
   be.coeff_out = coeffs ? coeffs + (size_t)b * 6 * M * D : nullptr;
@@ -415,6 +419,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   __shared__ double sc[2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm;
   __shared__ double cst[12];
+  __shared__ Num bnd[6 * D];
   if ((int)blockIdx.x >= B) return;
   // workgroups are dispatched in index order: `order` lets the caller start the runs it expects to
   // be long first (list scheduling: a long run that starts last sets the duration of the launch)
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   be.trace = trace ? trace + (size_t)b * trace_cap * 4 : nullptr;
   be.trace_cap = trace_cap;
   be.trace_xg = trace_xg ? trace_xg + (size_t)b * trace_cap * 2 * (D * (M - 1) + M) : nullptr;
-  load_boundary(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M);
+  load_boundary<LG>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M, bnd);
   const int n = be.t.n;
   be.npad = NS * kWave;
   be.hist = reinterpret_cast<typename BE::Hist *>(dyn_lds + stage);

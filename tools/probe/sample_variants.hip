@@ -301,6 +301,7 @@ extern "C" double probe_run(int variant, int B, int M, const double *prm9 /* v_m
   variant &= 0xff;
   p.v_max = prm9[0]; p.T_min = prm9[1]; p.T_max = prm9[2]; p.safe_dis = prm9[3]; p.delta_t = prm9[4];
   for (int k = 0; k < 4; ++k) p.w[k] = prm9[5 + k];
+  p.derive();
   Map3D m{};
   m.data = field; m.nx = nx; m.ny = ny; m.nz = nz; m.layout = 0; m.res = res;
   m.ox = origin[0]; m.oy = origin[1]; m.oz = origin[2];
