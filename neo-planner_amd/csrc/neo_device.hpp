@@ -395,23 +395,21 @@ struct Lookup3D {
   const Map3D &m;
   __amdgpu_buffer_rsrc_t rsrc;
   // fp32 arithmetic: cell coordinate minus one half in ONE fma, um = pos * inv + off (all wave-uniform operands)
-  float inv, off[3], mid[3], half[3], top[3];
+  float inv, off[3], hi[3];
   __device__ __forceinline__ explicit Lookup3D(const Map3D &m_)
       : m(m_), rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(m_.data), 0, (int)m_.bytes, 0x00020000)) {
     inv = (float)(1.0 / m_.res);
     off[0] = (float)(-m_.ox / m_.res - 0.5);
     off[1] = (float)(-m_.oy / m_.res - 0.5);
     off[2] = (float)(-m_.oz / m_.res - 0.5);
-    const int nn[3] = {m_.nx, m_.ny, m_.nz};
-    // (the constants are the same in every lane but come out of vector conversions: v_readfirstlane puts them in
-    // scalar registers, of which each instruction below can name one, instead of twelve vector registers held across the
-    // optimiser loop -- the three-waves-per-SIMD kernels have none to spare)
+    hi[0] = (float)m_.nx - 0.5f;
+    hi[1] = (float)m_.ny - 0.5f;
+    hi[2] = (float)m_.nz - 0.5f;
+    // (the same in every lane, but out of vector conversions: v_readfirstlane moves them to scalar registers)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       off[k] = uniform(off[k]);
-      mid[k] = uniform(0.5f * (float)nn[k] - 0.5f);  // centre and half width of [-0.5, n - 0.5)
-      half[k] = uniform(0.5f * (float)nn[k]);
-      top[k] = uniform(__uint_as_float(__float_as_uint((float)(nn[k] - 1)) - 1u));  // the float just below n - 1
+      hi[k] = uniform(hi[k]);
     }
   }
   struct Addr {
@@ -434,26 +432,16 @@ struct Lookup3D {
     Addr a;
     a.inside = on;
     if constexpr (sizeof(Real) == 4) {
-      // fp32: 7 instructions an axis.  The cell coordinate is clamped into [0, n - 1) first (v_med3_f32; `top` is the largest
-      // float below n - 1), so that truncation is the floor and the base corner needs no integer clamps; the fraction is
-      // what is left -- 0 in the half cell below the first voxel centre, one float spacing of n - 1 short of 1 in the
-      // half cell above the last.  Inside <=> -0.5 <= um < n - 0.5 <=> |um - mid| < half (the closed lower end differs from the open one on
-      // a set of measure zero; the fp64 parity path below keeps the oracle's comparisons).
+      // (measured and rejected: clamping the cell coordinate with v_med3_f32 before truncating -- 7 instructions an axis
+      // instead of 10, but nine more wave-uniform float constants, of which an instruction can name only one as a
+      // scalar operand; the integer clamps below take theirs from scalar registers: 1.22 M against 1.25 M traj/s at cfg2)
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const float um = fmaf(pos[k], inv, off[k]);
-#if defined(NEO_T1)
-        if (!(um >= -0.5f && um < (float)n[k] - 0.5f)) a.inside = false;
+        if (!(um >= -0.5f && um < hi[k])) a.inside = false;
         const int i = min(max((int)floorf(um), 0), n[k] - 2);
         a.i0[k] = i;
         a.fr[k] = __builtin_amdgcn_fmed3f(um - (float)i, 0.0f, 1.0f);
-#else
-        if (!(fabsf(um - mid[k]) < half[k])) a.inside = false;
-        const float tc = __builtin_amdgcn_fmed3f(um, 0.0f, top[k]);
-        const int i = (int)tc;
-        a.i0[k] = i;
-        a.fr[k] = tc - (float)i;
-#endif
       }
       if (!a.inside) a.i0[0] = a.i0[1] = a.i0[2] = 0;
       return a;
@@ -1530,17 +1518,7 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
     for (int u = 0; u < U; ++u) {
       const int j = r + (it0 + u) * L;
       on[u] = j < ns;
-      // beta_full row j: t = j * delta_t (:251); fp32 sampling forms the product in fp32 (two instructions instead of
-      // three with two fp64 ones: the result differs from the rounded fp64 product by at most one unit in the last place)
-      Real s;
-#if defined(NEO_T2)
-      if constexpr (false)
-#else
-      if constexpr (sizeof(Real) == 4)
-#endif
-        s = (float)j * dt;
-      else
-        s = (Real)((double)j * prm.delta_t);
+      const Real s = (Real)((double)j * prm.delta_t);  // beta_full row j: t = j * delta_t (:251)
       sv[u] = s;
       Real pos[D];
       if constexpr (kVelLate) {
