@@ -798,6 +798,7 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
   HIPCHK(c, hipStreamSynchronize(c->stream));
   e.data = field.release();
   e.m3 = Map3D{e.data, nx, ny, nz, layout, res, origin[0], origin[1], origin[2], (unsigned int)((nstore + 64) * dsz)};
+  e.m3.derive();
   c->maps[scene_id] = e;
   c->table_dirty = true;
   return NEO_OK;

@@ -91,6 +91,20 @@ struct Map3D {
                // 2 = cell-packed (8 corners of every cell contiguous)
   double res, ox, oy, oz;
   unsigned int bytes;  // size of the stored field (buffer-descriptor range)
+  // fp32 constants of the lookup (Lookup3D), derived on the host: cell coordinate minus one half = pos * f_inv + f_off,
+  // inside <=> -0.5 <= that < f_hi.  Computed in the kernel they are fp64 divisions whose results the compiler hoists
+  // out of the optimiser loop and keeps in vector registers (spilled at three wavefronts per SIMD); as part of the
+  // map record they arrive in scalar registers.
+  float f_inv, f_off[3], f_hi[3];
+  __host__ __device__ void derive() {
+    f_inv = (float)(1.0 / res);
+    f_off[0] = (float)(-ox / res - 0.5);
+    f_off[1] = (float)(-oy / res - 0.5);
+    f_off[2] = (float)(-oz / res - 0.5);
+    f_hi[0] = (float)nx - 0.5f;
+    f_hi[1] = (float)ny - 0.5f;
+    f_hi[2] = (float)nz - 0.5f;
+  }
 };
 
 // ------------------------------------------------------------------ wave helpers
@@ -125,6 +139,12 @@ __device__ __forceinline__ double uniform(double v) {
   int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
   int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
   return __hiloint2double(hi, lo);
+}
+// the value, hidden from loop-invariant code motion and common-subexpression elimination: what is computed from it is
+// computed where it is written (no instruction; used where a hoisted address costs a register across a whole loop)
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
 }
 __device__ __forceinline__ float uniform(float v) {
   return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
@@ -398,18 +418,11 @@ struct Lookup3D {
   float inv, off[3], hi[3];
   __device__ __forceinline__ explicit Lookup3D(const Map3D &m_)
       : m(m_), rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(m_.data), 0, (int)m_.bytes, 0x00020000)) {
-    inv = (float)(1.0 / m_.res);
-    off[0] = (float)(-m_.ox / m_.res - 0.5);
-    off[1] = (float)(-m_.oy / m_.res - 0.5);
-    off[2] = (float)(-m_.oz / m_.res - 0.5);
-    hi[0] = (float)m_.nx - 0.5f;
-    hi[1] = (float)m_.ny - 0.5f;
-    hi[2] = (float)m_.nz - 0.5f;
-    // (the same in every lane, but out of vector conversions: v_readfirstlane moves them to scalar registers)
+    inv = m_.f_inv;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      off[k] = uniform(off[k]);
-      hi[k] = uniform(hi[k]);
+      off[k] = m_.f_off[k];
+      hi[k] = m_.f_hi[k];
     }
   }
   struct Addr {

@@ -220,7 +220,9 @@ struct DevBackend {
 
   // FLAT x -> PIECE inputs
   __device__ __forceinline__ void scatter_x(const Vec &x) {
-    const int lane = lane_id();
+    // (opaque: the LDS addresses below are loop invariant -- hoisted out of the optimiser loop they become nine registers
+    // that live across everything and are spilled; formed here they cost one instruction each)
+    const int lane = opaque(lane_id());
     lds_wave_sync();
     Num *xn = reinterpret_cast<Num *>(xs);  // (the staging holds Num values)
 #pragma unroll
@@ -228,7 +230,7 @@ struct DevBackend {
       if (in_range(k, lane)) xn[k * kWave + lane] = x.v[k];
     lds_wave_sync();
     const int M = t.M;
-    const int p = LG::piece();
+    const int p = opaque(LG::piece());
     const bool act = p < M;
     t.tau = act ? xn[t.nq + p] : Num(0);
 #pragma unroll
@@ -310,16 +312,17 @@ struct DevBackend {
     Num gq[DL], gtau;
     const int bst = minco_backward<D, LG, Num, kPcr>(t, prm, gC, gT, gq, gtau);
     if (bst != 0) return bst;
-    // PIECE -> FLAT
+    // PIECE -> FLAT (addresses formed here, as in scatter_x)
     lds_wave_sync();
-    if (p >= 1 && p < t.M) {
+    const int pg = opaque(p), lg = opaque(lane);
+    if (pg >= 1 && pg < t.M) {
 #pragma unroll
-      for (int d = 0; d < DL; ++d) xn[(LG::dim0() + d) * (t.M - 1) + p - 1] = gq[d];
+      for (int d = 0; d < DL; ++d) xn[(LG::dim0() + d) * (t.M - 1) + pg - 1] = gq[d];
     }
-    if (p < t.M && LG::dim0() == 0) xn[t.nq + p] = gtau;
+    if (pg < t.M && LG::dim0() == 0) xn[t.nq + pg] = gtau;
     lds_wave_sync();
 #pragma unroll
-    for (int k = 0; k < NS; ++k) g.v[k] = in_range(k, lane) ? xn[k * kWave + lane] : Num(0);
+    for (int k = 0; k < NS; ++k) g.v[k] = in_range(k, lg) ? xn[k * kWave + lg] : Num(0);
 #ifdef NEO_STAMPS
     const long long s3 = wall_clock64();
     tk[0] += s1 - s0;

@@ -306,6 +306,7 @@ extern "C" double probe_run(int variant, int B, int M, const double *prm9 /* v_m
   m.data = field; m.nx = nx; m.ny = ny; m.nz = nz; m.layout = 0; m.res = res;
   m.ox = origin[0]; m.oy = origin[1]; m.oz = origin[2];
   m.bytes = (unsigned)((size_t)nx * ny * nz * 4 + 256);
+  m.derive();
   kern_t k = nullptr;
   switch (variant) {
     case 0: k = sample_v2<1, 4, false, false>; break;
