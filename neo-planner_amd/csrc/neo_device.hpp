@@ -140,6 +140,12 @@ __device__ __forceinline__ double uniform(double v) {
   int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+// position markers in the assembly listing (tools/probe/mark_counts.py prices the phases between them); no code
+#ifdef NEO_MARKS
+#define NEO_MARK(name) asm volatile("; NEOMARK " name)
+#else
+#define NEO_MARK(name)
+#endif
 // the value, hidden from loop-invariant code motion and common-subexpression elimination: what is computed from it is
 // computed where it is written (no instruction; used where a hoisted address costs a register across a whole loop)
 __device__ __forceinline__ int opaque(int v) {
@@ -1185,7 +1191,9 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
           Lo[i][j] = lane == 1 ? Num(0.0) : Lo[i][j];
           Up[i][j] = lane == t.M - 1 ? Num(0.0) : Up[i][j];
         }
+      NEO_MARK("fwd_pcr_begin");
       pcr_solve<DL, LG, Num>(t.M, Lo, Di, Up, R, y);
+      NEO_MARK("fwd_pcr_end");
     } else {
       thomas_solve<DL, LG, Num>((prm.dbg & (2 | 16)) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);
     }
@@ -1517,6 +1525,7 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
 
   // U samples per lane are prepared together and their gathers issued back to back before any of
   // them is consumed
+  NEO_MARK("loop_begin");
   for (int it0 = 0; it0 < iters; it0 += U) {
     Real sv[U], vel[U][D];
     typename LookupT::Addr ad[U];
@@ -1575,6 +1584,7 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
       }
     }
   }
+  NEO_MARK("loop_end");
   // (fp32 sampling only: the fp64 parity mode keeps the summation order below, the one its runs were pinned to the
   //  reference's recorded iterates with)
   if constexpr (sizeof(Real) == 4) {
@@ -1761,7 +1771,9 @@ __device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D), Num> &t, 
         R[0][d] = S[1][d];
         R[1][d] = S[2][d];
       }
+      NEO_MARK("bwd_pcr_begin");
       pcr_solve<DL, LG, Num>(M, LoT, DiT, UpT, R, y);
+      NEO_MARK("bwd_pcr_end");
 #pragma unroll
       for (int d = 0; d < DL; ++d) {
         lam[0][d] = (lane >= 1 && lane < M) ? y[0][d] : Num(0.0);

@@ -248,10 +248,13 @@ struct DevBackend {
 #ifdef NEO_STAMPS
     const long long s0 = wall_clock64();
 #endif
+    NEO_MARK("eval_begin");
     scatter_x(x);
+    NEO_MARK("scatter_done");
     Num *xn = reinterpret_cast<Num *>(xs);
     double energy, tsum;
     const int st = minco_forward<D, LG, Num, kPcr>(t, prm, energy, tsum);
+    NEO_MARK("forward_done");
 #ifdef NEO_STAMPS
     const long long s1 = wall_clock64();
 #endif
@@ -292,7 +295,9 @@ struct DevBackend {
       // the assignment wants the sample count of piece l in lane l
       int ns_by_piece = t.ns;
       if constexpr (LG::S > 1) ns_by_piece = __shfl(t.ns, min(LG::S * lane, kWave - 1), kWave);
+      NEO_MARK("assign_begin");
       const SampleLanes sl = balanced_sample_lanes(t.M, ns_by_piece, reinterpret_cast<int *>(xs));
+      NEO_MARK("assign_done");
       minco_sample<Real, D, LookupT, SU, false, LG>(t.M, sl, t.ns, cr, prm, lk, gCr, gTr, cf, ck,
                                                     fold_rows ? reinterpret_cast<Real *>(xs) : nullptr);
 #pragma unroll
@@ -310,7 +315,9 @@ struct DevBackend {
     costs[3] = uniform(ck);
     f = uniform(costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3]);
     Num gq[DL], gtau;
+    NEO_MARK("sample_done");
     const int bst = minco_backward<D, LG, Num, kPcr>(t, prm, gC, gT, gq, gtau);
+    NEO_MARK("backward_done");
     if (bst != 0) return bst;
     // PIECE -> FLAT (addresses formed here, as in scatter_x)
     lds_wave_sync();
@@ -323,6 +330,7 @@ struct DevBackend {
     lds_wave_sync();
 #pragma unroll
     for (int k = 0; k < NS; ++k) g.v[k] = in_range(k, lg) ? xn[k * kWave + lg] : Num(0);
+    NEO_MARK("gather_done");
 #ifdef NEO_STAMPS
     const long long s3 = wall_clock64();
     tk[0] += s1 - s0;

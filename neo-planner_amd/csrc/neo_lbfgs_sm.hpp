@@ -19,6 +19,9 @@
 #ifndef NEO_SM_STAMP  // timing experiments only (NEO_STAMPS builds of the device kernels define it)
 #define NEO_SM_STAMP(i)
 #endif
+#ifndef NEO_MARK
+#define NEO_MARK(name)
+#endif
 
 namespace neo {
 
@@ -67,6 +70,7 @@ struct LbfgsMachine {
 
   // after be.eval(x, f, g, costs()) returned `est`
   NEO_HD void advance(int est) {
+    NEO_MARK("advance_begin");
     const double epsmch = 2.220446049250313e-16;
     const double big = 1.0e10;
     int next;
@@ -100,8 +104,10 @@ struct LbfgsMachine {
       if (next == DO_START_ITER) {
         // ---- search direction
         NEO_SM_STAMP(0);
+        NEO_MARK("dir_begin");
         lbfgs_direction(be, g, d, tmp, tmp2, col, head, o.m, theta);
         NEO_SM_STAMP(1);
+        NEO_MARK("dir_end");
         // ---- line search set-up (lnsrlb)
         be.copy(t, x);
         be.copy(r, g);
@@ -129,7 +135,9 @@ struct LbfgsMachine {
       } else if (next == DO_LS_CONT) {
         next = DO_RETURN;
         for (;;) {
+          NEO_MARK("dcsrch_begin");
           task = dcsrch(be.ls(), f, gd, stp, task);
+          NEO_MARK("dcsrch_end");
           stp = be.uni(stp);
           if (task == LS_CONVERGENCE || task == LS_WARNING) {
             next = DO_SUCCESS;
@@ -161,6 +169,7 @@ struct LbfgsMachine {
         theta = 1.0;
         next = DO_START_ITER;  // RESTART_FROM_LNSRCH: same iteration, steepest descent, stp = 1
       } else {  // DO_SUCCESS: NEW_X
+        NEO_MARK("newx_begin");
         iter++;
         nit++;
         for (int k = 0; k < 4; ++k) cur()[k] = costs()[k];
@@ -195,6 +204,7 @@ struct LbfgsMachine {
         be.hist_put(slot, d, r);
         be.sput(slot, 1.0 / dr);
         theta = be.uni(rr / dr);
+        NEO_MARK("newx_end");
       }
     }
   }
