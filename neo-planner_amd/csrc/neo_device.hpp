@@ -817,7 +817,7 @@ struct Traj {
   int ns;                         // samples of this piece: int(T / delta_t)
   Num N[2][2];                 // pivot-block inverse of the joint system (lane = joint)
   const double *head, *tail;      // boundary states [3][D] in global memory (wave-uniform scalar loads)
-  const Num *bnd;                 // lane = (piece, dimension): head [3][D] then tail [3][D] in LDS (stage_boundary)
+  const Num *bnd;                 // lane = (piece, dimension) and lane groups: head [3][D] then tail [3][D] in LDS
 };
 
 // element (row k, dimension of this lane's local index dl) of the head (TAIL = false) or tail boundary state: a uniform
@@ -827,10 +827,10 @@ struct Traj {
 // loads queue behind the other wavefronts' field gathers -- measured 1.06 M -> 1.20 M traj/s at cfg2 without them.
 template <int D, class LG, bool TAIL, int DL, typename Num>
 __device__ __forceinline__ Num bstate(const Traj<D, DL, Num> &t, int k, int dl) {
-  if constexpr (LG::S == 1)
+  if constexpr (LG::S == 1 && LG::W == kWave)
     return (Num)(TAIL ? t.tail : t.head)[k * D + dl];
-  else
-    return t.bnd[((TAIL ? 3 : 0) + k) * D + LG::dim0()];
+  else  // (lane groups: every group has its own trajectory, so the pointers differ by lane and the loads would be vector loads)
+    return t.bnd[((TAIL ? 3 : 0) + k) * D + (LG::S > 1 ? LG::dim0() : dl)];
 }
 // lds: 6 * D elements of the wavefront's own
 template <int D, class LG, int DL, typename Num>

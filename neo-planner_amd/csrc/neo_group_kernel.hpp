@@ -112,8 +112,8 @@ struct GroupBackend {
     t.tau = act ? xn[t.nq + lane] : Num(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      t.P0[d] = (lane == 0 || !act) ? (Num)t.head[d] : xn[d * (M - 1) + (lane > 0 ? lane - 1 : 0)];
-      t.P1[d] = (lane >= M - 1) ? (Num)t.tail[d] : xn[d * (M - 1) + lane];
+      t.P0[d] = (lane == 0 || !act) ? bstate<D, GroupLanes<W>, false>(t, 0, d) : xn[d * (M - 1) + (lane > 0 ? lane - 1 : 0)];
+      t.P1[d] = (lane >= M - 1) ? bstate<D, GroupLanes<W>, true>(t, 0, d) : xn[d * (M - 1) + lane];
     }
     double energy = 0.0, tsum = 0.0;
     const int st = minco_forward<D, GroupLanes<W>, Num>(t, prm, energy, tsum);
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(kWave, (sizeof(Num) == 4 ? NEO_GRP_OCC_F32 : NEO_GR
   __shared__ double sc[G][2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm[G];
   __shared__ double cst[G][12];
+  __shared__ Num bnd[G][6 * D];  // boundary states of each group's trajectory, copied once when it is taken
   extern __shared__ double dyn_lds[];  // G * 2 * maxcor * n doubles
   using BE = GroupBackend<D, W, NS, Real, MapT, LookupT, NEO_GRP_U, Num>;
   const MapT map = maps[0];
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(kWave, (sizeof(Num) == 4 ? NEO_GRP_OCC_F32 : NEO_GR
   be.t.nq = nq;
   be.t.n = n;
   be.t.L = GroupLanes<W>::lanes_per_piece(M);
+  be.t.bnd = bnd[g];
 
   LbfgsOpts o{prm.ftol, prm.gtol, prm.maxls, prm.maxiter, prm.maxfun, NEO_LBFGS_M};
   LbfgsMachine<BE> mach(be, o);
@@ -225,6 +227,12 @@ __global__ __launch_bounds__(kWave, (sizeof(Num) == 4 ? NEO_GRP_OCC_F32 : NEO_GR
     b = busy ? (order ? order[tk] : tk) : 0;
     be.t.head = head + (size_t)b * 3 * D;
     be.t.tail = tail + (size_t)b * 3 * D;
+    // (read through these pointers -- one per group, so vector loads -- the boundary states cost ~25 global loads an
+    //  evaluation, each queued behind the field gathers)
+    lds_wave_sync();
+    for (int e = gl; e < 6 * D; e += W)
+      bnd[g][e] = (Num)(e < 3 * D ? be.t.head[e] : be.t.tail[e - 3 * D]);
+    lds_wave_sync();
 #pragma unroll
     for (int k = 0; k < NS; ++k) mach.x.v[k] = (k * W + gl < n) ? x0[(size_t)b * n + k * W + gl] : 0.0;
     mach.begin();
