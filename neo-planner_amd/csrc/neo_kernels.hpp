@@ -73,6 +73,8 @@ struct DevBackend {
   // solve is fp64: the parity mode's recorded runs are pinned to its rounding, and in the mixed mode the reduction was
   // measured SLOWER (fp64: 744 k against 778 k traj/s at cfg2, 142 k against 156 k at cfg5 -- five levels of 63 fp64
   // instructions with ~60 live doubles spill where block Thomas does not)
+  // (measured again after the spills had gone: in the lane = (piece, dimension) kernel the fp64 reduction fits the
+  // registers -- 251 of 256, no spills -- and changes nothing: 774 k traj/s either way)
   static constexpr bool kPcr = sizeof(Num) == 4 && LG::W == kWave;
   // FLAT layout with NS slots: n <= 64 * NS
   struct Vec {
