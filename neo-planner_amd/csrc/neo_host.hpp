@@ -54,6 +54,10 @@ struct neo_ctx {
   // scratch for the host-pointer entry points
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
+  // pinned mirror of the scratch layout of neo_optimize_batch: ONE copy in and ONE copy out per call instead of four
+  // and six from pageable memory (each of those stages through the runtime and waits)
+  void *pinned = nullptr;
+  size_t pinned_bytes = 0;
   bool profile = false;
   neo::ProfileSlot prof[NEO_KERNEL_COUNT];
   long long *sample_counter = nullptr;  // optional device array [B] (neo_optimize_sample_counter)
