@@ -1181,15 +1181,40 @@ int neo_eval_traj_batch(neo_ctx *c, int B, int M, int D, const double *x, const 
   std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   const size_t n = (size_t)D * (M - 1) + M, bs = (size_t)B;
-  rc = ensure_scratch(c, bs * (n + 6 * D + (size_t)K * 3 * D) * sizeof(double) + bs * sizeof(int) + 6 * 256);
+  // scratch layout [x | head | tail | state | count]; small calls through the pinned mirror (one copy each way, as in
+  // neo_optimize_batch)
+  size_t o_x, o_h, o_t, o_s, o_c, o_end;
+  {
+    Carver lay(nullptr);
+    auto at = [&](size_t bytes) { lay.take<char>(0); const size_t o = lay.off; lay.off += bytes; return o; };
+    o_x = at(bs * n * sizeof(double));
+    o_h = at(bs * 3 * D * sizeof(double));
+    o_t = at(bs * 3 * D * sizeof(double));
+    o_s = at(bs * K * 3 * D * sizeof(double));
+    o_c = at(bs * sizeof(int));
+    o_end = lay.off;
+  }
+  const bool staged = o_end <= (size_t)256 * 1024;
+  rc = ensure_scratch(c, o_end + 256);
   if (rc) return rc;
-  Carver cv(c->scratch);
-  double *dx = cv.take<double>(bs * n), *dh = cv.take<double>(bs * 3 * D), *dt = cv.take<double>(bs * 3 * D);
-  double *ds = cv.take<double>(bs * K * 3 * D);
-  int *dcnt = cv.take<int>(bs);
-  HIPCHK(c, hipMemcpyAsync(dx, x, bs * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(dh, head, bs * 3 * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(dt, tail, bs * 3 * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (staged) {
+    rc = ensure_pinned(c, o_end + 256);
+    if (rc) return rc;
+  }
+  char *dbase = static_cast<char *>(c->scratch), *hbase = static_cast<char *>(c->pinned);
+  double *dx = reinterpret_cast<double *>(dbase + o_x), *dh = reinterpret_cast<double *>(dbase + o_h);
+  double *dt = reinterpret_cast<double *>(dbase + o_t), *ds = reinterpret_cast<double *>(dbase + o_s);
+  int *dcnt = reinterpret_cast<int *>(dbase + o_c);
+  if (staged) {
+    std::memcpy(hbase + o_x, x, bs * n * sizeof(double));
+    std::memcpy(hbase + o_h, head, bs * 3 * D * sizeof(double));
+    std::memcpy(hbase + o_t, tail, bs * 3 * D * sizeof(double));
+    HIPCHK(c, hipMemcpyAsync(dbase + o_x, hbase + o_x, o_s - o_x, hipMemcpyHostToDevice, c->stream));
+  } else {
+    HIPCHK(c, hipMemcpyAsync(dx, x, bs * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dh, head, bs * 3 * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dt, tail, bs * 3 * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
   if (D == 2)
     hipLaunchKernelGGL((traj_state_kernel<2>), dim3(B), dim3(kWave), 0, c->stream, B, M, c->dev, dx, dh, dt, hz, K, ds,
                        dcnt);
@@ -1197,6 +1222,13 @@ int neo_eval_traj_batch(neo_ctx *c, int B, int M, int D, const double *x, const 
     hipLaunchKernelGGL((traj_state_kernel<3>), dim3(B), dim3(kWave), 0, c->stream, B, M, c->dev, dx, dh, dt, hz, K, ds,
                        dcnt);
   HIPCHK(c, hipGetLastError());
+  if (staged) {
+    HIPCHK(c, hipMemcpyAsync(hbase + o_s, dbase + o_s, o_end - o_s, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(state, hbase + o_s, bs * K * 3 * D * sizeof(double));
+    std::memcpy(count, hbase + o_c, bs * sizeof(int));
+    return NEO_OK;
+  }
   HIPCHK(c, hipMemcpyAsync(state, ds, bs * K * 3 * D * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(count, dcnt, bs * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
