@@ -979,30 +979,68 @@ int neo_cost_grad_batch(neo_ctx *c, int scene_id, int B, int M, int D, const dou
   if (B == 0) return NEO_OK;
   std::lock_guard<std::recursive_mutex> whole_call(c->mu);  // scratch buffers stay ours until the copies back are done
   const size_t n = (size_t)D * (M - 1) + M, bs = (size_t)B;
+  // scratch layout [x | head | tail | cost | costs4 | grad | coeffs | status]; small calls (get_cost / get_grad of one
+  // trajectory) through the pinned mirror: one copy each way, as in neo_optimize_batch
+  size_t o_x, o_h, o_t, o_c, o_c4, o_g, o_co, o_st, o_end;
+  {
+    Carver lay(nullptr);
+    auto at = [&](size_t bytes) { lay.take<char>(0); const size_t o = lay.off; lay.off += bytes; return o; };
+    o_x = at(bs * n * sizeof(double));
+    o_h = at(bs * 3 * D * sizeof(double));
+    o_t = at(bs * 3 * D * sizeof(double));
+    o_c = at(bs * sizeof(double));
+    o_c4 = at(bs * 4 * sizeof(double));
+    o_g = at(bs * n * sizeof(double));
+    o_co = at(bs * 6 * M * D * sizeof(double));
+    o_st = at(bs * sizeof(int));
+    o_end = lay.off;
+  }
+  const bool staged = o_end <= (size_t)256 * 1024;
   double *dx, *dh, *dt, *dc, *dc4, *dg, *dco;
   int *dst;
   {
     std::lock_guard<std::recursive_mutex> g(c->mu);
     hipSetDevice(c->device);
-    const size_t bytes = bs * (2 * n + 6 * D + 5 + 6 * M * D) * sizeof(double) + bs * sizeof(int) + 8 * 256;
-    rc = ensure_scratch(c, bytes);
+    rc = ensure_scratch(c, o_end + 256);
     if (rc) return rc;
-    Carver cv(c->scratch);
-    dx = cv.take<double>(bs * n);
-    dh = cv.take<double>(bs * 3 * D);
-    dt = cv.take<double>(bs * 3 * D);
-    dc = cv.take<double>(bs);
-    dc4 = cv.take<double>(bs * 4);
-    dg = cv.take<double>(bs * n);
-    dco = cv.take<double>(bs * 6 * M * D);
-    dst = cv.take<int>(bs);
-    HIPCHK(c, hipMemcpyAsync(dx, x, bs * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(dh, head, bs * 3 * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(dt, tail, bs * 3 * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (staged) {
+      rc = ensure_pinned(c, o_end + 256);
+      if (rc) return rc;
+    }
+    char *dbase = static_cast<char *>(c->scratch), *hbase = static_cast<char *>(c->pinned);
+    dx = reinterpret_cast<double *>(dbase + o_x);
+    dh = reinterpret_cast<double *>(dbase + o_h);
+    dt = reinterpret_cast<double *>(dbase + o_t);
+    dc = reinterpret_cast<double *>(dbase + o_c);
+    dc4 = reinterpret_cast<double *>(dbase + o_c4);
+    dg = reinterpret_cast<double *>(dbase + o_g);
+    dco = reinterpret_cast<double *>(dbase + o_co);
+    dst = reinterpret_cast<int *>(dbase + o_st);
+    if (staged) {
+      std::memcpy(hbase + o_x, x, bs * n * sizeof(double));
+      std::memcpy(hbase + o_h, head, bs * 3 * D * sizeof(double));
+      std::memcpy(hbase + o_t, tail, bs * 3 * D * sizeof(double));
+      HIPCHK(c, hipMemcpyAsync(dbase + o_x, hbase + o_x, o_c - o_x, hipMemcpyHostToDevice, c->stream));
+    } else {
+      HIPCHK(c, hipMemcpyAsync(dx, x, bs * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(dh, head, bs * 3 * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(dt, tail, bs * 3 * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
   }
   rc = neo_cost_grad_batch_dev(c, scene_id, B, M, D, dx, dh, dt, dc, dc4, dg, coeffs ? dco : nullptr, dst);
   if (rc) return rc;
   std::lock_guard<std::recursive_mutex> g(c->mu);
+  if (staged) {
+    char *dbase = static_cast<char *>(c->scratch), *hbase = static_cast<char *>(c->pinned);
+    HIPCHK(c, hipMemcpyAsync(hbase + o_c, dbase + o_c, o_end - o_c, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(cost, hbase + o_c, bs * sizeof(double));
+    std::memcpy(costs4, hbase + o_c4, bs * 4 * sizeof(double));
+    std::memcpy(grad, hbase + o_g, bs * n * sizeof(double));
+    if (coeffs) std::memcpy(coeffs, hbase + o_co, bs * 6 * M * D * sizeof(double));
+    if (status) std::memcpy(status, hbase + o_st, bs * sizeof(int));
+    return NEO_OK;
+  }
   HIPCHK(c, hipMemcpyAsync(cost, dc, bs * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(costs4, dc4, bs * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(grad, dg, bs * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
