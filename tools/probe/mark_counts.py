@@ -12,7 +12,7 @@ compiler moved away from their source position are counted where they landed."""
 import re, sys
 src, pat = sys.argv[1], re.compile(sys.argv[2])
 lines = open(src).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3neo15optimize_kernel") and ":" in l and pat.search(l))
+start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3neo") and "optimize" in l and ":" in l and pat.search(l))
 region, depth, in_label = "prologue", 0, False
 order, acc = [], {}
 for l in lines[start + 1:]:
