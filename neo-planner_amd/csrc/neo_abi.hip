@@ -547,6 +547,10 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
     // small planar problems on the reference's own map (M = 3 -> n = 7): eight replans per wavefront, opt-in
     if ((c->params.flags & NEO_FLAG_LANE_GROUPS) && D == 2 && !a.slots && a.M <= 16 && D * (a.M - 1) + a.M <= 32)
       return launch_opt_groups_2d(c, f32, a);
+    const int fl2 = c->params.flags;
+    if (D == 2 && slots_for(a.M, D) <= 2 &&
+        ((a.B >= kTwoWavesFromBatch && !(fl2 & NEO_FLAG_ONE_WAVE_PER_SIMD)) || (fl2 & NEO_FLAG_TWO_WAVES_PER_SIMD)))
+      return launch_opt_2d_w2(c, f32, a);
     return launch_opt_2d(c, D, f32, a);
   }
   if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");

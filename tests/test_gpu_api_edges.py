@@ -274,6 +274,22 @@ def test_one_and_two_waves_per_simd_agree_bit_for_bit():
         assert out[0]["nfev"].mean() > 10
 
 
+def test_one_and_two_waves_per_simd_agree_bit_for_bit_on_the_reference_map(scene):
+    """the same for the reference's own shape in batches: D = 2 on the nearest-cell map, fp64 and fp32 sampling (from 4096
+    trajectories per call on the library takes the two-waves allocation by itself)"""
+    _, m, _ = scene
+    for M, B in ((3, 200), (5, 128), (21, 64)):
+        head, tail, wp, ts = synth.replan_requests(31, B, M - 1, D=2, length_range=(4.0, 9.0), jitter=0.3)
+        for dtype in ("f64", "f32"):
+            out = []
+            for waves in (1, 2):
+                bp = npa.BatchPlanner(sample_dtype=dtype, waves_per_simd=waves)
+                out.append(bp.optimize(m, bp.pack_x(wp, ts), head, tail))
+            for k in ("x", "costs", "costs_last", "nit", "nfev", "status"):
+                assert np.array_equal(out[0][k], out[1][k]), (M, dtype, k)
+            assert out[0]["nfev"].mean() > 8
+
+
 def test_two_waves_with_four_slots_store_the_pairs_in_fp32():
     """n > 128 (cfg5's M = 41): the two-waves variant keeps the L-BFGS pairs in fp32 (LDS for eight wavefronts per CU).
     That is a perturbation at the 1e-7 level of an optimiser whose gradient is fp32 already: runs part as any two
