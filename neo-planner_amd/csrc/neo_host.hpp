@@ -164,6 +164,7 @@ int launch_opt_3d_f64(neo_ctx *c, int elem, int layout, const OptArgs &a);  // n
 int launch_opt_3d_w2(neo_ctx *c, int elem, int layout, const OptArgs &a);   // neo_disp_opt3d_w2.hip
 int launch_opt_3d_x(neo_ctx *c, int elem, int layout, const OptArgs &a);    // neo_disp_opt3d_x.hip
 int launch_opt_groups(neo_ctx *c, int elem, int layout, const OptArgs &a);  // neo_disp_group.hip
+int launch_opt_3d_f64_w2(neo_ctx *c, int elem, int layout, const OptArgs &a);
 int launch_opt_2d_w2(neo_ctx *c, bool f32, const OptArgs &a);
 int launch_opt_groups_2d(neo_ctx *c, bool f32, const OptArgs &a);           // neo_disp_group.hip (D = 2, nearest-cell map)
 

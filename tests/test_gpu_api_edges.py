@@ -265,13 +265,16 @@ def test_one_and_two_waves_per_simd_agree_bit_for_bit():
     # CU, both variants then fold in registers (neo_launch_opt.hpp)
     for M, B in ((5, 300), (21, 200), (31, 96)):
         head, tail, wp, ts = synth.replan_requests(2, B, M - 1, D=3)
-        out = []
-        for waves in (1, 2):
-            bp = npa.BatchPlanner(sample_dtype="f32", waves_per_simd=waves)
-            out.append(bp.optimize(g3, bp.pack_x(wp, ts), head, tail))
-        for k in ("x", "costs", "costs_last", "nit", "nfev", "status"):
-            assert np.array_equal(out[0][k], out[1][k]), (M, k)
-        assert out[0]["nfev"].mean() > 10
+        # ("f64": the parity mode has a two-waves allocation where the lane = (piece, dimension) layout applies, 3 M <= 64;
+        #  elsewhere the flag changes nothing)
+        for dtype in ("f32", "f64"):
+            out = []
+            for waves in (1, 2):
+                bp = npa.BatchPlanner(sample_dtype=dtype, waves_per_simd=waves)
+                out.append(bp.optimize(g3, bp.pack_x(wp, ts), head, tail))
+            for k in ("x", "costs", "costs_last", "nit", "nfev", "status"):
+                assert np.array_equal(out[0][k], out[1][k]), (M, dtype, k)
+            assert out[0]["nfev"].mean() > 10
 
 
 def test_one_and_two_waves_per_simd_agree_bit_for_bit_on_the_reference_map(scene):
