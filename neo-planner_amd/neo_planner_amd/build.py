@@ -45,7 +45,14 @@ def _newest_header():
 
 # per-unit compiler options: the all-fp32 optimiser kernels are allocated for three wavefronts per SIMD (168 registers);
 # LLVM's alternative register-pressure tracker spills fewer registers there (25 instead of 33; 19 without SLP)
-UNIT_FLAGS = {"neo_disp_opt3d_x.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"]}
+# The fp64 kernels in the two-wavefronts-per-SIMD allocation (256 registers): machine LICM hoists loop-invariant values --
+# the fp64 coefficients of exp(), LDS addresses -- out of the optimiser loop and the allocator then spills them (31
+# registers in the cfg2 parity kernel, reloaded one after the other at every evaluation); letting the sinking pass move
+# such instructions back into the loop leaves 7 and is worth 13 % (549 k -> 620 k traj/s; the all-fp32 kernels do not
+# care: 1.26 M either way).
+_SINK = ["-mllvm", "-sink-insts-to-avoid-spills"]
+UNIT_FLAGS = {"neo_disp_opt3d_x.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
+              "neo_disp_opt3d_f64.hip": _SINK, "neo_disp_opt3d_w2.hip": _SINK, "neo_disp_opt2d.hip": _SINK}
 
 
 def _compile(src, obj, verbose):
