@@ -1,5 +1,8 @@
+"""Latency of the reference-shaped callbacks get_cost(x) / get_grad(x) (expert_planner.py:539-585) for one trajectory of
+M = 3 on the 2-D map: one neo_cost_grad_batch call each, through the pinned small-call path."""
 import os, sys, time, contextlib, io
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/neo-planner_amd")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "neo-planner_amd"))
 import numpy as np
 import neo_planner_amd as npa
 from neo_planner_amd import synth
