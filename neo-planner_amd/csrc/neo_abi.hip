@@ -564,9 +564,10 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
   const bool two = f32 && slots_for(a.M, D) <= NEO_W2_MAX_SLOTS &&
                    ((a.B >= kTwoWavesFromBatch && !(fl & NEO_FLAG_ONE_WAVE_PER_SIMD)) || (fl & NEO_FLAG_TWO_WAVES_PER_SIMD));
   if (two) return launch_opt_3d_w2(c, elem, layout, a);
-  // fp64 sampling (the parity mode): the two-waves allocation spills, so only where the lane = (piece, dimension)
-  // layout keeps that small (n <= 128, 3 M <= 64) and the batch queues for the SIMDs
-  if (!f32 && slots_for(a.M, D) <= 2 && 3 * a.M <= kWave &&
+  // fp64 sampling (the parity mode): two wavefronts per SIMD for n <= 128 when the batch queues for the SIMDs (the
+  // unit is compiled so that these kernels spill 0 - 13 registers, build.py; cfg2 360 k -> 637 k traj/s, M = 25 239 k
+  // -> 400 k, M = 32 162 k -> 241 k; four FLAT slots would spill 112)
+  if (!f32 && slots_for(a.M, D) <= 2 &&
       ((a.B >= kTwoWavesFromBatch && !(fl & NEO_FLAG_ONE_WAVE_PER_SIMD)) || (fl & NEO_FLAG_TWO_WAVES_PER_SIMD)))
     return launch_opt_3d_f64_w2(c, elem, layout, a);
   return f32 ? launch_opt_3d_f32(c, elem, layout, a) : launch_opt_3d_f64(c, elem, layout, a);

@@ -265,8 +265,7 @@ def test_one_and_two_waves_per_simd_agree_bit_for_bit():
     # CU, both variants then fold in registers (neo_launch_opt.hpp)
     for M, B in ((5, 300), (21, 200), (31, 96)):
         head, tail, wp, ts = synth.replan_requests(2, B, M - 1, D=3)
-        # ("f64": the parity mode has a two-waves allocation where the lane = (piece, dimension) layout applies, 3 M <= 64;
-        #  elsewhere the flag changes nothing)
+        # ("f64": the parity mode has a two-waves allocation too, for n <= 128 variables)
         for dtype in ("f32", "f64"):
             out = []
             for waves in (1, 2):
