@@ -489,10 +489,14 @@ def main():
             torch.cuda.synchronize(); tb_.append(time.perf_counter() - t1_)
             ctx.lib.neo_esdf_drop(ctx.h, tmp_.scene_id)
         nv_ = a.grid ** 3
+        # EDT: 1 B occupancy in, 2 B row distances out and in, 4 B plane distances out and in, 4 B fp32 distance out = 17 B
+        # (+ 4 B the packing pass reads back); packing writes 1 (linear), 4 (yz4) or 8 (cell8) stored elements per voxel
+        elems_ = {"linear": 1, "yz4": 4, "cell8": 8}[a.layout]
+        bpv_ = 17 + 4 + elems_ * (4 if store == "f32" else 2)
         esdf_build = {"what": "neo_esdf_build_3d: exact EDT of the occupancy grid (three separable integer passes) + layout "
                               "packing, device to device, wall time of the whole call (allocations included)",
-                      "voxels": nv_, "ms": 1e3 * min(tb_), "algorithmic_bytes_per_voxel": 21 + 2 * (4 if store == "f32" else 3),
-                      "GBps": nv_ * (21 + 2 * (4 if store == "f32" else 3)) / min(tb_) / 1e9}
+                      "voxels": nv_, "ms": 1e3 * min(tb_), "algorithmic_bytes_per_voxel": bpv_,
+                      "GBps": nv_ * bpv_ / min(tb_) / 1e9}
         del d_occ_
     slots = None
     scenes = [g3]
