@@ -205,6 +205,24 @@ __global__ __launch_bounds__(256) void edt3_line_kernel(const SrcT *__restrict__
   // (or the whole line).  While a level has fewer (point, column) items than the block has threads, G = 2 .. 8 threads
   // share an item -- contiguous parts of its range, combined through `part` (leftmost minimum wins: parts in order,
   // strict comparison) -- so that the coarse levels, few points with long ranges, do not run on a handful of threads.
+  // leftmost minimiser of f[q] + (p - q)^2 over a <= q <= b: four candidates' LDS reads in flight at a time, compared in
+  // order with a strict "<" (kSqInf + 4095^2 < 2^31)
+  auto scan = [&](int p, int xl, int a, int b, int &best, int &arg) {
+    int q = a;
+    for (; q + 3 <= b; q += 4) {
+      const int f0 = f[q * TX + xl], f1 = f[(q + 1) * TX + xl], f2 = f[(q + 2) * TX + xl], f3 = f[(q + 3) * TX + xl];
+      const int d0 = p - q, d1 = d0 - 1, d2 = d0 - 2, d3 = d0 - 3;
+      const int c0 = f0 + d0 * d0, c1 = f1 + d1 * d1, c2 = f2 + d2 * d2, c3 = f3 + d3 * d3;
+      if (c0 < best) { best = c0; arg = q; }
+      if (c1 < best) { best = c1; arg = q + 1; }
+      if (c2 < best) { best = c2; arg = q + 2; }
+      if (c3 < best) { best = c3; arg = q + 3; }
+    }
+    for (; q <= b; ++q) {
+      const int dq = p - q, c = f[q * TX + xl] + dq * dq;
+      if (c < best) { best = c; arg = q; }
+    }
+  };
   __shared__ int part_best[256];
   __shared__ int part_arg[256];
   auto level = [&](int npts, int p0, int dp, int S) {
@@ -221,10 +239,7 @@ __global__ __launch_bounds__(256) void edt3_line_kernel(const SrcT *__restrict__
         const int lo = S ? am[(p - S) * TX + xl] : 0, hi = S ? am[min(p + S, nline - 1) * TX + xl] : nline - 1;
         const int chunk = (hi - lo + G) / G, a = lo + g * chunk, b = min(hi, a + chunk - 1);
         int best = 0x7fffffff, arg = lo;
-        for (int q = a; q <= b; ++q) {
-          const int dq = p - q, c = f[q * TX + xl] + dq * dq;  // (kSqInf + 4095^2 < 2^31)
-          if (c < best) { best = c; arg = q; }
-        }
+        scan(p, xl, a, b, best, arg);
         part_best[threadIdx.x] = best;
         part_arg[threadIdx.x] = arg;
       }
@@ -244,10 +259,7 @@ __global__ __launch_bounds__(256) void edt3_line_kernel(const SrcT *__restrict__
         p = min(p0 + k * dp, nline - 1);
         const int lo = S ? am[(p - S) * TX + xl] : 0, hi = S ? am[min(p + S, nline - 1) * TX + xl] : nline - 1;
         int best = 0x7fffffff, arg = lo;
-        for (int q = lo; q <= hi; ++q) {
-          const int dq = p - q, c = f[q * TX + xl] + dq * dq;
-          if (c < best) { best = c; arg = q; }
-        }
+        scan(p, xl, lo, hi, best, arg);
         am[p * TX + xl] = (uint16_t)arg;
       }
     }
