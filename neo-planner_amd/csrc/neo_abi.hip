@@ -545,6 +545,7 @@ int check_shape(neo_ctx *c, int B, int M, int D) {
 }
 
 
+constexpr int kTwoWavesFromBatchF64 = 1024;  // fp64 kernels (measured, one launch at a time: 1024 +4 %, 2048 +9 %, 3072 +23 %)
 constexpr int kTwoWavesFromBatch = 4096;  // 4 trajectories per SIMD of an MI355X (measured: 2048 -> one wave is
                                           // faster, 9.1 vs 10.1 ms; 4096 -> two are, 11.0 vs 13.6 ms)
 
@@ -561,7 +562,8 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
       return launch_opt_groups_2d(c, f32, a);
     const int fl2 = c->params.flags;
     if (D == 2 && slots_for(a.M, D) <= 2 &&
-        ((a.B >= kTwoWavesFromBatch && !(fl2 & NEO_FLAG_ONE_WAVE_PER_SIMD)) || (fl2 & NEO_FLAG_TWO_WAVES_PER_SIMD)))
+        ((a.B >= (f32 ? kTwoWavesFromBatch : kTwoWavesFromBatchF64) && !(fl2 & NEO_FLAG_ONE_WAVE_PER_SIMD)) ||
+         (fl2 & NEO_FLAG_TWO_WAVES_PER_SIMD)))
       return launch_opt_2d_w2(c, f32, a);
     return launch_opt_2d(c, D, f32, a);
   }
@@ -580,7 +582,7 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
   // unit is compiled so that these kernels spill 0 - 13 registers, build.py; cfg2 360 k -> 637 k traj/s, M = 25 239 k
   // -> 400 k, M = 32 162 k -> 241 k; four FLAT slots would spill 112)
   if (!f32 && slots_for(a.M, D) <= 2 &&
-      ((a.B >= kTwoWavesFromBatch && !(fl & NEO_FLAG_ONE_WAVE_PER_SIMD)) || (fl & NEO_FLAG_TWO_WAVES_PER_SIMD)))
+      ((a.B >= kTwoWavesFromBatchF64 && !(fl & NEO_FLAG_ONE_WAVE_PER_SIMD)) || (fl & NEO_FLAG_TWO_WAVES_PER_SIMD)))
     return launch_opt_3d_f64_w2(c, elem, layout, a);
   return f32 ? launch_opt_3d_f32(c, elem, layout, a) : launch_opt_3d_f64(c, elem, layout, a);
 }
