@@ -103,9 +103,10 @@ typedef struct neo_params {
 } neo_params;
 
 /* neo_params.flags.  The optimiser kernel exists in two register allocations with bit-identical results:
- * one wavefront per SIMD (shortest evaluation; default below 4096 trajectories per call) and two per SIMD
+ * one wavefront per SIMD (shortest evaluation; default below 1024 trajectories per call) and two per SIMD
  * (slower evaluations, higher throughput once the trajectories queue for the SIMDs: large calls, or several
- * calls in flight on several streams; 3-D fields with fp32 sampling and n <= 128 variables only). */
+ * calls in flight on several streams; n <= 128 variables in the fp64 mode and on the 2-D map with D = 2, n <= 256
+ * on 3-D fields with fp32 sampling). */
 #define NEO_FLAG_ONE_WAVE_PER_SIMD 32
 #define NEO_FLAG_TWO_WAVES_PER_SIMD 64
 /* small problems (n <= 32 variables, M <= 16, one scene: a 3-D field with fp32 sampling, or the 2-D nearest-cell map

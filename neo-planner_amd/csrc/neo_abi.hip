@@ -545,9 +545,11 @@ int check_shape(neo_ctx *c, int B, int M, int D) {
 }
 
 
-constexpr int kTwoWavesFromBatchF64 = 1024;  // fp64 kernels (measured, one launch at a time: 1024 +4 %, 2048 +9 %, 3072 +23 %)
-constexpr int kTwoWavesFromBatch = 4096;  // 4 trajectories per SIMD of an MI355X (measured: 2048 -> one wave is
-                                          // faster, 9.1 vs 10.1 ms; 4096 -> two are, 11.0 vs 13.6 ms)
+// From this batch size on the kernels take the two-wavefronts-per-SIMD register allocation (three in the all-fp32
+// mode, always).  Measured in round 3, one launch at a time, two waves against one: fp64 mode +4 % at 1024, +9 % at 2048,
+// +23 % at 3072 trajectories; mixed mode +2 %, +5 %, +23 % (round 2 had found one wave faster up to 2048: 9.1 against
+// 10.1 ms -- before the per-evaluation loads and the spills of the two-waves kernels were gone).
+constexpr int kTwoWavesFromBatch = 1024;
 
 int fail_locked(neo_ctx *c, int code, const char *msg) {
   std::lock_guard<std::recursive_mutex> g(c->mu);
@@ -562,7 +564,7 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
       return launch_opt_groups_2d(c, f32, a);
     const int fl2 = c->params.flags;
     if (D == 2 && slots_for(a.M, D) <= 2 &&
-        ((a.B >= (f32 ? kTwoWavesFromBatch : kTwoWavesFromBatchF64) && !(fl2 & NEO_FLAG_ONE_WAVE_PER_SIMD)) ||
+        ((a.B >= kTwoWavesFromBatch && !(fl2 & NEO_FLAG_ONE_WAVE_PER_SIMD)) ||
          (fl2 & NEO_FLAG_TWO_WAVES_PER_SIMD)))
       return launch_opt_2d_w2(c, f32, a);
     return launch_opt_2d(c, D, f32, a);
@@ -582,7 +584,7 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
   // unit is compiled so that these kernels spill 0 - 13 registers, build.py; cfg2 360 k -> 637 k traj/s, M = 25 239 k
   // -> 400 k, M = 32 162 k -> 241 k; four FLAT slots would spill 112)
   if (!f32 && slots_for(a.M, D) <= 2 &&
-      ((a.B >= kTwoWavesFromBatchF64 && !(fl & NEO_FLAG_ONE_WAVE_PER_SIMD)) || (fl & NEO_FLAG_TWO_WAVES_PER_SIMD)))
+      ((a.B >= kTwoWavesFromBatch && !(fl & NEO_FLAG_ONE_WAVE_PER_SIMD)) || (fl & NEO_FLAG_TWO_WAVES_PER_SIMD)))
     return launch_opt_3d_f64_w2(c, elem, layout, a);
   return f32 ? launch_opt_3d_f32(c, elem, layout, a) : launch_opt_3d_f64(c, elem, layout, a);
 }

@@ -277,7 +277,7 @@ def test_one_and_two_waves_per_simd_agree_bit_for_bit():
 
 
 def test_one_and_two_waves_per_simd_agree_bit_for_bit_on_the_reference_map(scene):
-    """the same for the reference's own shape in batches: D = 2 on the nearest-cell map, fp64 and fp32 sampling (from 4096
+    """the same for the reference's own shape in batches: D = 2 on the nearest-cell map, fp64 and fp32 sampling (from 1024
     trajectories per call on the library takes the two-waves allocation by itself)"""
     _, m, _ = scene
     for M, B in ((3, 200), (5, 128), (21, 64)):
