@@ -92,6 +92,21 @@ def test_esdf_build_3d_is_the_exact_edt(shape, seed):
         assert np.max(np.abs(dis - np.array([o3.lookup(p)[0] for p in pts]))) < 1e-12
 
 
+def test_esdf_build_3d_line_lengths_around_powers_of_two():
+    """the y / z passes solve a line by monotone minima over spacings 2^k: line lengths 2 .. 34 on both axes, with and
+    without occupied voxels in a line, dense and sparse"""
+    from scipy import ndimage
+    rng = np.random.default_rng(12)
+    for n in (2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 34):
+        for shape in ((n, 6, 5), (4, n, 7), (n, n, 3)):
+            for dens in (0.02, 0.3):
+                occ = (rng.random(shape) < dens).astype(np.uint8)
+                occ[0, 0, 0] = 1                                  # at least one occupied voxel
+                want = (ndimage.distance_transform_edt(1 - occ) * 0.25).astype(np.float32)
+                g3 = npa.ESDF3D.from_occupancy(occ, 0.25, (0.0, 0.0, 0.0), layout="linear", want_dist=True)
+                assert np.array_equal(g3.dist, want), (shape, dens)
+
+
 def test_esdf_build_3d_full_scene_matches_scipy():
     from scipy import ndimage
     occ = synth.occupancy_3d(1, n=160, res=30.0 / 160)
