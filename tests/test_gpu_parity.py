@@ -767,7 +767,9 @@ def test_every_boundary_row_reaches_every_optimiser_kernel():
     ctx = _lib.Context(0)
     g3 = npa.ESDF3D(dist, 0.4, (0.0, -6.4, 0.0), store="f32", layout="yz4", ctx=ctx)
     cap = 4
-    for M in (3, 21, 25, 41):
+    # (piece counts on both sides of every kernel switch: lane = (piece, dimension) up to 21, FLAT slots 1 / 2 / 4 at
+    #  n = 64 / 128, the five-level cap of the fp32 reduction from 34)
+    for M in (1, 2, 3, 16, 17, 21, 22, 25, 32, 33, 34, 41, 64):
         B = 8
         head, tail, wp, _ = _random_requests(rng, B, M, 3, (np.array([1.0, -5.0, 1.0]), np.array([11.5, 5.0, 10.0])))
         ts = rng.uniform(0.8, 2.5, (B, M))
