@@ -181,23 +181,28 @@ constexpr int kSqInf = 1 << 28;
 
 // SrcT = uint16_t: plane distances from row distances (squared while the tile is loaded); uint32_t: volume distances
 // from plane distances.  `stride_line` = elements between consecutive voxels of a line, `stride_slab` = elements
-// between the slabs a block row works on (grid.y), nline = voxels per line.  Dynamic LDS: nline * TX * 6 bytes.
+// between the slabs a block row works on (grid.y), nline = voxels per line.  Dynamic LDS: nline * TX * 4 (uint16 source) or 6 bytes.
 template <typename SrcT, int TX, bool FINAL>
 __global__ __launch_bounds__(256) void edt3_line_kernel(const SrcT *__restrict__ src, int nx, int nline, size_t stride_line,
                                                         size_t stride_slab, double res, uint32_t *__restrict__ out_sq,
                                                         float *__restrict__ out_dist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
-  int *f = reinterpret_cast<int *>(tile_raw);                                  // [nline][TX] squared values
-  uint16_t *am = reinterpret_cast<uint16_t *>(tile_raw + (size_t)nline * TX * 4);  // [nline][TX] minimisers
+  // [nline][TX] values: row distances as they are (uint16, squared when read: half the LDS, twice the blocks per CU) or
+  // plane distances (already squared); then [nline][TX] minimisers
+  using FT = std::conditional_t<sizeof(SrcT) == 2, uint16_t, int>;
+  FT *f = reinterpret_cast<FT *>(tile_raw);
+  uint16_t *am = reinterpret_cast<uint16_t *>(tile_raw + (size_t)nline * TX * sizeof(FT));
+  auto val = [&](int i) -> int {
+    const int v = (int)f[i];
+    if constexpr (sizeof(SrcT) == 2) return v >= kXInf ? kSqInf : v * v;
+    return v;
+  };
   const int x0 = blockIdx.x * TX;
   const size_t base = (size_t)blockIdx.y * stride_slab;
   for (int i = threadIdx.x; i < nline * TX; i += 256) {
     const int q = i / TX, xl = i - q * TX;
-    int v = kSqInf;
-    if (x0 + xl < nx) {
-      const int r = (int)src[base + (size_t)q * stride_line + x0 + xl];
-      if constexpr (sizeof(SrcT) == 2) v = r >= kXInf ? kSqInf : r * r; else v = r;
-    }
+    FT v = sizeof(SrcT) == 2 ? (FT)kXInf : (FT)kSqInf;
+    if (x0 + xl < nx) v = (FT)src[base + (size_t)q * stride_line + x0 + xl];
     f[i] = v;
   }
   __syncthreads();
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256) void edt3_line_kernel(const SrcT *__restrict__
   auto scan = [&](int p, int xl, int a, int b, int &best, int &arg) {
     int q = a;
     for (; q + 3 <= b; q += 4) {
-      const int f0 = f[q * TX + xl], f1 = f[(q + 1) * TX + xl], f2 = f[(q + 2) * TX + xl], f3 = f[(q + 3) * TX + xl];
+      const int f0 = val(q * TX + xl), f1 = val((q + 1) * TX + xl), f2 = val((q + 2) * TX + xl), f3 = val((q + 3) * TX + xl);
       const int d0 = p - q, d1 = d0 - 1, d2 = d0 - 2, d3 = d0 - 3;
       const int c0 = f0 + d0 * d0, c1 = f1 + d1 * d1, c2 = f2 + d2 * d2, c3 = f3 + d3 * d3;
       if (c0 < best) { best = c0; arg = q; }
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(256) void edt3_line_kernel(const SrcT *__restrict__
       if (c3 < best) { best = c3; arg = q + 3; }
     }
     for (; q <= b; ++q) {
-      const int dq = p - q, c = f[q * TX + xl] + dq * dq;
+      const int dq = p - q, c = val(q * TX + xl) + dq * dq;
       if (c < best) { best = c; arg = q; }
     }
   };
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(256) void edt3_line_kernel(const SrcT *__restrict__
     const int p = i / TX, xl = i - p * TX;
     if (x0 + xl >= nx) continue;
     const int q = am[i], dq = p - q;
-    const int best = min(f[q * TX + xl] + dq * dq, kSqInf);
+    const int best = min(val(q * TX + xl) + dq * dq, kSqInf);
     const size_t o = base + (size_t)p * stride_line + x0 + xl;
     if constexpr (FINAL) {
       // no occupied voxel at all: keep a large finite distance (scipy's convention there is an artefact of its
@@ -924,11 +929,12 @@ int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_d
       const size_t rows = (size_t)ny * nz;
       hipLaunchKernelGGL(edt3_x_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 4 * (size_t)nx * sizeof(uint16_t),
                          c->stream, src, nx, rows, d_gx.as<uint16_t>());
-      // tiles of at most 64 KB of LDS (6 bytes a voxel): TX x-columns by the whole line
+      // tiles of at most 64 KB of LDS (4 bytes a voxel in the y pass, 6 in the z pass): TX x-columns by the whole line
       const size_t plane = (size_t)nx * ny;
 #define NEO_EDT_LINE(SRC, TXV, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd)                                 \
   hipLaunchKernelGGL((edt3_line_kernel<SRC, TXV, FINAL>), dim3((unsigned)((nx + TXV - 1) / TXV), (unsigned)(nslab)), \
-                     dim3(256), (size_t)(nline) * TXV * 6, c->stream, srcp, nx, nline, sline, sslab, res, outsq, outd)
+                     dim3(256), (size_t)(nline) * TXV * (sizeof(SRC) == 2 ? 4 : 6), c->stream, srcp, nx, nline, sline,    \
+                     sslab, res, outsq, outd)
 #define NEO_EDT_PASS(SRC, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd)                             \
   if ((size_t)(nline) * 32 * 6 <= 65536) NEO_EDT_LINE(SRC, 32, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd);      \
   else if ((size_t)(nline) * 16 * 6 <= 65536) NEO_EDT_LINE(SRC, 16, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd); \
