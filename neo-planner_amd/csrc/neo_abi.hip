@@ -935,8 +935,12 @@ int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_d
   hipLaunchKernelGGL((edt3_line_kernel<SRC, TXV, FINAL>), dim3((unsigned)((nx + TXV - 1) / TXV), (unsigned)(nslab)), \
                      dim3(256), (size_t)(nline) * TXV * (sizeof(SRC) == 2 ? 4 : 6), c->stream, srcp, nx, nline, sline,    \
                      sslab, res, outsq, outd)
+      // 16 columns a tile while that keeps four or more blocks on a CU (measured at 300^3: y pass 248 -> 204 us, z pass
+      // 384 -> 252 us against 32 columns; 8 columns in the z pass: 278), else the widest tile that fits 64 KB
 #define NEO_EDT_PASS(SRC, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd)                             \
-  if ((size_t)(nline) * 32 * 6 <= 65536) NEO_EDT_LINE(SRC, 32, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd);      \
+  if ((size_t)(nline) * 16 * (sizeof(SRC) == 2 ? 4 : 6) <= 40960)                                           \
+    NEO_EDT_LINE(SRC, 16, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd);                             \
+  else if ((size_t)(nline) * 32 * 6 <= 65536) NEO_EDT_LINE(SRC, 32, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd); \
   else if ((size_t)(nline) * 16 * 6 <= 65536) NEO_EDT_LINE(SRC, 16, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd); \
   else if ((size_t)(nline) * 8 * 6 <= 65536) NEO_EDT_LINE(SRC, 8, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd);   \
   else NEO_EDT_LINE(SRC, 2, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd)
