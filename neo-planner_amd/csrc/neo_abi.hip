@@ -874,7 +874,8 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
   e.elem = store_dtype;
   // +64 elements of slack: the x-pair load of the last voxel row touches one element past the end
   HIPCHK(c, field.alloc((nstore + 64) * dsz));
-  HIPCHK(c, hipMemsetAsync(field.p, 0, (nstore + 64) * dsz, c->stream));
+  // (the pack kernels write every stored element; only the 64 elements of padding behind them need zeroing)
+  HIPCHK(c, hipMemsetAsync(static_cast<char *>(field.p) + nstore * dsz, 0, 64 * dsz, c->stream));
   const dim3 grid((unsigned)((nvox + 255) / 256)), blk(256);
 #define NEO_PACK(KERNEL)                                                                                               \
   do {                                                                                                             \
