@@ -912,24 +912,29 @@ int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_d
   if (store_dtype != NEO_F32 && store_dtype != NEO_F16) return fail(c, NEO_ERR_INVALID, "store_dtype must be f32 or f16");
   if (nx > 4096 || ny > 4096 || nz > 4096) return fail(c, NEO_ERR_INVALID, "3-D ESDF build: at most 4096 voxels per axis");
   const size_t nvox = (size_t)nx * ny * nz;
-  DevBuf d_dist;
+  // the passes' intermediates and the fp32 distances live in the context's scratch buffer (kept between calls: a map
+  // update at sensor rate then allocates nothing but the field itself)
+  float *d_dist_p = nullptr;
   {
     hipSetDevice(c->device);
-    DevBuf d_occ, d_gx, d_sq;
+    DevBuf d_occ;
     const uint8_t *src = occ;
     if (!occ_is_device) {
       HIPCHK(c, d_occ.alloc(nvox));
       HIPCHK(c, hipMemcpyAsync(d_occ.p, occ, nvox, hipMemcpyHostToDevice, c->stream));
       src = d_occ.as<uint8_t>();
     }
-    HIPCHK(c, d_gx.alloc(nvox * sizeof(uint16_t)));
-    HIPCHK(c, d_sq.alloc(nvox * sizeof(uint32_t)));
-    HIPCHK(c, d_dist.alloc(nvox * sizeof(float)));
+    int rc = ensure_scratch(c, nvox * (sizeof(uint16_t) + sizeof(uint32_t) + sizeof(float)) + 4 * 256);
+    if (rc) return rc;
+    Carver cv(c->scratch);
+    uint16_t *d_gx = cv.take<uint16_t>(nvox);
+    uint32_t *d_sq = cv.take<uint32_t>(nvox);
+    d_dist_p = cv.take<float>(nvox);
     {
       ProfScope ps(c, NEO_KERNEL_ESDF_BUILD);
       const size_t rows = (size_t)ny * nz;
       hipLaunchKernelGGL(edt3_x_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 4 * (size_t)nx * sizeof(uint16_t),
-                         c->stream, src, nx, rows, d_gx.as<uint16_t>());
+                         c->stream, src, nx, rows, d_gx);
       // tiles of at most 64 KB of LDS (4 bytes a voxel in the y pass, 6 in the z pass): TX x-columns by the whole line
       const size_t plane = (size_t)nx * ny;
 #define NEO_EDT_LINE(SRC, TXV, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd)                                 \
@@ -946,16 +951,16 @@ int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_d
   else if ((size_t)(nline) * 8 * 6 <= 65536) NEO_EDT_LINE(SRC, 8, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd);   \
   else NEO_EDT_LINE(SRC, 2, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd)
       // pass Y: lines along y (stride nx) in every z slab; pass Z: lines along z (stride nx * ny) for every y row
-      NEO_EDT_PASS(uint16_t, false, d_gx.as<uint16_t>(), ny, (size_t)nx, plane, nz, d_sq.as<uint32_t>(), (float *)nullptr);
-      NEO_EDT_PASS(uint32_t, true, d_sq.as<uint32_t>(), nz, plane, (size_t)nx, ny, (uint32_t *)nullptr, d_dist.as<float>());
+      NEO_EDT_PASS(uint16_t, false, d_gx, ny, (size_t)nx, plane, nz, d_sq, (float *)nullptr);
+      NEO_EDT_PASS(uint32_t, true, d_sq, nz, plane, (size_t)nx, ny, (uint32_t *)nullptr, d_dist_p);
 #undef NEO_EDT_PASS
 #undef NEO_EDT_LINE
     }
     HIPCHK(c, hipGetLastError());
-    if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, d_dist.p, nvox * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, d_dist_p, nvox * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  return neo_esdf_upload_3d(c, scene_id, d_dist.p, NEO_F32, 1, nx, ny, nz, res, origin, store_dtype, layout);
+  return neo_esdf_upload_3d(c, scene_id, d_dist_p, NEO_F32, 1, nx, ny, nz, res, origin, store_dtype, layout);
 }
 
 int neo_esdf_query(neo_ctx *c, int scene_id, int n, const double *pts, double *dist, double *grad) {
