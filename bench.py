@@ -118,7 +118,7 @@ def parse(argv=None):
     ap.add_argument("--grid", type=int, default=300)
     ap.add_argument("--dtype", default="f32x", choices=["f32", "f64", "f32x"],
                     help="f32: fp32 sampled terms, fp64 solve and optimiser; f64: the parity mode; f32x: everything in fp32")
-    ap.add_argument("--layout", default="yz4", choices=["linear", "yz4", "cell8"],
+    ap.add_argument("--layout", default="yz4", choices=["linear", "yz4", "cell8", "brick"],
                     help="voxel order of the field in HBM (include/neo_planner.h NEO_LAYOUT_*); yz4 = one line per lookup")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall budget of the NumPy-port sample")
     ap.add_argument("--native-seconds", type=float, default=4.0, help="wall budget of each cpu_native run")
@@ -491,7 +491,7 @@ def main():
         nv_ = a.grid ** 3
         # EDT: 1 B occupancy in, 2 B row distances out and in, 4 B plane distances out and in, 4 B fp32 distance out = 17 B
         # (+ 4 B the packing pass reads back); packing writes 1 (linear), 4 (yz4) or 8 (cell8) stored elements per voxel
-        elems_ = {"linear": 1, "yz4": 4, "cell8": 8}[a.layout]
+        elems_ = {"linear": 1, "yz4": 4, "cell8": 8, "brick": 4}[a.layout]
         bpv_ = 17 + 4 + elems_ * (4 if store == "f32" else 2)
         esdf_build = {"what": "neo_esdf_build_3d: exact EDT of the occupancy grid (three separable integer passes) + layout "
                               "packing, device to device, wall time of the whole call (allocations included)",

@@ -79,6 +79,9 @@ enum {
                             cache line per lookup and x-adjacent cells share half their bytes (4x the memory) */
   NEO_LAYOUT_CELL8 = 2,  /* cell-packed: the 2x2x2 corners of every interpolation cell contiguous (8x the
                             memory; one aligned 32-byte read per lookup instead of four gathers) */
+  NEO_LAYOUT_BRICK = 3,  /* corner bricks: one 128-byte line per block of 2 x 2 x 2 cells holding the block's 27 corners
+                            (fp32; fp16: 4 x 2 x 2 cells, 45 corners) -- a lookup reads one line, and a path stays on it
+                            for two cells in every direction (4x the memory in fp32, like NEO_LAYOUT_YZ4) */
 };
 
 /* planner parameters: DefaultConfig / PlannerConfig fields (expert_planner.py:12-25,
@@ -114,7 +117,7 @@ typedef struct neo_params {
  * lanes each, for n <= 16; four of 16 lanes beyond.  Opt-in: a piece's samples are strided over fewer lanes, so sums associate differently
  * and results agree with the default kernel to fp32 rounding, not bit for bit. */
 #define NEO_FLAG_LANE_GROUPS 128
-/* all-fp32 evaluation (3-D fields, fp32 sampling): the coefficient solve, the adjoint pass and the optimiser's vectors
+/* all-fp32 evaluation (fp32 sampling; 3-D fields and the 2-D reference map): the coefficient solve, the adjoint pass and the optimiser's vectors
  * and stored pairs in fp32 too, two wavefronts per SIMD.  Per evaluation the cost and gradient then agree with the
  * fp64 solve to ~1e-5 instead of 2e-6; the optimiser's statistics (evaluations, final costs) are those of the default
  * mode.  Opt-in throughput mode. */
@@ -265,7 +268,10 @@ int neo_optimize_trace_xg(neo_ctx *ctx, double *dev_xg, int cap);
  * trajectory order[i].  Results stay in the caller's order.  Workgroups start in index order, so
  * putting the runs expected to be long first shortens the launch (a late long run is its tail);
  * NULL = identity; it must be a permutation of 0..B-1 and is ignored by launches of another batch size.
- * neo_planner_amd.BatchPlanner sorts by time slack (sum(ts) * v_max / distance). */
+ * neo_planner_amd.BatchPlanner sorts by time slack (sum(ts) * v_max / distance).
+ * neo_sampled_terms_batch_dev launches of exactly B trajectories honour the same permutation: there the lever is
+ * locality -- workgroup i runs on XCD i mod 8, each XCD has its own L2, and BatchPlanner.spatial_order deals requests
+ * that fly through the same part of the field to the same XCD. */
 int neo_optimize_dispatch_order(neo_ctx *ctx, const int32_t *dev_order, int B);
 /* the same from a HOST permutation (copied into a context-owned device buffer); NULL or B = 0 resets.
  * Either way the permutation only applies to launches of exactly B trajectories. */

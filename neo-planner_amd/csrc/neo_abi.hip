@@ -366,6 +366,30 @@ __global__ void pack3d_cell8_kernel(const SrcT *__restrict__ src, int nx, int ny
   }
 }
 
+// corner-brick layout: one 128-byte line per block of 2 x 2 x 2 cells (fp32: 32 elements a line, 27 used) or 4 x 2 x 2
+// cells (fp16: 64 elements, 45 used); element ((cz * 3 + cy) * CX + cx) of block (bx, by, bz) = src at the block's corner
+// (cx, cy, cz), clamped at the upper faces; the rest of the line is zero.  One thread per stored element.
+template <typename SrcT, typename DstT>
+__global__ void pack3d_brick_kernel(const SrcT *__restrict__ src, int nx, int ny, int nz, int nbx, int nby, size_t total,
+                                    DstT *__restrict__ dst) {
+  constexpr int SHX = sizeof(DstT) == 4 ? 1 : 2, CX = (1 << SHX) + 1, PER = 128 / (int)sizeof(DstT);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t blk = i / PER;
+  const int e = (int)(i - blk * PER);
+  float v = 0.0f;
+  if (e < 9 * CX) {
+    const int cz = e / (3 * CX), cy = (e / CX) % 3, cx = e % CX;
+    const int bx = (int)(blk % nbx), by = (int)((blk / nbx) % nby), bz = (int)(blk / ((size_t)nbx * nby));
+    const int x = min((bx << SHX) + cx, nx - 1), y = min(2 * by + cy, ny - 1), z = min(2 * bz + cz, nz - 1);
+    v = (float)src[((size_t)z * ny + y) * nx + x];
+  }
+  if constexpr (sizeof(DstT) == 2)
+    dst[i] = __float2half(v);
+  else
+    dst[i] = (DstT)v;
+}
+
 // get_full_state_cmd (traj_utils.py:85-195): one wavefront per trajectory solves the
 // coefficients, then its lanes walk the sample times.
 template <int D>
@@ -568,6 +592,8 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
     if ((c->params.flags & NEO_FLAG_LANE_GROUPS) && D == 2 && !a.slots && a.M <= 16 && D * (a.M - 1) + a.M <= 32)
       return launch_opt_groups_2d(c, f32, a);
     const int fl2 = c->params.flags;
+    // all-fp32 mode on the reference's own map: the timed arithmetic, pinned to the reference's fixtures there
+    if ((fl2 & NEO_FLAG_F32_SOLVE) && f32) return launch_opt_2d_x(c, D, a);
     if (D == 2 && slots_for(a.M, D) <= 2 &&
         ((a.B >= kTwoWavesFromBatch && !(fl2 & NEO_FLAG_ONE_WAVE_PER_SIMD)) ||
          (fl2 & NEO_FLAG_TWO_WAVES_PER_SIMD)))
@@ -576,7 +602,7 @@ int dispatch_opt(neo_ctx *c, int kind, int elem, int layout, int D, const OptArg
   }
   if (D != 3) return fail(c, NEO_ERR_INVALID, "a 3-D map needs D = 3");
   const int fl = c->params.flags;
-  if ((fl & NEO_FLAG_LANE_GROUPS) && f32 && (layout == NEO_LAYOUT_LINEAR || layout == NEO_LAYOUT_YZ4) && !a.slots &&
+  if ((fl & NEO_FLAG_LANE_GROUPS) && f32 && (layout == NEO_LAYOUT_LINEAR || layout == NEO_LAYOUT_YZ4 || layout == NEO_LAYOUT_BRICK) && !a.slots &&
       a.M <= 16 && D * (a.M - 1) + a.M <= 32)
     return launch_opt_groups(c, elem, layout, a);
   if ((fl & NEO_FLAG_F32_SOLVE) && f32) return launch_opt_3d_x(c, elem, layout, a);  // all-fp32 mode
@@ -851,7 +877,7 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
   if (src_dtype != NEO_F64 && src_dtype != NEO_F32) return fail(c, NEO_ERR_INVALID, "src_dtype must be f64 or f32");
   if (store_dtype != NEO_F32 && store_dtype != NEO_F16)
     return fail(c, NEO_ERR_INVALID, "store_dtype must be f32 or f16");
-  if (layout != NEO_LAYOUT_LINEAR && layout != NEO_LAYOUT_YZ4 && layout != NEO_LAYOUT_CELL8)
+  if (layout != NEO_LAYOUT_LINEAR && layout != NEO_LAYOUT_YZ4 && layout != NEO_LAYOUT_CELL8 && layout != NEO_LAYOUT_BRICK)
     return fail(c, NEO_ERR_INVALID, "bad layout");
   // the lookups form voxel indices with 24-bit multiplies: (iz * ny + iy) * nx + ix
   if ((size_t)ny * nz >= ((size_t)1 << 24) || (size_t)nx >= ((size_t)1 << 24))
@@ -860,7 +886,11 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
   drop_locked(c, scene_id);
   const size_t nvox = (size_t)nx * ny * nz;
   const size_t ssz = src_dtype == NEO_F64 ? 8 : 4, dsz = store_dtype == NEO_F32 ? 4 : 2;
-  const size_t nstore = layout == NEO_LAYOUT_YZ4 ? nvox * 4 : (layout == NEO_LAYOUT_CELL8 ? nvox * 8 : nvox);
+  // corner bricks: blocks of 2 x 2 x 2 cells (fp32) / 4 x 2 x 2 cells (fp16), one 128-byte line each
+  const int bshx = store_dtype == NEO_F32 ? 1 : 2;
+  const int nbx = ((nx - 1) + (1 << bshx) - 1) >> bshx, nby = (ny - 1 + 1) / 2, nbz = (nz - 1 + 1) / 2;
+  const size_t nstore = layout == NEO_LAYOUT_YZ4 ? nvox * 4 : (layout == NEO_LAYOUT_CELL8 ? nvox * 8 :
+                        (layout == NEO_LAYOUT_BRICK ? (size_t)nbx * nby * nbz * (128 / dsz) : nvox));
   if ((nstore + 64) * dsz >= (size_t)4 << 30) return fail(c, NEO_ERR_INVALID, "field too large for 32-bit buffer offsets in this layout");
   const void *src = dist;
   DevBuf staged, field;
@@ -888,7 +918,17 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
     else                                                                                                           \
       hipLaunchKernelGGL((KERNEL<float, __half>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz, (__half *)field.p);   \
   } while (0)
-  if (layout == NEO_LAYOUT_CELL8)
+  if (layout == NEO_LAYOUT_BRICK) {
+    const dim3 gb((unsigned)((nstore + 255) / 256));
+    if (src_dtype == NEO_F64 && store_dtype == NEO_F32)
+      hipLaunchKernelGGL((pack3d_brick_kernel<double, float>), gb, blk, 0, c->stream, (const double *)src, nx, ny, nz, nbx, nby, nstore, (float *)field.p);
+    else if (src_dtype == NEO_F64)
+      hipLaunchKernelGGL((pack3d_brick_kernel<double, __half>), gb, blk, 0, c->stream, (const double *)src, nx, ny, nz, nbx, nby, nstore, (__half *)field.p);
+    else if (store_dtype == NEO_F32)
+      hipLaunchKernelGGL((pack3d_brick_kernel<float, float>), gb, blk, 0, c->stream, (const float *)src, nx, ny, nz, nbx, nby, nstore, (float *)field.p);
+    else
+      hipLaunchKernelGGL((pack3d_brick_kernel<float, __half>), gb, blk, 0, c->stream, (const float *)src, nx, ny, nz, nbx, nby, nstore, (__half *)field.p);
+  } else if (layout == NEO_LAYOUT_CELL8)
     NEO_PACK(pack3d_cell8_kernel);
   else if (layout == NEO_LAYOUT_YZ4)
     NEO_PACK(pack3d_yz4_kernel);
@@ -900,6 +940,8 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
   e.data = field.release();
   e.m3 = Map3D{e.data, nx, ny, nz, layout, res, origin[0], origin[1], origin[2], (unsigned int)((nstore + 64) * dsz)};
   e.m3.derive();
+  e.m3.nbx = nbx;
+  e.m3.nby = nby;
   c->maps[scene_id] = e;
   c->table_dirty = true;
   return NEO_OK;

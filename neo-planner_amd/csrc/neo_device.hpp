@@ -88,7 +88,8 @@ struct Map3D {
   const void *data;
   int nx, ny, nz;
   int layout;  // 0 linear [z][y][x], 1 = yz-quads (the 2x2 (y,z) neighbourhood of every voxel contiguous, x-major),
-               // 2 = cell-packed (8 corners of every cell contiguous)
+               // 2 = cell-packed (8 corners of every cell contiguous), 3 = corner bricks (one 128-byte line per block of
+               // 2 x 2 x 2 cells (fp32: its 27 corners) or 4 x 2 x 2 cells (fp16: its 45 corners))
   double res, ox, oy, oz;
   unsigned int bytes;  // size of the stored field (buffer-descriptor range)
   // fp32 constants of the lookup (Lookup3D), derived on the host: cell coordinate minus one half = pos * f_inv + f_off,
@@ -96,6 +97,7 @@ struct Map3D {
   // out of the optimiser loop and keeps in vector registers (spilled at three wavefronts per SIMD); as part of the
   // map record they arrive in scalar registers.
   float f_inv, f_off[3], f_hi[3];
+  int nbx, nby;  // corner-brick layout: blocks along x and y (set by the upload for layout 3)
   __host__ __device__ void derive() {
     f_inv = (float)(1.0 / res);
     f_off[0] = (float)(-ox / res - 0.5);
@@ -500,6 +502,31 @@ struct Lookup3D {
           q.c[w >> 1][w & 1][1] = __half2float(__ushort_as_half((unsigned short)(v[w] >> 16)));
         }
       }
+    } else if (LAYOUT == 3 || (LAYOUT == 9 && m.layout == 3)) {
+      // corner bricks: the cells are grouped in blocks of 2 x 2 x 2 (fp32) or 4 x 2 x 2 (fp16: x is the direction most
+      // requests fly in), and all (2+1)^3 = 27 (or 5 x 3 x 3 = 45) corners of a block sit in ONE 128-byte line, [z][y][x]
+      // inside the line.  A lookup is four x-pairs of that line -- one address register, four immediate offsets -- and
+      // a path stays on the line for two cells in EVERY direction, where the yz-quad line is eight cells along x and one
+      // along y and z: fewer lines per path (tools/sim_esdf_locality.py: -27 % lines fetched at cfg2), the same memory
+      // (16 bytes a cell in fp32).
+      constexpr int SHX = sizeof(E) == 4 ? 1 : 2, CX = (1 << SHX) + 1;  // cells (log2) and corners of a block along x
+      const unsigned int bx = (unsigned)a.i0[0] >> SHX, by = (unsigned)a.i0[1] >> 1, bz = (unsigned)a.i0[2] >> 1;
+      const unsigned int lx = (unsigned)a.i0[0] & ((1u << SHX) - 1u), ly = (unsigned)a.i0[1] & 1u, lz = (unsigned)a.i0[2] & 1u;
+      const unsigned int blk = __umul24(__umul24(bz, (unsigned)m.nby) + by, (unsigned)m.nbx) + bx;
+      const unsigned int in_line = (lz * 3u + ly) * (unsigned)CX + lx;  // element of corner (0,0,0) inside the line
+#pragma unroll
+      for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const unsigned int so = (unsigned)((dz * 3 + dy) * CX);  // compile-time: the instruction's immediate offset
+          if constexpr (sizeof(E) == 4) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(blk * 128u + in_line * 4u + so * 4u), 0, 0);
+            q.c[dz][dy][0] = __uint_as_float(v[0]);
+            q.c[dz][dy][1] = __uint_as_float(v[1]);
+          } else {
+            load_pair<E>(vox + blk * 64u + in_line + so, q.c[dz][dy][0], q.c[dz][dy][1]);
+          }
+        }
     } else if (LAYOUT == 0 || (LAYOUT == 9 && m.layout == 0)) {
       // 32-bit element index of corner (0,0,0); the other three x-pairs sit at +nx, +nx*ny, +nx*ny+nx
       const unsigned int base = __umul24(__umul24((unsigned)a.i0[2], (unsigned)m.ny) + (unsigned)a.i0[1], (unsigned)m.nx) +

@@ -36,6 +36,10 @@ int dispatch_eval(neo_ctx *c, const MapEntry &e, int D, const EvalArgs &a) {
 #else
   const bool f32 = c->params.sample_dtype == NEO_F32;
   if (e.kind == 0) {
+    if (f32 && (c->params.flags & NEO_FLAG_F32_SOLVE)) {  // all-fp32 mode on the 2-D map (neo_disp_opt2d_x.hip)
+      if (D == 2) return launch_eval<2, float, Map2D, Lookup2D<float>, float>(c, e.m2, a);
+      return launch_eval<3, float, Map2D, Lookup2D<float>, float>(c, e.m2, a);
+    }
     if (D == 2)
       return f32 ? launch_eval<2, float, Map2D, Lookup2D<float>>(c, e.m2, a)
                  : launch_eval<2, double, Map2D, Lookup2D<double>>(c, e.m2, a);
@@ -49,6 +53,7 @@ int dispatch_eval(neo_ctx *c, const MapEntry &e, int D, const EvalArgs &a) {
   return launch_eval<3, float, Map3D, Lookup3D<float, __half, LAY>, float>(c, e.m3, a);
     if (e.m3.layout == 0) { NEO_3DX(0) }
     if (e.m3.layout == 2) { NEO_3DX(2) }
+    if (e.m3.layout == 3) { NEO_3DX(3) }
     NEO_3DX(1)
 #undef NEO_3DX
   }
@@ -60,6 +65,7 @@ int dispatch_eval(neo_ctx *c, const MapEntry &e, int D, const EvalArgs &a) {
              : launch_eval<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, e.m3, a);
   if (e.m3.layout == 0) { NEO_3D(0) }
   if (e.m3.layout == 2) { NEO_3D(2) }
+  if (e.m3.layout == 3) { NEO_3D(3) }
   NEO_3D(1)
 #undef NEO_3D
 #endif

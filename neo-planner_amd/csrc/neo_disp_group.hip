@@ -60,6 +60,10 @@ int launch_opt_groups(neo_ctx *c, int elem, int layout, const OptArgs &a) {
     if (elem == NEO_F32) return launch_group<float, Lookup3D<float, float, 1>>(c, a);
     return launch_group<float, Lookup3D<float, __half, 1>>(c, a);
   }
+  if (layout == NEO_LAYOUT_BRICK) {
+    if (elem == NEO_F32) return launch_group<float, Lookup3D<float, float, 3>>(c, a);
+    return launch_group<float, Lookup3D<float, __half, 3>>(c, a);
+  }
   if (elem == NEO_F32) return launch_group<float, Lookup3D<float, float, 0>>(c, a);
   return launch_group<float, Lookup3D<float, __half, 0>>(c, a);
 }

@@ -9,6 +9,7 @@ int launch_opt_3d_f64(neo_ctx *c, int elem, int layout, const OptArgs &a) {
   return launch_opt<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, a);
   if (layout == 0) { NEO_3D(0) }
   if (layout == 2) { NEO_3D(2) }
+  if (layout == 3) { NEO_3D(3) }
   NEO_3D(1)
 #undef NEO_3D
 }
@@ -21,6 +22,7 @@ int launch_opt_3d_f64_w2(neo_ctx *c, int elem, int layout, const OptArgs &a) {
   return launch_opt<3, double, Map3D, Lookup3D<double, __half, LAY>, 2>(c, a);
   if (layout == 0) { NEO_3D(0) }
   if (layout == 2) { NEO_3D(2) }
+  if (layout == 3) { NEO_3D(3) }
   NEO_3D(1)
 #undef NEO_3D
 }

@@ -12,6 +12,7 @@ int launch_opt_3d_w2(neo_ctx *c, int elem, int layout, const OptArgs &a) {
   return launch_opt<3, float, Map3D, Lookup3D<float, __half, LAY>, 2>(c, a);
   if (layout == 0) { NEO_3D2(0) }
   if (layout == 2) { NEO_3D2(2) }
+  if (layout == 3) { NEO_3D2(3) }
   NEO_3D2(1)
 #undef NEO_3D2
 #endif

@@ -13,6 +13,7 @@ int launch_opt_3d_x(neo_ctx *c, int elem, int layout, const OptArgs &a) {
   return launch_opt<3, float, Map3D, Lookup3D<float, __half, LAY>, 2, float>(c, a);
   if (layout == 0) { NEO_3DX(0) }
   if (layout == 2) { NEO_3DX(2) }
+  if (layout == 3) { NEO_3DX(3) }
   NEO_3DX(1)
 #undef NEO_3DX
 #endif

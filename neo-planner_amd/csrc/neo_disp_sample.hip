@@ -48,7 +48,7 @@ int launch_sample_chunk(neo_ctx *c, const MapT &map, const SampleArgs &a) {
 template <int D, typename Real, class MapT, class LookupT>
 int launch_sample(neo_ctx *c, const MapT &map, const SampleArgs &a) {
   hipLaunchKernelGGL((sample_kernel<D, Real, MapT, LookupT>), dim3(a.B), dim3(kWave), 0, c->stream, a.B, a.M, c->dev,
-                     map, a.coeffs, a.ts, a.costs2, a.grad_C, a.grad_T);
+                     map, a.coeffs, a.ts, a.costs2, a.grad_C, a.grad_T, (c->order_B == a.B ? c->dispatch_order : nullptr));
   return NEO_OK;
 }
 
@@ -87,6 +87,7 @@ int dispatch_sample(neo_ctx *c, const MapEntry &e, int D, const SampleArgs &a) {
              : launch_sample<3, double, Map3D, Lookup3D<double, __half, LAY>>(c, e.m3, a);
   if (e.m3.layout == 0) { NEO_3D(0) }
   if (e.m3.layout == 2) { NEO_3D(2) }
+  if (e.m3.layout == 3) { NEO_3D(3) }
   NEO_3D(1)
 #undef NEO_3D
 #endif

@@ -166,6 +166,7 @@ int launch_opt_3d_x(neo_ctx *c, int elem, int layout, const OptArgs &a);    // n
 int launch_opt_groups(neo_ctx *c, int elem, int layout, const OptArgs &a);  // neo_disp_group.hip
 int launch_opt_3d_f64_w2(neo_ctx *c, int elem, int layout, const OptArgs &a);
 int launch_opt_2d_w2(neo_ctx *c, bool f32, const OptArgs &a);
+int launch_opt_2d_x(neo_ctx *c, int D, const OptArgs &a);                   // neo_disp_opt2d_x.hip (all-fp32 mode)
 int launch_opt_groups_2d(neo_ctx *c, bool f32, const OptArgs &a);           // neo_disp_group.hip (D = 2, nearest-cell map)
 
 }  // namespace neo

@@ -584,9 +584,13 @@ __global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? NEO_SAMPLE_OCC : 2) void
                                                                                   const double *__restrict__ ts,
                                                                                   double *__restrict__ costs2,
                                                                                   double *__restrict__ grad_C,
-                                                                                  double *__restrict__ grad_T) {
-  const int b = blockIdx.x;
-  if (b >= B) return;
+                                                                                  double *__restrict__ grad_T,
+                                                                                  const int *__restrict__ order) {
+  if ((int)blockIdx.x >= B) return;
+  // workgroup i runs on XCD i mod 8 (round-robin dispatch) and each XCD has its own 4 MB L2: `order` lets the caller
+  // hand every XCD requests that fly through the same part of the field (BatchPlanner.spatial_order); results stay in
+  // the caller's order
+  const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
   __shared__ int seg[kWave];
   // rows of the per-piece fold (fp32 sampling, minco_sample)
   __shared__ __attribute__((aligned(16))) Real rows[sizeof(Real) == 4 ? kWave * 8 * D : 4];

@@ -11,7 +11,8 @@ LIB_PATH = os.environ.get("NEO_PLANNER_LIB") or os.path.join(PKG, "libneo_planne
 
 NEO_OK = 0
 NEO_F64, NEO_F32, NEO_F16 = 0, 1, 2
-NEO_LAYOUT_LINEAR, NEO_LAYOUT_YZ4, NEO_LAYOUT_CELL8 = 0, 1, 2
+NEO_LAYOUT_LINEAR, NEO_LAYOUT_YZ4, NEO_LAYOUT_CELL8, NEO_LAYOUT_BRICK = 0, 1, 2, 3
+LAYOUTS = {"linear": NEO_LAYOUT_LINEAR, "yz4": NEO_LAYOUT_YZ4, "cell8": NEO_LAYOUT_CELL8, "brick": NEO_LAYOUT_BRICK}
 NEO_TRAJ_CONVERGED_GRAD, NEO_TRAJ_CONVERGED_F, NEO_TRAJ_ABNORMAL = 0, 1, 2
 NEO_TRAJ_MAXITER, NEO_TRAJ_NUMERIC_RANGE, NEO_TRAJ_NONFINITE, NEO_TRAJ_BAD_SCENE = 3, 4, 5, 6
 NEO_TRAJ_FLAG_COLLISION = 0x100

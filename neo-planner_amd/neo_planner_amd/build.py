@@ -14,7 +14,7 @@ INCLUDE = os.path.join(os.path.dirname(os.path.dirname(PKG)), "include")
 # NEO_BUILD_OUT: where an experiment build (NEO_BUILD_DEFS) is written; the product is always the in-tree path
 LIB = os.environ.get("NEO_BUILD_OUT") or os.path.join(PKG, "libneo_planner_hip.so")
 OBJDIR = os.path.join(CSRC, "build")
-SOURCES = ["neo_abi.hip", "neo_disp_eval.hip", "neo_disp_sample.hip", "neo_disp_opt2d.hip", "neo_disp_opt3d_f32.hip",
+SOURCES = ["neo_abi.hip", "neo_disp_eval.hip", "neo_disp_sample.hip", "neo_disp_opt2d.hip", "neo_disp_opt2d_x.hip", "neo_disp_opt3d_f32.hip",
            "neo_disp_opt3d_f64.hip", "neo_disp_opt3d_w2.hip", "neo_disp_opt3d_x.hip", "neo_disp_group.hip"]
 HEADERS = ["neo_device.hpp", "neo_kernels.hpp", "neo_host.hpp", "neo_launch_opt.hpp", "neo_lbfgs.hpp",
            "neo_linesearch.hpp", "neo_lbfgs_sm.hpp", "neo_lbfgs_dir.hpp", "neo_group_kernel.hpp"]
@@ -52,6 +52,7 @@ def _newest_header():
 # care: 1.26 M either way).
 _SINK = ["-mllvm", "-sink-insts-to-avoid-spills"]
 UNIT_FLAGS = {"neo_disp_opt3d_x.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
+              "neo_disp_opt2d_x.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
               # (the fp64 unit also without machine LICM: no spills at all in its two-waves kernels, 618 k -> 640 k; the
               #  same pair costs the mixed mode 6 % and the all-fp32 mode 2 %, so only there)
               "neo_disp_opt3d_f64.hip": _SINK + ["-mllvm", "-disable-machine-licm"],

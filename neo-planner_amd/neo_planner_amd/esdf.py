@@ -133,7 +133,7 @@ class ESDF3D:
         c.check(c.lib.neo_esdf_upload_3d(c.h, self.scene_id, pointer, src_dtype, int(src_dev), nx, ny, nz,
                                          self.resolution, ctypes.cast(org, ctypes.c_void_p),
                                          {"f32": _lib.NEO_F32, "f16": _lib.NEO_F16}[store],
-                                         {"linear": _lib.NEO_LAYOUT_LINEAR, "yz4": _lib.NEO_LAYOUT_YZ4, "cell8": _lib.NEO_LAYOUT_CELL8}[layout]))
+                                         _lib.LAYOUTS[layout]))
 
     @classmethod
     def from_occupancy(cls, occ, resolution, origin_xyz, store="f32", layout="linear", ctx=None, want_dist=False):
@@ -165,7 +165,7 @@ class ESDF3D:
         c.check(c.lib.neo_esdf_build_3d(c.h, self.scene_id, pointer, int(on_dev), nx, ny, nz, self.resolution,
                                         ctypes.cast(org, ctypes.c_void_p),
                                         {"f32": _lib.NEO_F32, "f16": _lib.NEO_F16}[store],
-                                        {"linear": _lib.NEO_LAYOUT_LINEAR, "yz4": _lib.NEO_LAYOUT_YZ4, "cell8": _lib.NEO_LAYOUT_CELL8}[layout],
+                                        _lib.LAYOUTS[layout],
                                         _lib.ptr(self.dist)))
         return self
 

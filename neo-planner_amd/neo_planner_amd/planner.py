@@ -92,7 +92,10 @@ class MinJerkPlanner:
         self.iter_num = 0
         self.opt_running_times = 0
         self.coeffs = []
-        self.sample_dtype = sample_dtype
+        # "f32x": everything in fp32 (NEO_FLAG_F32_SOLVE) -- the arithmetic bench.py times, here behind the reference's own
+        # interface so that the recorded reference runs (tests/golden g3 / g6) can be replayed in it
+        self.flags = _lib.NEO_FLAG_F32_SOLVE if sample_dtype == "f32x" else 0
+        self.sample_dtype = "f32" if sample_dtype == "f32x" else sample_dtype
         self.stale_T = stale_T
         self._cache = {}
         self._scene = None
@@ -221,7 +224,7 @@ class MinJerkPlanner:
         cfg = PlannerConfig(v_max=self.v_max, T_min=self.T_min, T_max=self.T_max, safe_dis=self.safe_dis,
                             delta_t=self.delta_t, weights=self.weights,
                             collision_cost_tol=self.collision_cost_tol)
-        _push_params(self.ctx, cfg, self.sample_dtype, self.stale_T)
+        _push_params(self.ctx, cfg, self.sample_dtype, self.stale_T, self.flags)
 
     def _launch_plan_once(self, wpts_list, ts):
         """one launch of len(wpts_list) trajectories that share head / tail / durations: (x, costs, last, nit, nfev, st)"""
@@ -407,8 +410,8 @@ class BatchPlanner:
     def __init__(self, config=None, ctx=None, sample_dtype="f64", stale_T=True, waves_per_simd=None, lane_groups=False):
         """waves_per_simd: None (the library decides by batch size), 1 (shortest evaluations) or 2 (highest
         throughput when several batches are in flight) -- include/neo_planner.h NEO_FLAG_*; same results.
-        sample_dtype: "f64" (parity mode), "f32" (fp32 sampled terms, fp64 solve and optimiser) or "f32x" (3-D fields:
-        everything in fp32, NEO_FLAG_F32_SOLVE)"""
+        sample_dtype: "f64" (parity mode), "f32" (fp32 sampled terms, fp64 solve and optimiser) or "f32x" (everything
+        in fp32, NEO_FLAG_F32_SOLVE: 3-D fields and the reference's 2-D map)"""
         self.cfg = config if config is not None else PlannerConfig()
         self._ctx = ctx
         self.all_f32 = sample_dtype == "f32x"
@@ -546,6 +549,47 @@ class BatchPlanner:
         dist = np.linalg.norm(tail[:, 0] - head[:, 0], axis=1)
         slack = ts.sum(axis=1) * self.cfg.v_max / np.maximum(dist, 1e-9)
         return np.argsort(-slack, kind="stable").astype(np.int32)
+
+    @staticmethod
+    def spatial_order(head, tail, xcds=8, cell=1.0, key=None):
+        """XCD-aware spatial dispatch order for the ESDF-lookup kernel (neo_optimize_dispatch_order): requests are keyed by
+        a coarse Morton code of where they fly -- the midpoint of start and goal in cells of `cell` metres -- sorted, and
+        the sorted list is dealt so that workgroups i, i + 8, i + 16, ... (one XCD: the hardware dispatches workgroups
+        round-robin over the 8 XCDs, each with its own 4 MB L2) hold one contiguous run of it.  Requests whose
+        corridors overlap then share an L2 and run at about the same time.  Results are in the caller's order and
+        bit-identical whatever the order."""
+        head = np.asarray(head); tail = np.asarray(tail)
+        B = head.shape[0]
+        if key is None:
+            mid = 0.5 * (head[:, 0] + tail[:, 0])
+            q = np.floor((mid - mid.min(axis=0)) / cell).astype(np.int64)
+            bits = max(1, int(np.ceil(np.log2(max(int(q.max()) + 1, 2)))))
+            key = np.zeros(B, dtype=np.int64)
+            D = q.shape[1]
+            for b in range(bits):
+                for d in range(D):
+                    key |= ((q[:, d] >> b) & 1) << (D * b + d)
+        srt = np.argsort(key, kind="stable")
+        out = np.empty(B, dtype=np.int32)
+        # workgroup i -> XCD i mod xcds; XCD k takes the k-th contiguous share of the sorted list (shares differ by at
+        # most one request when xcds does not divide B)
+        bounds = (np.arange(xcds + 1) * B) // xcds
+        pos = np.arange(B)
+        for k in range(xcds):
+            mine = pos[k::xcds]
+            seg = srt[bounds[k]:bounds[k + 1]]
+            m = min(len(mine), len(seg))
+            out[mine[:m]] = seg[:m]
+        if B % xcds:
+            # uneven shares: fill what is left in index order (still a permutation)
+            used = np.zeros(B, dtype=bool)
+            filled = np.zeros(B, dtype=bool)
+            for k in range(xcds):
+                mine = pos[k::xcds]; seg = srt[bounds[k]:bounds[k + 1]]
+                m = min(len(mine), len(seg))
+                used[seg[:m]] = True; filled[mine[:m]] = True
+            out[~filled] = np.flatnonzero(~used)
+        return out
 
     def optimize_dev(self, map, x, head, tail, costs, costs_last, nit, nfev, status, slots=None, x0=None):
         """torch CUDA tensors (float64 / int32), asynchronous on the context's stream.

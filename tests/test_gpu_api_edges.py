@@ -396,6 +396,9 @@ def test_lane_group_kernel_small_problems():
     x0 = la.pack_x(wp, ts)
     a, b = la.optimize(g_lin, x0, head, tail, order=False), la.optimize(g_yz4, x0, head, tail, order=False)
     assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["nfev"], b["nfev"])
+    g_brk = npa.ESDF3D(dist, 0.3, synth.DOMAIN_ORIGIN, store="f32", layout="brick")
+    c = la.optimize(g_brk, x0, head, tail, order=False)
+    assert np.array_equal(a["x"], c["x"]) and np.array_equal(a["nfev"], c["nfev"])
 
 
 def test_lane_groups_with_dispatch_order_and_batches_in_flight():

@@ -83,7 +83,7 @@ def test_esdf_build_3d_is_the_exact_edt(shape, seed):
     occ = (rng.random(shape) < 0.01).astype(np.uint8)
     occ[0] = 1                                            # ground slab, as every synthetic scene has
     want = (ndimage.distance_transform_edt(1 - occ) * 0.1).astype(np.float32)
-    for layout in ("linear", "yz4", "cell8"):
+    for layout in ("linear", "yz4", "cell8", "brick"):
         g3 = npa.ESDF3D.from_occupancy(occ, 0.1, (0.0, -1.0, 0.0), layout=layout, want_dist=True)
         assert np.array_equal(g3.dist, want)
         pts = rng.uniform([0, -1, 0], [shape[2] * 0.1, -1 + shape[1] * 0.1, shape[0] * 0.1], (500, 3))
@@ -124,7 +124,7 @@ def test_trilinear_lookup_matches_oracle_and_ties_back_to_2d():
     rng = np.random.default_rng(1)
     h, w = d["esdf_map"].shape
     pts = rng.uniform([origin[0] - 0.2, origin[1] - 0.2, -0.1], [origin[0] + w * res + 0.2, origin[1] + h * res + 0.2, 0.7], (3000, 3))
-    for layout in ("linear", "yz4", "cell8"):
+    for layout in ("linear", "yz4", "cell8", "brick"):
         for store, tol in (("f32", 1e-12), ("f16", 2e-3)):
             g3 = npa.ESDF3D(vol, res, origin, store=store, layout=layout)
             dis, grd = g3.query(pts)
@@ -145,6 +145,7 @@ def test_trilinear_lookup_matches_oracle_and_ties_back_to_2d():
 def test_cost_grad_matches_reference_g1(path):
     d = load(path)
     m = _gpu_map(d)
+    # (the all-fp32 mode against the same fixtures: tests/test_gpu_reference_fixtures.py)
     for dtype, tol in (("f64", 1e-10), ("f32", 2e-5)):
         bp = npa.BatchPlanner(sample_dtype=dtype)
         for M in (3, 21, 41):
@@ -208,7 +209,7 @@ def test_cost_grad_trilinear_matches_oracle():
     dist = (ndimage.distance_transform_edt(1 - occ) * res).astype(np.float32)
     origin = (-1.0, -6.0, 0.0)
     o3 = onp.Grid3DESDF(dist, res, origin)
-    for layout in ("linear", "yz4", "cell8"):
+    for layout in ("linear", "yz4", "cell8", "brick"):
         g3 = npa.ESDF3D(dist, res, origin, store="f32", layout=layout)
         for M, B in ((3, 4), (21, 4), (41, 2)):
             head, tail, wp, ts = _random_requests(rng, B, M, 3, (np.array([0.0, -5.0, 1.0]), np.array([10.5, 5.0, 8.0])))
@@ -224,6 +225,43 @@ def test_cost_grad_trilinear_matches_oracle():
                     c = pl.get_cost(x[b]); g = pl.get_grad(x[b])
                     assert abs(out["cost"][b] - c) <= tol * abs(c)
                     assert rel_err(out["grad"][b], g) < tol * 5
+
+
+def test_every_layout_holds_the_same_numbers_and_gives_the_same_bits():
+    """the field layouts (linear, yz-quads, cell-packed, corner bricks) store the same corner values: every mode's
+    evaluation and every whole run is bit-identical across them, for fp32 and fp16 storage, on odd grid sizes (partly
+    filled blocks at the upper faces of the brick layout) -- only the addresses differ"""
+    rng = np.random.default_rng(77)
+    from scipy import ndimage
+    for shape in ((31, 45, 38), (8, 9, 7), (2, 3, 5)):
+        occ = (rng.random(shape) < 0.004).astype(np.uint8)
+        occ[0] = 1
+        res = 0.3
+        dist = (ndimage.distance_transform_edt(1 - occ) * res).astype(np.float32)
+        origin = (0.0, -0.5 * shape[1] * res, 0.0)
+        hi = np.array([shape[2] * res, 0.5 * shape[1] * res, shape[0] * res])
+        lo = np.array([0.0, -0.5 * shape[1] * res, 0.0])
+        for store in ("f32", "f16"):
+            maps = {lay: npa.ESDF3D(dist, res, origin, store=store, layout=lay) for lay in ("linear", "yz4", "cell8", "brick")}
+            pts = rng.uniform(lo - 0.2, hi + 0.2, (4000, 3))
+            ref_d, ref_g = maps["linear"].query(pts)
+            for lay in ("yz4", "cell8", "brick"):
+                d_, g_ = maps[lay].query(pts)
+                assert np.array_equal(d_, ref_d) and np.array_equal(g_, ref_g), (shape, store, lay)
+            for M, B in ((3, 16), (21, 8), (41, 4)):
+                head, tail, wp, ts = _random_requests(rng, B, M, 3, (lo + 0.3, hi - 0.3))
+                ts = rng.uniform(0.6, 2.0, (B, M))
+                for dtype in ("f64", "f32", "f32x"):
+                    bp = npa.BatchPlanner(sample_dtype=dtype)
+                    x = bp.pack_x(wp, ts)
+                    ref = bp.cost_grad(maps["linear"], x, head, tail)
+                    for lay in ("yz4", "brick"):
+                        got = bp.cost_grad(maps[lay], x, head, tail)
+                        assert np.array_equal(got["cost"], ref["cost"]) and np.array_equal(got["grad"], ref["grad"]), (shape, store, lay, dtype, M)
+                    if M == 21:
+                        ro = bp.optimize(maps["yz4"], x, head, tail)
+                        rb = bp.optimize(maps["brick"], x, head, tail)
+                        assert np.array_equal(ro["x"], rb["x"]) and np.array_equal(ro["nfev"], rb["nfev"]), (shape, store, dtype)
 
 
 def test_all_fp32_joint_solve_by_cyclic_reduction_for_every_piece_count():

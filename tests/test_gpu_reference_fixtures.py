@@ -1,0 +1,83 @@
+"""
+The three arithmetic modes against the REFERENCE-GENERATED fixtures on the reference's own 2-D map:
+G1 per evaluation, every G3 run, the 256 G6 requests -- `f32x`, the mode bench.py's `value` is measured in, included.
+The measurements live in tools/ref_fixture_parity.py (also behind bench.py's `parity.vs_reference_fixtures` and
+profiles/r04_reference_fixture_parity.json); this file holds them to thresholds.
+
+What can be asked of whole runs: the REAL reference under another BLAS kernel set ends within
+north_star's 1e-4 of itself on 88 % of these 256 requests; fp32 arithmetic perturbs every evaluation by 1e-6..1e-5
+instead of 1e-16, so its runs leave the reference's path earlier -- the same algorithm on an objective within the stated
+per-evaluation tolerance.  Hence: fp64 must match the reference's self-agreement; the fp32 modes must show the reference's
+exit and exception statistics and end at the reference's cost level.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import ref_fixture_parity as rfp  # noqa: E402
+
+
+def test_g1_every_mode_against_the_reference_evaluation():
+    """f64 1e-10, f32 2e-5 on all 24 reference evaluations.  f32x (fp32 solve: positions good to ~1e-4 m) 4e-5 -- except
+    where the reference objective itself is discontinuous within that resolution: a sample next to a face of the
+    nearest-cell map or a duration next to a multiple of delta_t.  Those cases are held to the reference's OWN jump
+    under fp32-sized noise on x (measured with the pinned oracle): the device may not be further from the reference than
+    the reference is from itself a few 1e-6 away."""
+    r = rfp.g1_report()
+    print({m: (v["cost_max"], v["cost_median"], len(v["beyond"])) for m, v in r.items()})
+    assert r["f64"]["n"] == 24
+    assert not r["f64"]["beyond"] and not r["f32"]["beyond"], (r["f64"]["beyond"], r["f32"]["beyond"])
+    assert r["f64"]["coeffs_max"] < 1e-11 and r["f32"]["coeffs_max"] < 1e-11 and r["f32x"]["coeffs_max"] < 2e-5
+    x = r["f32x"]
+    assert x["within_tolerance"] >= 20 and x["cost_median"] < 2e-6 and x["grad_median"] < 2e-5, x
+    for b in x["beyond"]:
+        assert b["reference_jump_under_4e_6_noise"] >= 0.3 * b["cost"], b
+
+
+def test_g3_every_recorded_reference_run_in_every_mode():
+    rows = rfp.g3_report()
+    s = rfp.g3_summary(rows)
+    print(s)
+    n = s["f64"]["n"]
+    assert n >= 22
+    # fp64: what tests/test_gpu_parity.py::test_planner_reproduces_reference_runs_g3_g5 asserts run by run
+    assert s["f64"]["same_exception"] == n and s["f64"]["finals_within_1e_4"] >= n - 3
+    for mode in ("f32", "f32x"):
+        m = s[mode]
+        # the same exceptions (collision cost too large / none) and the same number of plan_once attempts on nearly every
+        # recorded scenario; finals at the reference's cost level
+        assert m["same_exception"] >= n - 3, (mode, m)
+        assert m["same_run_count"] >= n - 4, (mode, m)
+        assert m["finals_within_1e_4"] >= n - 5, (mode, m)           # measured: 19 of 22 in both fp32 modes
+        assert m["cost_within_1e_2"] >= n - 5, (mode, m)
+        assert m["cost_rel_median"] < 1e-4, (mode, m)
+
+
+def test_g6_shares_within_1e_4_of_the_reference_beside_the_reference_against_itself():
+    r = rfp.g6_report()
+    ref, dev = r["reference_vs_itself"], r["device_vs_reference"]
+    print({k: (v["finals_within_1e_4"], v["same_nfev"], v["cost_within_1e_2"]) for k, v in dev.items()}, ref["self_agreement_min"])
+    n = dev["f64"]["n"]
+    assert n >= 240
+    slack = 2.0 * np.sqrt(0.25 / n)
+    # fp64: parts from the reference no more often than the reference from itself under another BLAS kernel set
+    assert dev["f64"]["finals_within_1e_4"] >= ref["self_agreement_min"] - slack
+    assert dev["f64"]["x_rel_median"] < 1e-9 and dev["f64"]["same_exception"] >= 0.95
+    for mode, within, c2 in (("f32", 0.6, 0.8), ("f32x", 0.45, 0.7)):
+        m = dev[mode]
+        # measured (profiles/r04_reference_fixture_parity.json): finals within 1e-4 of the reference's on 72.5 % (f32) and
+        # 54.6 % (f32x) of the 251 runs -- the reference against itself: 89.6 %; cost within 1e-2 on 90 % / 79 %
+        assert m["finals_within_1e_4"] >= within - slack, (mode, m)
+        assert m["cost_within_1e_2"] >= c2 - slack, (mode, m)
+        assert m["same_exception"] >= 0.97, (mode, m)                  # `collision cost too large` on the same requests
+        assert abs(m["mean_nfev"] - ref["mean_nfev"]) <= 0.15 * ref["mean_nfev"], (mode, m)
+        # exits: every run ends by L-BFGS-B's own tests; the fp32 modes end fewer line searches ABNORMALly than the
+        # reference (f32x: 3 against 32 of 251 -- a search that has contracted below fp32 resolution repeats a point and
+        # is closed by dcsrch's rounding-error warning, which L-BFGS-B treats as a completed search)
+        assert set(m["exits"]) <= {"CONVERGED_F", "CONVERGED_GRAD", "ABNORMAL"}, (mode, m["exits"])
+        assert m["exits"].get("ABNORMAL", 0) <= ref["exits"].get("ABNORMAL", 0) + 8, (mode, m["exits"], ref["exits"])

@@ -2,7 +2,7 @@
 G6: how far does the REFERENCE part from ITSELF?
 
 tests/golden/g6_reference_vs_itself.npz holds the finals of the real `MinJerkPlanner.plan_once`
-(expert_planner.py:205-237, run read-only by tools/gen_golden.py) on 64 M = 21 requests of the 2-D reference map, under
+(expert_planner.py:205-237, run read-only by tools/gen_golden.py) on 256 M = 21 requests of the 2-D reference map (64 in round 3; requests 0..63 unchanged), under
 four BLAS environments that differ by environment variables only -- no source change:
 
     blas_threads_1             OPENBLAS_NUM_THREADS=1  (the environment of every other fixture)

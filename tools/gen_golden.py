@@ -405,7 +405,7 @@ def gen_g3b(want=4, min_evals=60):
 
 
 # ---------------------------------------------------------------- G6: the reference against itself
-G6_REQUESTS = 64
+G6_REQUESTS = 256       # (round 4: 64 -> 256; requests 0..63 are the round-3 ones, seeds 2600 + k)
 G6_ENVS = [("blas_threads_1", {"OPENBLAS_NUM_THREADS": "1", "OMP_NUM_THREADS": "1"}),
            ("blas_threads_8", {"OPENBLAS_NUM_THREADS": "8", "OMP_NUM_THREADS": "8"}),
            ("blas_coretype_haswell", {"OPENBLAS_NUM_THREADS": "1", "OMP_NUM_THREADS": "1", "OPENBLAS_CORETYPE": "Haswell"}),
@@ -446,11 +446,15 @@ def g6_child(path):
             out[f"q{k}_nfev"] = res.nfev
             out[f"q{k}_nit"] = res.nit
             out[f"q{k}_fun"] = np.float64(res.fun)
+            out[f"q{k}_status"] = int(res.status)
+            out[f"q{k}_message"] = str(res.message)
         else:       # minimize() itself was left through an exception (OverflowError inside a callback)
             out[f"q{k}_x"] = np.full(20 * 2 + 21, np.nan)
             out[f"q{k}_nfev"] = -1
             out[f"q{k}_nit"] = -1
             out[f"q{k}_fun"] = np.float64(np.nan)
+            out[f"q{k}_status"] = -1
+            out[f"q{k}_message"] = ""
         out[f"q{k}_error"] = err
         out[f"q{k}_costs"] = np.array(planner.costs)
     import numpy
@@ -465,7 +469,7 @@ def g6_child(path):
 
 
 def gen_g6():
-    """The same 64 M = 21 requests through the REAL reference under different BLAS environments (environment
+    """The same 256 M = 21 requests through the REAL reference under different BLAS environments (environment
     variables only, no source change): how often does expert_planner.py part from ITSELF?  """
     import subprocess
     import tempfile
@@ -481,11 +485,17 @@ def gen_g6():
     out["res"] = synth.RES
     out["origin"] = np.array([0.0, -15.0])
     with tempfile.TemporaryDirectory() as td:
-        for name, env in G6_ENVS:
+        procs = []
+        for name, env in G6_ENVS:      # (one child per environment, side by side: each is a single-threaded run)
             e = dict(os.environ)
             e.update(env)
             path = os.path.join(td, name + ".npz")
-            subprocess.check_call([sys.executable, os.path.abspath(__file__), "g6child", path], env=e)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "g6child", path], env=e))
+        for p_ in procs:
+            if p_.wait() != 0:
+                raise RuntimeError("g6 child failed")
+        for name, env in G6_ENVS:
+            path = os.path.join(td, name + ".npz")
             d = np.load(path)
             for key in d.files:
                 out[f"{name}__{key}"] = d[key]
