@@ -9,8 +9,8 @@ bench.py -- trajectories/sec of the batched replan inner loop on MI355X (BASELIN
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set for each, rendezvous on 127.0.0.1) before anything touches a GPU.
 
 Workload (config.workload): BASELINE.json configs[1] -- per GPU one 300^3-voxel fp32 ESDF of a synthetic
-random-forest scene (pillars + floating canopy boxes) resident in HBM in the yz-quad layout
-(NEO_LAYOUT_YZ4: the 8 corners of a trilinear cell in 32 contiguous bytes, 432 MB), and request batches of
+random-forest scene (pillars + floating canopy boxes) resident in HBM in the corner-brick layout
+(NEO_LAYOUT_BRICK: one 128-byte line per block of 2 x 2 x 2 trilinear cells holding its 27 corners, 432 MB), and request batches of
 B = 4096 replans with 20 intermediate waypoints (M = 21 pieces, D = 3, n = 81 variables) whose starts, goals and
 waypoints fill the volume (synth.VOLUME: heights 1..25 m, climbing and descending paths).  One launch optimises one
 batch of 4096 from its initial guess to L-BFGS-B termination (neo_optimize_batch_dev), inputs already in HBM.
@@ -93,11 +93,25 @@ GATHER_LINE_ROOFLINE_GBPS = 7020.0
 
 
 def hbm_traffic(pm):
-    """bytes the L2 moved to and from the fabric (HBM / Infinity Cache) per launch: 2 x FETCH_SIZE + WRITE_SIZE, counters
-    in KB (the gfx950 correction of MI355X_MICROARCH.md, checked for this access shape by tools/gpu_gather_calib.py)"""
-    if "FETCH_SIZE" not in pm or "WRITE_SIZE" not in pm:
+    """bytes the L2 moved to and from the fabric (HBM / Infinity Cache) per launch.  From the L2's own read requests by
+    size when the profile has them (32 n32 + 64 n64 + 128 n128: exact for every launch shape); otherwise 2 x FETCH_SIZE
+    -- the gfx950 correction of MI355X_MICROARCH.md, calibrated for large streaming / gather launches
+    (profiles/r03_gather_calib.json; small grids read ~0.9 x there, so the rule is recorded in `traffic_rule`)."""
+    if "WRITE_SIZE" not in pm:
+        return None
+    if "TCC_EA0_RDREQ_128B_sum" in pm and "TCC_EA0_RDREQ_sum" in pm:
+        n128, n64, n32 = pm["TCC_EA0_RDREQ_128B_sum"], pm.get("TCC_EA0_RDREQ_64B_sum", 0.0), pm.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+        return 128.0 * n128 + 64.0 * n64 + 32.0 * n32 + pm["WRITE_SIZE"] * 1024.0
+    if "FETCH_SIZE" not in pm:
         return None
     return (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
+
+
+def traffic_rule(pm):
+    if "WRITE_SIZE" not in pm:
+        return None
+    return ("32/64/128-byte L2 read requests (TCC_EA0_RDREQ_*) + WRITE_SIZE" if "TCC_EA0_RDREQ_128B_sum" in pm
+            else "2 x FETCH_SIZE + WRITE_SIZE (large-launch calibration)")
 
 
 def l2_hit(pm):
@@ -118,12 +132,17 @@ def parse(argv=None):
     ap.add_argument("--grid", type=int, default=300)
     ap.add_argument("--dtype", default="f32x", choices=["f32", "f64", "f32x"],
                     help="f32: fp32 sampled terms, fp64 solve and optimiser; f64: the parity mode; f32x: everything in fp32")
-    ap.add_argument("--layout", default="yz4", choices=["linear", "yz4", "cell8", "brick"],
-                    help="voxel order of the field in HBM (include/neo_planner.h NEO_LAYOUT_*); yz4 = one line per lookup")
+    ap.add_argument("--layout", default="brick", choices=["linear", "yz4", "cell8", "brick"],
+                    help="voxel order of the field in HBM (include/neo_planner.h NEO_LAYOUT_*); brick = one 128-byte line per block "
+                         "of 2 x 2 x 2 cells (default since round 4), yz4 = the round-2/3 default: one line per 8 cells along x")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall budget of the NumPy-port sample")
     ap.add_argument("--native-seconds", type=float, default=4.0, help="wall budget of each cpu_native run")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-retries", action="store_true", help="skip the warm_start_plan retry-chain measurement")
     ap.add_argument("--no-modes", action="store_true", help="time only the --dtype mode (cfg2 on one GPU times all three)")
+    ap.add_argument("--esdf-order", default="spatial", choices=["spatial", "index"],
+                    help="dispatch order of the stand-alone ESDF-lookup kernel: XCD-aware spatial order "
+                         "(BatchPlanner.spatial_order) or index order; the other one is timed beside it")
     ap.add_argument("--planar", action="store_true", help="round-1 workload: every request in the plane z = 2 m, no canopy")
     ap.add_argument("--no-order", action="store_true", help="dispatch trajectories in index order")
     ap.add_argument("--lane-groups", action="store_true",
@@ -256,6 +275,8 @@ def cpu_leg(workdir):
         per_core_single=nat_single, mean_nfev=float(base["nfev"][sel].mean()),
         sample=f"{len(sel)} trajectories of batch 0, {dt:.1f} s wall on {cores} threads; oracle/cpu_native: C++ fp64, the "
                "reference's banded 6M x 6M system and per-sample loops, L-BFGS-B control flow of csrc/neo_lbfgs.hpp")
+    out["cpu_native"]["status_hist"] = np.bincount(base["status"][sel] & 0xff, minlength=7).tolist()
+    out["cpu_native"]["collision_flag_frac"] = float(((base["status"][sel] & 0x100) != 0).mean())
     w = np.asarray(cfgp.weights)
     nq = D * (M - 1)
     arrays["nat_idx"] = sel
@@ -279,7 +300,9 @@ def cpu_leg(workdir):
         c1 = (o["costs_last"] * w).sum(axis=1)
         relc = np.abs(c1 - c0) / np.maximum(np.abs(c0), 1e-12)
         dx = np.abs(o["x"][:, :nq] - arrays["nat_wp"]).max(axis=1) / np.maximum(np.abs(arrays["nat_wp"]).max(axis=1), 1e-12)
-        return dict(n=int(len(sel)), what=name, frac_same_nfev=float((o["nfev"] == arrays["nat_nfev"]).mean()),
+        return dict(n=int(len(sel)), what=name, status_hist=np.bincount(o["status"] & 0xff, minlength=7).tolist(),
+                    collision_flag_frac=float(((o["status"] & 0x100) != 0).mean()),
+                    frac_same_nfev=float((o["nfev"] == arrays["nat_nfev"]).mean()),
                     control_points_frac_within_1e_4=float((dx <= 1e-4).mean()), control_points_rel_median=float(np.median(dx)),
                     final_cost_frac_within_1e_4=float((relc <= 1e-4).mean()), final_cost_rel_median=float(np.median(relc)))
     out["parity_control"] = dict(
@@ -397,6 +420,13 @@ def main():
     a = parse(argv)
     if a.cpu_leg:
         return cpu_leg(a.cpu_leg)
+    if a.gpus > 1 and not a.dry_run and not a.share_gpu and a.dist_backend == "nccl":
+        # fail before anything touches a GPU (device_count() does not initialise HIP on this image), with one line
+        import torch
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            print(f"bench.py: --gpus {a.gpus} asked for, {have} GPU(s) visible on this node: nothing was run", file=sys.stderr)
+            sys.exit(3)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a, argv))
     rank = int(os.environ.get("RANK", "0"))
@@ -426,7 +456,7 @@ def main():
     M, D, B = a.waypoints + 1, 3, a.batch
     n = D * (M - 1) + M
     default_workload = (a.config == "cfg2" and a.batch == 4096 and a.waypoints == 20 and a.grid == 300
-                        and a.dtype == "f32x" and a.layout == "yz4" and not a.planar)
+                        and a.dtype == "f32x" and a.layout == "brick" and not a.planar)
     # one GPU, cfg2: all three arithmetic modes are timed under the same protocol
     modes = [a.dtype] + ([m_ for m_ in ("f32x", "f32", "f64") if m_ != a.dtype]
                          if (a.config == "cfg2" and world == 1 and not a.no_modes) else [])
@@ -626,6 +656,20 @@ def main():
         launches = ctypes.c_int64()
         kms = ctypes.c_double()
         ctx.check(ctx.lib.neo_profile_read(ctx.h, _lib.NEO_KERNEL_OPTIMIZE, ctypes.byref(launches), ctypes.byref(kms)))
+        # one launch ALONE on the chip (outside the timed region): what a caller with a single request batch gets -- with
+        # `--streams` launches in flight each one lasts longer than it would by itself
+        solo = None
+        if rank == 0 and not use_dist:
+            ctx.check(ctx.lib.neo_profile_reset(ctx.h))
+            ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
+            for _ in range(3):
+                launch(batches[0], bpm)
+                fence()
+            ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
+            ctx.set_stream(None)
+            l_s = ctypes.c_int64(); m_s = ctypes.c_double()
+            ctx.check(ctx.lib.neo_profile_read(ctx.h, _lib.NEO_KERNEL_OPTIMIZE, ctypes.byref(l_s), ctypes.byref(m_s)))
+            solo = m_s.value / max(l_s.value, 1)
         nfev_all = torch.stack([bt["nfev"] for bt in batches]).cpu().numpy().astype(np.int64)
         nsamp_all = torch.stack([bt["nsamp"] for bt in batches]).cpu().numpy()
         status_all = torch.stack([bt["status"] for bt in batches]).cpu().numpy()
@@ -636,7 +680,7 @@ def main():
         # algorithmic bytes of ONE launch, mean over the step's batches: S*C*e per evaluation + 2*n*4 + 20
         bytes_launch = (float(nsamp_all.sum()) * 8 * esz + float(nfev_all.sum()) * (2 * n * 4 + 20)) / n_sets
         b0_ = batches[0]
-        return dict(mode=mode, elapsed=el, kernel_ms=kernel_ms, launches=int(launches.value), nfev_all=nfev_all,
+        return dict(mode=mode, elapsed=el, kernel_ms=kernel_ms, launches=int(launches.value), nfev_all=nfev_all, solo_ms=solo,
                     nsamp_all=nsamp_all, status_all=status_all, accepted_frac=float(accepted.mean()),
                     bytes_launch=bytes_launch, mean_nit=float(b0_["nit"].float().mean().item()),
                     b0=dict(x=b0_["x"].clone(), last=b0_["last"].clone(), nfev=b0_["nfev"].clone()))
@@ -668,26 +712,90 @@ def main():
         got = torch.stack([bt["gathered"][r_ * B:(r_ + 1) * B].double().nan_to_num().sum() for r_ in range(world)]).to(cdev)
         gather_ok = bool(torch.equal(mine.view(torch.int32), bt["packed"].view(torch.int32)) and torch.equal(got, sums))
     mode_runs = {a.dtype: main_run}
-    # one launch ALONE on the chip (outside the timed region): with `--streams` launches in flight each one lasts longer than
-    # it would by itself, which the per-launch roofline figure of the contract carries; this is the undisturbed duration
-    solo_ms = None
-    if rank == 0 and not use_dist:
-        bp._sync()
-        fence()
-        ctx.check(ctx.lib.neo_profile_reset(ctx.h))
-        ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
-        for _ in range(3):
-            launch(batches[0], bp)
-            fence()
-        ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
-        ctx.set_stream(None)
-        l_s = ctypes.c_int64(); m_s = ctypes.c_double()
-        ctx.check(ctx.lib.neo_profile_read(ctx.h, _lib.NEO_KERNEL_OPTIMIZE, ctypes.byref(l_s), ctypes.byref(m_s)))
-        solo_ms = m_s.value / max(l_s.value, 1)
+    solo_ms = main_run["solo_ms"]
     for m_ in modes[1:]:
         mode_runs[m_] = time_mode(m_)
     bp._sync()
 
+    # ---- the reference's ACCEPTED result is warm_start_plan's: up to five plan_once attempts, the failed ones re-seeded
+    # with N(0, 0.5) jitter (expert_planner.py:186-203); `value` counts first attempts.  Here the whole chain is timed
+    # under the same protocol: per request batch the first launch of B trajectories, then the compacted re-launches of
+    # the requests that failed (BatchPlanner.plan's chain).  Which requests fail, and their re-seeded guesses, are found in
+    # an untimed pass (a caller learns them from the status array between launches); the timed region replays every
+    # launch of the chain, first attempts included, `--streams` batches in flight.
+    retries = None
+    if rank == 0 and not use_dist and a.config == "cfg2" and init is None and n_scenes == 1 and not a.no_retries:
+        bp._sync()
+        fence()
+        failed_of = lambda st_: ((st_ & 0xff) > 3) | ((st_ & 0x100) != 0)
+        chains = []
+        solved_total, attempts_sum = 0, 0
+        t_prep = time.time()
+        for r_, bt in enumerate(batches):
+            launch(bt, bp)
+        fence()
+        for r_, bt in enumerate(batches):
+            h_, t_, wp_, ts_ = sets[r_]
+            st_ = bt["status"].cpu().numpy()
+            todo = np.flatnonzero(failed_of(st_))
+            attempts = np.ones(B, dtype=np.int64)
+            chain = []
+            for att in range(1, 5):
+                if todo.size == 0:
+                    break
+                wp_n, ts_n = bp.init_guess(h_[todo], t_[todo], M - 1)
+                noise = np.stack([np.random.default_rng([20260, r_, int(i), att]).normal(0.0, 0.5, (D, M - 1)) for i in todo])
+                nb_ = int(todo.size)
+                with torch.cuda.stream(bt["st"]):
+                    e_ = dict(B=nb_, x0=torch.from_numpy(bp.pack_x(wp_n + noise, ts_n)).to(dev),
+                              head=torch.from_numpy(np.ascontiguousarray(h_[todo])).to(dev),
+                              tail=torch.from_numpy(np.ascontiguousarray(t_[todo])).to(dev),
+                              costs=torch.zeros(nb_, 4, dtype=torch.float64, device=dev), last=torch.zeros(nb_, 4, dtype=torch.float64, device=dev),
+                              nit=torch.zeros(nb_, dtype=torch.int32, device=dev), nfev=torch.zeros(nb_, dtype=torch.int32, device=dev),
+                              status=torch.zeros(nb_, dtype=torch.int32, device=dev), nsamp=torch.zeros(nb_, dtype=torch.int64, device=dev))
+                    e_["x"] = torch.empty_like(e_["x0"])
+                chain.append(e_)
+                ctx.set_stream(bt["st"].cuda_stream)
+                ctx.check(ctx.lib.neo_optimize_sample_counter(ctx.h, ctypes.c_void_p(e_["nsamp"].data_ptr())))
+                with torch.cuda.stream(bt["st"]):
+                    bp.optimize_dev(g3, e_["x"], e_["head"], e_["tail"], e_["costs"], e_["last"], e_["nit"], e_["nfev"], e_["status"], x0=e_["x0"])
+                bt["st"].synchronize()
+                attempts[todo] += 1
+                todo = todo[failed_of(e_["status"].cpu().numpy())]
+            chains.append(chain)
+            solved_total += B - int(todo.size)
+            attempts_sum += int(attempts.sum())
+        prep_s = time.time() - t_prep
+
+        def chain_step():
+            for bt, chain in zip(batches, chains):
+                launch(bt, bp)
+                for e_ in chain:
+                    ctx.check(ctx.lib.neo_optimize_sample_counter(ctx.h, ctypes.c_void_p(e_["nsamp"].data_ptr())))
+                    with torch.cuda.stream(bt["st"]):
+                        bp.optimize_dev(g3, e_["x"], e_["head"], e_["tail"], e_["costs"], e_["last"], e_["nit"], e_["nfev"],
+                                        e_["status"], x0=e_["x0"])
+        fence()
+        chain_step()
+        fence()
+        k_steps = max(2, a.steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(k_steps):
+            chain_step()
+        fence()
+        el_r = time.perf_counter() - t0
+        ctx.set_stream(None)
+        n_req = B * n_sets
+        retries = {"what": "warm_start_plan for every request (expert_planner.py:186-203): first launch of every batch plus the compacted "
+                           "re-launches of its failed requests (OverflowError statuses or `collision cost too large`), re-seeded "
+                           "straight line + N(0, 0.5), at most 5 attempts; all launches of the chain inside the timed region, "
+                           f"{n_lanes} batches in flight; the failed sets and their re-seeded guesses come from an untimed pass",
+                   "max_attempts": 5, "steps": k_steps, "ms_per_step": 1e3 * el_r / k_steps,
+                   "requests_per_s": n_req * k_steps / el_r,
+                   "accepted_after_retries_traj_per_s": solved_total * k_steps / el_r,
+                   "accepted_frac_first_attempt": main_run["accepted_frac"], "accepted_frac_after_retries": solved_total / n_req,
+                   "mean_attempts": attempts_sum / n_req, "launches_per_step": n_sets + sum(len(c_) for c_ in chains),
+                   "retry_trajectories_per_step": int(sum(e_["B"] for c_ in chains for e_ in c_)), "untimed_preparation_s": prep_s}
     kernel_ms = main_run["kernel_ms"]
     launches = ctypes.c_int64(main_run["launches"])
     pp = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -703,24 +811,6 @@ def main():
         st1 = torch.zeros(B, dtype=torch.int32, device=dev)
         ctx.check(ctx.lib.neo_cost_grad_batch_dev(ctx.h, g3.scene_id, B, M, D, pp(b0["x0"]), pp(b0["head"]), pp(b0["tail"]),
                                                   pp(cost1), pp(c4), pp(grad1), pp(coeffs), pp(st1)))
-        d_ts = torch.from_numpy(np.ascontiguousarray(ts)).to(dev)
-        c2 = torch.zeros(B, 2, dtype=torch.float64, device=dev)
-        gC = torch.zeros_like(coeffs)
-        gT = torch.zeros(B, M, dtype=torch.float64, device=dev)
-        run = lambda: ctx.check(ctx.lib.neo_sampled_terms_batch_dev(ctx.h, g3.scene_id, B, M, D, pp(coeffs), pp(d_ts),
-                                                                    pp(c2), pp(gC), pp(gT)))
-        for _ in range(5):
-            run()
-        torch.cuda.synchronize()
-        ctx.check(ctx.lib.neo_profile_reset(ctx.h))
-        ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
-        for _ in range(50):
-            run()
-        torch.cuda.synchronize()
-        ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
-        l2 = ctypes.c_int64(); m2 = ctypes.c_double()
-        ctx.check(ctx.lib.neo_profile_read(ctx.h, _lib.NEO_KERNEL_ESDF_SAMPLE, ctypes.byref(l2), ctypes.byref(m2)))
-        us = 1e3 * m2.value / max(l2.value, 1)
         ns_piece = np.floor(ts / bp.cfg.delta_t).astype(np.int64)
         n_samples = int(ns_piece.sum())
         esz = 4 if store == "f32" else 2
@@ -729,7 +819,7 @@ def main():
         # ... or with what this stand-alone kernel really moves besides the field: fp64 coefficients in, their
         # partials out, durations in / partials out, 2 cost terms
         by_ops = n_samples * 8.0 * esz + B * (2 * 6 * M * D * 8 + 2 * M * 8 + 16)
-        # footprint of the field: distinct 128-byte lines the launch's lookups touch
+        # footprint of the field: distinct 128-byte lines the launch's lookups touch (linear voxel order)
         cf = coeffs.cpu().numpy().reshape(B, M, 6, D)
         jmax = int(ns_piece.max())
         tj = (np.arange(jmax) * bp.cfg.delta_t)[None, None, :]                                   # [1,1,J]
@@ -745,28 +835,10 @@ def main():
                 for dx in (0, 1):
                     ids.append((((i0[:, 2] + dz) * a.grid + i0[:, 1] + dy) * a.grid + i0[:, 0] + dx) * esz // 128)
         footprint = int(np.unique(np.concatenate(ids)).size) * 128
-        pm_s, src_s = pmc_profile(f"sample_kernel@{B}", default_workload)
-        esdf = {"kernel": "sample_kernel", "bound": "hbm", "achieved": by_8d2 / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": by_8d2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                "frac_8d2": by_8d2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                "frac_with_operands": by_ops / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                "kernel_us": us, "launches": int(l2.value), "samples_per_launch": n_samples,
-                "algorithmic_bytes_per_launch": by_8d2, "bytes_per_launch_with_operands": by_ops,
-                "lookups_per_s": n_samples / (us * 1e-6),
-                "esdf_footprint_bytes": footprint, "esdf_bytes": a.grid ** 3 * esz,
-                "traffic": hbm_traffic(pm_s), "l2_hit_rate": l2_hit(pm_s), "traffic_source": src_s}
-        if esdf["traffic"]:
-            # the kernel against what it really moves: 128-byte lines for 32-byte lookups
-            esdf["traffic_GBps"] = esdf["traffic"] / (us * 1e-6) / 1e9
-            esdf["frac_traffic_of_hbm_peak"] = esdf["traffic_GBps"] / HBM_PEAK_GBPS
-            esdf["frac_traffic_of_gather_roofline"] = esdf["traffic_GBps"] / GATHER_LINE_ROOFLINE_GBPS
-            esdf["gather_roofline"] = {"GBps_of_128B_lines": GATHER_LINE_ROOFLINE_GBPS, "source": "profiles/r03_gather_calib.json",
-                                       "what": "random 32-byte lookups (two adjacent 16-byte loads per lane) over a 432 MB buffer, "
-                                               "the rate the chip sustains for this access shape"}
-            esdf["lookups_per_fetched_line"] = n_samples / max(pm_s.get("FETCH_SIZE", 0) * 1024.0 * 2 / 128, 1.0)
-        # the same kernel over ALL request batches of a step in one launch (n_sets * B trajectories): with more
-        # wavefronts than the chip holds at once the launch is bound by throughput, not by the run time of one wavefront
-        if n_sets > 1 and init is None:
+        l2 = ctypes.c_int64(); m2 = ctypes.c_double()
+        whole = n_sets > 1 and init is None
+        coeffs_a = d_ts_a = None
+        if whole:
             Ba = B * n_sets
             coeffs_a = torch.zeros(Ba, 6 * M, D, dtype=torch.float64, device=dev)
             for r_, bt in enumerate(batches):
@@ -774,37 +846,103 @@ def main():
                                                           pp(bt["tail"]), pp(cost1), pp(c4), pp(grad1),
                                                           pp(coeffs_a[r_ * B:(r_ + 1) * B]), pp(st1)))
             ts_a = np.ascontiguousarray(np.concatenate([st_[3] for st_ in sets], axis=0))
+            head_a = np.concatenate([st_[0] for st_ in sets]); tail_a = np.concatenate([st_[1] for st_ in sets])
             d_ts_a = torch.from_numpy(ts_a).to(dev)
-            c2a = torch.zeros(Ba, 2, dtype=torch.float64, device=dev)
-            gCa = torch.zeros_like(coeffs_a)
-            gTa = torch.zeros(Ba, M, dtype=torch.float64, device=dev)
-            run_a = lambda: ctx.check(ctx.lib.neo_sampled_terms_batch_dev(ctx.h, g3.scene_id, Ba, M, D, pp(coeffs_a),
-                                                                          pp(d_ts_a), pp(c2a), pp(gCa), pp(gTa)))
+            ns_a = int(np.floor(ts_a / bp.cfg.delta_t).astype(np.int64).sum())
+            by_a = ns_a * 8.0 * esz + Ba * (2 * n * 4 + 20)
+        d_ts = torch.from_numpy(np.ascontiguousarray(ts)).to(dev)
+
+        def time_sample(scene, nb, co, dts, order_np, reps):
+            """mean launch duration (HIP events on the kernel's stream) of sample_kernel over nb trajectories"""
+            c2 = torch.zeros(nb, 2, dtype=torch.float64, device=dev)
+            gC = torch.zeros(nb, 6 * M, D, dtype=torch.float64, device=dev)
+            gT = torch.zeros(nb, M, dtype=torch.float64, device=dev)
+            od = torch.from_numpy(order_np).to(dev) if order_np is not None else None
+            ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, pp(od) if od is not None else None, nb))
+            run = lambda: ctx.check(ctx.lib.neo_sampled_terms_batch_dev(ctx.h, scene, nb, M, D, pp(co), pp(dts), pp(c2), pp(gC), pp(gT)))
             for _ in range(3):
-                run_a()
+                run()
             torch.cuda.synchronize()
             ctx.check(ctx.lib.neo_profile_reset(ctx.h))
             ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
-            for _ in range(20):
-                run_a()
+            for _ in range(reps):
+                run()
             torch.cuda.synchronize()
             ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
             ctx.check(ctx.lib.neo_profile_read(ctx.h, _lib.NEO_KERNEL_ESDF_SAMPLE, ctypes.byref(l2), ctypes.byref(m2)))
-            us_a = 1e3 * m2.value / max(l2.value, 1)
-            ns_a = int(np.floor(ts_a / bp.cfg.delta_t).astype(np.int64).sum())
-            by_a = ns_a * 8.0 * esz + Ba * (2 * n * 4 + 20)
-            esdf["whole_step_launch"] = {"trajectories": Ba, "kernel_us": us_a, "launches": int(l2.value),
-                                         "samples_per_launch": ns_a, "algorithmic_bytes_per_launch": by_a,
-                                         "achieved": by_a / (us_a * 1e-6) / 1e9,
-                                         "frac_8d2": by_a / (us_a * 1e-6) / 1e9 / HBM_PEAK_GBPS}
-            pm_a, src_a = pmc_profile(f"sample_kernel@{Ba}", default_workload)
-            if src_a and src_a != src_s or (pm_a and pm_a != pm_s):
-                tr_a = hbm_traffic(pm_a)
-                esdf["whole_step_launch"].update(traffic=tr_a, l2_hit_rate=l2_hit(pm_a), traffic_source=src_a)
-                if tr_a:
-                    esdf["whole_step_launch"].update(
-                        traffic_GBps=tr_a / (us_a * 1e-6) / 1e9, frac_traffic_of_hbm_peak=tr_a / (us_a * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                        frac_traffic_of_gather_roofline=tr_a / (us_a * 1e-6) / 1e9 / GATHER_LINE_ROOFLINE_GBPS)
+            ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, None, 0))
+            return 1e3 * m2.value / max(l2.value, 1), int(l2.value), (c2, gC, gT)
+
+        def esdf_block(scene, layout_name, default_wl):
+            """the ESDF-lookup kernel on one field: the 4096-trajectory launch and the launch over every request batch of a
+            step, in the chosen dispatch order, the other order timed beside it (same bits either way: checked)"""
+            orders = {"index": None, "spatial": npa.BatchPlanner.spatial_order(head, tail)}
+            other = "index" if a.esdf_order == "spatial" else "spatial"
+            us, nl, out_main = time_sample(scene, B, coeffs, d_ts, orders[a.esdf_order], 50)
+            us_o, _, out_o = time_sample(scene, B, coeffs, d_ts, orders[other], 20)
+            same = all(torch.equal(x_, y_) for x_, y_ in zip(out_main, out_o))
+            pm_s, src_s = pmc_profile(f"sample_kernel@{B}", default_wl)
+            e = {"kernel": "sample_kernel", "layout": layout_name, "dispatch_order": a.esdf_order, "bound": "hbm",
+                 "achieved": by_8d2 / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
+                 "unit": "GB/s", "frac": by_8d2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                 "frac_8d2": by_8d2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                 "frac_with_operands": by_ops / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                 "kernel_us": us, "launches": nl, f"kernel_us_{other}_order": us_o, "orders_give_the_same_bits": bool(same),
+                 "samples_per_launch": n_samples,
+                 "algorithmic_bytes_per_launch": by_8d2, "bytes_per_launch_with_operands": by_ops,
+                 "lookups_per_s": n_samples / (us * 1e-6),
+                 "esdf_footprint_bytes": footprint, "esdf_bytes": a.grid ** 3 * esz,
+                 "traffic": hbm_traffic(pm_s), "l2_hit_rate": l2_hit(pm_s), "traffic_source": src_s, "traffic_rule": traffic_rule(pm_s)}
+            if e["traffic"]:
+                # the kernel against what it really moves: 128-byte lines for 32-byte lookups
+                e["traffic_GBps"] = e["traffic"] / (us * 1e-6) / 1e9
+                e["traffic_over_algorithmic"] = e["traffic"] / by_8d2
+                e["frac_traffic_of_hbm_peak"] = e["traffic_GBps"] / HBM_PEAK_GBPS
+                e["frac_traffic_of_gather_roofline"] = e["traffic_GBps"] / GATHER_LINE_ROOFLINE_GBPS
+                e["gather_roofline"] = {"GBps_of_128B_lines": GATHER_LINE_ROOFLINE_GBPS, "source": "profiles/r03_gather_calib.json",
+                                        "what": "random 32-byte lookups (two adjacent 16-byte loads per lane) over a 432 MB buffer, "
+                                                "the rate the chip sustains for this access shape"}
+                lines = pm_s.get("TCC_EA0_RDREQ_128B_sum") or (pm_s.get("FETCH_SIZE", 0) * 1024.0 * 2 / 128)
+                e["lookups_per_fetched_line"] = n_samples / max(lines, 1.0)
+            # the same kernel over ALL request batches of a step in one launch (n_sets * B trajectories): with more
+            # wavefronts than the chip holds at once the launch is bound by throughput, not by the run time of one wavefront
+            if whole:
+                orders_a = {"index": None, "spatial": npa.BatchPlanner.spatial_order(head_a, tail_a)}
+                us_a, nl_a, _ = time_sample(scene, Ba, coeffs_a, d_ts_a, orders_a[a.esdf_order], 20)
+                us_ao, _, _ = time_sample(scene, Ba, coeffs_a, d_ts_a, orders_a[other], 8)
+                w_ = {"trajectories": Ba, "kernel_us": us_a, "launches": nl_a, f"kernel_us_{other}_order": us_ao,
+                      "dispatch_order": a.esdf_order, "samples_per_launch": ns_a, "algorithmic_bytes_per_launch": by_a,
+                      "achieved": by_a / (us_a * 1e-6) / 1e9, "frac_8d2": by_a / (us_a * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+                pm_a, src_a = pmc_profile(f"sample_kernel@{Ba}", default_wl)
+                if pm_a and (src_a != src_s or pm_a != pm_s):
+                    tr_a = hbm_traffic(pm_a)
+                    w_.update(traffic=tr_a, l2_hit_rate=l2_hit(pm_a), traffic_source=src_a, traffic_rule=traffic_rule(pm_a))
+                    if tr_a:
+                        lines_a = pm_a.get("TCC_EA0_RDREQ_128B_sum") or (pm_a.get("FETCH_SIZE", 0) * 1024.0 * 2 / 128)
+                        w_.update(traffic_GBps=tr_a / (us_a * 1e-6) / 1e9, traffic_over_algorithmic=tr_a / by_a,
+                                  lookups_per_fetched_line=ns_a / max(lines_a, 1.0),
+                                  frac_traffic_of_hbm_peak=tr_a / (us_a * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                  frac_traffic_of_gather_roofline=tr_a / (us_a * 1e-6) / 1e9 / GATHER_LINE_ROOFLINE_GBPS)
+                e["whole_step_launch"] = w_
+            return e
+
+        esdf = esdf_block(g3.scene_id, a.layout, default_workload)
+        if a.layout != "brick" and a.config in ("cfg2", "cfg5") and not a.planar:
+            # the same launches on the corner-brick layout of the same field (NEO_LAYOUT_BRICK: a 128-byte line per block of
+            # 2 x 2 x 2 cells): fewer lines per path -- counters: profiles/r04_*_pmc_esdf_locality_*.json
+            d_occ2 = torch.from_numpy(occ).to(dev)
+            gb = npa.ESDF3D.from_occupancy(d_occ2, res, synth.DOMAIN_ORIGIN, store=store, layout="brick", ctx=ctx)
+            del d_occ2
+            eb = esdf_block(gb.scene_id, "brick", False)
+            esdf["brick_layout"] = {k: eb[k] for k in ("layout", "dispatch_order", "kernel_us", "frac_8d2", "frac_with_operands",
+                                                       "lookups_per_s", "orders_give_the_same_bits") if k in eb}
+            esdf["brick_layout"].update({k: v for k, v in eb.items() if k.startswith("kernel_us_")})
+            if "whole_step_launch" in eb:
+                esdf["brick_layout"]["whole_step_launch"] = {k: v for k, v in eb["whole_step_launch"].items()
+                                                             if k in ("trajectories", "kernel_us", "frac_8d2", "dispatch_order")
+                                                             or k.startswith("kernel_us_")}
+            ctx.check(ctx.lib.neo_esdf_drop(ctx.h, gb.scene_id))
+            bp._sync()
     nfev_all, nsamp_all, status_all = main_run["nfev_all"], main_run["nsamp_all"], main_run["status_all"]
     status_h = status_all[0]
     bytes_launch = main_run["bytes_launch"]
@@ -818,6 +956,8 @@ def main():
         ach = r_["bytes_launch"] / (r_["kernel_ms"] * 1e-3) / 1e9
         return {"value": v_, "unit": "traj/s", "ms_per_step": 1e3 * r_["elapsed"] / a.steps,
                 "accepted_frac": r_["accepted_frac"], "accepted_traj_per_s": v_ * r_["accepted_frac"],
+                "single_batch_ms": r_["solo_ms"],
+                "single_batch_traj_per_s": (B / (r_["solo_ms"] * 1e-3)) if r_["solo_ms"] else None,
                 "kernel_ms": r_["kernel_ms"], "roofline_frac": ach / HBM_PEAK_GBPS,
                 "roofline_frac_aggregate": r_["bytes_launch"] * n_sets * a.steps / r_["elapsed"] / 1e9 / HBM_PEAK_GBPS,
                 "mean_nfev": float(r_["nfev_all"].mean()), "max_nfev": int(r_["nfev_all"].max()),
@@ -872,6 +1012,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "accepted_traj_per_s": value * main_run["accepted_frac"], "accepted_frac": main_run["accepted_frac"],
+            # what a caller with ONE request batch gets: a single launch of B trajectories alone on the chip (`value` keeps
+            # `--streams` launches in flight and is the throughput figure)
+            "single_batch_ms": solo_ms, "single_batch_traj_per_s": (B / (solo_ms * 1e-3)) if solo_ms else None,
+            "accepted_after_retries": retries,
             "config": {"workload": f"{a.config}: request batches of B={B} trajectories x {M - 1} waypoints (M={M} pieces, D=3, "
                                    f"n={n}), {n_sets} batch(es) per step per GPU, {n_scenes} x {a.grid}^3 {store} ESDF per GPU "
                                    f"(trilinear, layout {a.layout}; " +
@@ -892,7 +1036,7 @@ def main():
                          "kernel": "optimize_group_kernel" if (a.lane_groups and M <= 16 and n <= 32 and a.layout != "cell8"
                                                                and a.dtype in ("f32", "f32x")) else "optimize_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": hbm_traffic(pm_o), "traffic_source": src_o,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": hbm_traffic(pm_o), "traffic_source": src_o, "traffic_rule": traffic_rule(pm_o),
                          "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes of this "
                                          "command (counter KB x 1024; the x 2 is MI355X_MICROARCH.md's gfx950 correction, confirmed "
                                          "for these 16-byte-per-lane gathers against TCC_EA0_RDREQ_128B: profiles/r03_gather_calib.json)",
@@ -960,6 +1104,38 @@ def main():
                 "tests/test_gpu_replay.py: every point every run of a 256-trajectory cfg2 batch evaluates is re-evaluated by "
                 "the fp64 CPU oracle (value 4e-5 / gradient 2e-4 in the all-fp32 mode, 2e-5 / 2e-4 mixed, 1e-10 / 1e-8 fp64) "
                 "and every L-BFGS-B decision is re-derived on the host from the recorded values; profiles/r03_replay_*.json")
+            # the three modes against the REFERENCE-GENERATED fixtures on the reference's own 2-D map (tools/ref_fixture_parity.py;
+            # thresholds: tests/test_gpu_reference_fixtures.py): G6 = 256 plan_once runs of M = 21, share of finals within 1e-4
+            # of the real reference's, beside the reference under another BLAS kernel set against itself
+            try:
+                sys.path.insert(0, os.path.join(REPO, "tools"))
+                import ref_fixture_parity as rfp
+                g6 = rfp.g6_report()
+                g1 = rfp.g1_report(with_reference_jump=False)
+                g3 = rfp.g3_summary(rfp.g3_report())
+                keep = ("n", "finals_within_1e_4", "finals_within_1e_2", "cost_within_1e_4", "cost_within_1e_2", "same_nfev",
+                        "x_rel_median", "cost_rel_median", "mean_nfev", "same_exception", "exceptions", "exits")
+                par["vs_reference_fixtures"] = {
+                    "what": g6["what"],
+                    "g6_finals_within_1e_4_of_the_reference": {m_: v_["finals_within_1e_4"] for m_, v_ in g6["device_vs_reference"].items()},
+                    "g6_reference_vs_itself_other_blas_kernels": g6["reference_vs_itself"]["self_agreement_min"],
+                    "g6": {"reference_vs_itself": g6["reference_vs_itself"],
+                           "device_vs_reference": {m_: {k_: v_[k_] for k_ in keep if k_ in v_} for m_, v_ in g6["device_vs_reference"].items()}},
+                    "g1_per_evaluation": {m_: {k_: v_[k_] for k_ in ("n", "tolerance", "within_tolerance", "cost_max", "cost_median",
+                                                                      "grad_max", "grad_median", "coeffs_max")} for m_, v_ in g1.items()},
+                    "g1_note": "evaluations beyond a mode's tolerance sit at discontinuities of the reference objective (nearest-cell "
+                               "faces, int(T / delta_t)): tests/test_gpu_reference_fixtures.py holds each to the reference's own jump there",
+                    "g3_recorded_runs": g3}
+                bp._sync()
+            except Exception as ex:       # (fixtures missing in a stripped checkout: say so, do not fail the bench line)
+                par["vs_reference_fixtures"] = {"error": f"{type(ex).__name__}: {ex}"}
+            # exit statuses side by side: GPU modes (modes.*.status_hist), cpu_native, each control
+            par["exit_status_hist"] = {"order": "CONVERGED_GRAD, CONVERGED_F, ABNORMAL, MAXITER, NUMERIC_RANGE, NONFINITE, BAD_SCENE",
+                                       "gpu": {m_: np.bincount(r_["status_all"][0] & 0xff, minlength=7).tolist() for m_, r_ in mode_runs.items()},
+                                       "cpu_native": cpu_out["cpu_native"].get("status_hist"),
+                                       "controls": {k_: v_.get("status_hist") for k_, v_ in cpu_out["parity_control"].items()},
+                                       "note": "GPU rows: batch 0 of the timed run (4096 runs); cpu_native and controls: the runs of "
+                                               "batch 0 the CPU finished inside its time budget"}
             par["control"] = cpu_out["parity_control"]
             par["reading"] = ("the objective is discontinuous (int(T/dt) sample counts): two faithful CPU implementations "
                               "part at the rates under `control`; the GPU rows are to be read against those, not against 1.0")

@@ -164,7 +164,9 @@ int neo_esdf_upload_3d(neo_ctx *ctx, int scene_id, const void *dist, int src_dty
 /* 3-D counterpart of neo_esdf_build_2d (esdf.py:23-29 in three dimensions): uint8 occupancy
  * [nz][ny][nx] (non-zero = occupied; host pointer, or device pointer when occ_is_device != 0) ->
  * exact Euclidean distance * resolution on the device, stored as for neo_esdf_upload_3d.
- * out_dist: optional HOST buffer [nz][ny][nx] float32 receiving the distances. */
+ * out_dist: optional HOST buffer [nz][ny][nx] float32 receiving the distances.
+ * Device memory: besides the stored field the build needs 10 bytes per voxel of intermediates (NEO_ERR_HIP if they do not
+ * fit); they are kept in the context for the next build while they are at most 512 MB and released otherwise. */
 int neo_esdf_build_3d(neo_ctx *ctx, int scene_id, const uint8_t *occupancy, int occ_is_device, int nx,
                       int ny, int nz, double resolution, const double origin[3], int store_dtype,
                       int layout, float *out_dist);

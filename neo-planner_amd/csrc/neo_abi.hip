@@ -977,7 +977,9 @@ int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_d
       const size_t rows = (size_t)ny * nz;
       hipLaunchKernelGGL(edt3_x_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 4 * (size_t)nx * sizeof(uint16_t),
                          c->stream, src, nx, rows, d_gx);
-      // tiles of at most 64 KB of LDS (4 bytes a voxel in the y pass, 6 in the z pass): TX x-columns by the whole line
+      // tiles of at most 64 KB of LDS INCLUDING the kernel's 2 KB of static part_best / part_arg (4 bytes a voxel in the y
+      // pass, 6 in the z pass): TX x-columns by the whole line
+      constexpr size_t kEdtTile = 65536 - 2 * 256 * sizeof(int);
       const size_t plane = (size_t)nx * ny;
 #define NEO_EDT_LINE(SRC, TXV, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd)                                 \
   hipLaunchKernelGGL((edt3_line_kernel<SRC, TXV, FINAL>), dim3((unsigned)((nx + TXV - 1) / TXV), (unsigned)(nslab)), \
@@ -988,9 +990,9 @@ int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_d
 #define NEO_EDT_PASS(SRC, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd)                             \
   if ((size_t)(nline) * 16 * (sizeof(SRC) == 2 ? 4 : 6) <= 40960)                                           \
     NEO_EDT_LINE(SRC, 16, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd);                             \
-  else if ((size_t)(nline) * 32 * 6 <= 65536) NEO_EDT_LINE(SRC, 32, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd); \
-  else if ((size_t)(nline) * 16 * 6 <= 65536) NEO_EDT_LINE(SRC, 16, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd); \
-  else if ((size_t)(nline) * 8 * 6 <= 65536) NEO_EDT_LINE(SRC, 8, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd);   \
+  else if ((size_t)(nline) * 32 * 6 <= kEdtTile) NEO_EDT_LINE(SRC, 32, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd); \
+  else if ((size_t)(nline) * 16 * 6 <= kEdtTile) NEO_EDT_LINE(SRC, 16, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd); \
+  else if ((size_t)(nline) * 8 * 6 <= kEdtTile) NEO_EDT_LINE(SRC, 8, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd);   \
   else NEO_EDT_LINE(SRC, 2, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd)
       // pass Y: lines along y (stride nx) in every z slab; pass Z: lines along z (stride nx * ny) for every y row
       NEO_EDT_PASS(uint16_t, false, d_gx, ny, (size_t)nx, plane, nz, d_sq, (float *)nullptr);
@@ -1002,7 +1004,17 @@ int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_d
     if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, d_dist_p, nvox * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  return neo_esdf_upload_3d(c, scene_id, d_dist_p, NEO_F32, 1, nx, ny, nz, res, origin, store_dtype, layout);
+  const int rc_up = neo_esdf_upload_3d(c, scene_id, d_dist_p, NEO_F32, 1, nx, ny, nz, res, origin, store_dtype, layout);
+  // the intermediates stay in the context's scratch for the next update of a scene of this size -- up to 512 MB (a 300^3
+  // scene: 270 MB); beyond that (600^3: 2.2 GB, 1000^3: 10 GB) they are released, a map build does not pin gigabytes of
+  // HBM for the lifetime of the context
+  if (c->scratch_bytes > ((size_t)512 << 20)) {
+    hipStreamSynchronize(c->stream);
+    hipFree(c->scratch);
+    c->scratch = nullptr;
+    c->scratch_bytes = 0;
+  }
+  return rc_up;
 }
 
 int neo_esdf_query(neo_ctx *c, int scene_id, int n, const double *pts, double *dist, double *grad) {

@@ -845,6 +845,8 @@ struct Traj {
   Num N[2][2];                 // pivot-block inverse of the joint system (lane = joint)
   const double *head, *tail;      // boundary states [3][D] in global memory (wave-uniform scalar loads)
   const Num *bnd;                 // lane = (piece, dimension) and lane groups: head [3][D] then tail [3][D] in LDS
+  Num *pcr_mult = nullptr;        // LDS [levels][M][8] + [M][4]: the multipliers of the forward cyclic reduction, kept for the
+                                  // adjoint pass (pcr_solve / pcr_solve_transposed); nullptr: the adjoint reduces K^T itself
 };
 
 // element (row k, dimension of this lane's local index dl) of the head (TAIL = false) or tail boundary state: a uniform
@@ -1029,9 +1031,12 @@ __device__ __forceinline__ void thomas_solve(int M, const Num (&Lo)[2][2], const
 // 1e-7 (tests/test_gpu_parity.py).  The fp64 modes keep block Thomas: their runs are pinned to its rounding.
 // In: L, Dg, U, R of joint p on the lanes of piece p (1 <= p <= M-1; boundary values already folded into R, L_1 = 0,
 // U_{M-1} = 0); other lanes are made identity rows here.  Out: y on those lanes.
+// `mult` (LDS, may be nullptr): when given, every level's multipliers a, g of every joint and the final pivot inverses are
+// written there -- [level][M][8] (negated) then [M][4] -- for pcr_solve_transposed: K^-1 = Dfin^-1 P_last ... P_1 with P_k = I + (a, g of
+// level k), hence K^-T = P_1^T ... P_last^T Dfin^-T, and the adjoint system K^T lambda = r needs no reduction of its own.
 template <int DL, class LG, typename Num>
 __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2], Num (&U)[2][2], Num (&R)[2][DL],
-                                          Num (&y)[2][DL]) {
+                                          Num (&y)[2][DL], Num *mult = nullptr) {
   static_assert(LG::W == kWave, "written for lane groups that span the wavefront");
   const int p = LG::piece();
   const bool in = p >= 1 && p < M;
@@ -1060,7 +1065,10 @@ __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2]
   // durations in [0.1, 5] s: <= 19, 4.8, 0.14, 8e-5, 6e-11 relative to the diagonal after levels 1 .. 5), so what a
   // sixth level (M > 33: cfg5) would eliminate is five orders below the rounding of the fp32 solve.
   const int s_end = sizeof(Num) == 4 ? min(M - 1, 32) : M - 1;
-  for (int s = 1; s < s_end; s <<= 1) {
+  typedef Num Quad __attribute__((ext_vector_type(4)));
+  const bool writer = mult != nullptr && in && LG::dim0() == 0;  // one lane per joint writes
+  int level = 0;
+  for (int s = 1; s < s_end; s <<= 1, ++level) {
     invert();
     // neighbours at distance s (lanes without one read themselves: their coupling block is zero by then)
     const int lp = lane - s * LG::S, ln = lane + s * LG::S;
@@ -1096,6 +1104,12 @@ __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2]
         a[i][j] = -fma(L[i][0], Ip[0][j], L[i][1] * Ip[1][j]);
         g[i][j] = -fma(U[i][0], In[0][j], U[i][1] * In[1][j]);
       }
+    if (writer) {
+      Quad *dst = reinterpret_cast<Quad *>(mult + ((size_t)level * M + p) * 8);
+      // (stored NEGATED: a and g are formed as -(...), and the products themselves are what sits in registers)
+      dst[0] = Quad{-a[0][0], -a[0][1], -a[1][0], -a[1][1]};
+      dst[1] = Quad{-g[0][0], -g[0][1], -g[1][0], -g[1][1]};
+    }
     Num Ln2[2][2], Un2[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1121,10 +1135,70 @@ __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2]
       }
   }
   invert();
+  if (writer) *reinterpret_cast<Quad *>(mult + (size_t)level * M * 8 + (size_t)p * 4) = Quad{I[0][0], I[0][1], I[1][0], I[1][1]};
 #pragma unroll
   for (int d = 0; d < DL; ++d) {
     y[0][d] = fma(I[0][0], R[0][d], I[0][1] * R[1][d]);
     y[1][d] = fma(I[1][0], R[0][d], I[1][1] * R[1][d]);
+  }
+}
+
+// levels pcr_solve runs for M pieces (the loop above), and the LDS floats its multipliers take
+__host__ __device__ __forceinline__ int pcr_levels(int M, bool f32 = true) {
+  const int s_end = f32 ? (M - 1 < 32 ? M - 1 : 32) : M - 1;
+  int n = 0;
+  for (int s = 1; s < s_end; s <<= 1) ++n;
+  return n;
+}
+__host__ __device__ __forceinline__ int pcr_mult_elems(int M) { return (pcr_levels(M) * 8 + 4) * M; }
+
+// The adjoint system K^T lambda = r from the multipliers pcr_solve left in `mult`:
+//     lambda = P_1^T ... P_last^T (Dfin^-T r),     (P_k^T w)_j = w_j + a_{j+s}^T w_{j+s} + g_{j-s}^T w_{j-s},   s = 2^k.
+// A level is two 16-byte LDS reads, eight multiply-adds and 4 DL neighbour fetches -- against 63 vector instructions and
+// 28 fetches for a level of the reduction itself: the adjoint pass no longer pays for a second reduction of a matrix the
+// forward pass has already reduced (the joint matrix depends on the durations only, and those do not change between the
+// two passes of an evaluation).
+template <int DL, class LG, typename Num>
+__device__ __forceinline__ void pcr_solve_transposed(int M, const Num *mult, const Num (&R)[2][DL], Num (&y)[2][DL]) {
+  static_assert(LG::W == kWave, "written for lane groups that span the wavefront");
+  typedef Num Quad __attribute__((ext_vector_type(4)));
+  const int p = LG::piece();
+  const bool in = p >= 1 && p < M;
+  const int pj = in ? p : 1;  // (a valid address for the lanes that hold no joint; their values are masked)
+  const int lane = lane_id();
+  const int nlev = pcr_levels(M, sizeof(Num) == 4);
+  Num w[2][DL];
+  {
+    const Quad I = *reinterpret_cast<const Quad *>(mult + (size_t)nlev * M * 8 + (size_t)pj * 4);
+#pragma unroll
+    for (int d = 0; d < DL; ++d) {
+      w[0][d] = in ? fma(I.x, R[0][d], I.z * R[1][d]) : Num(0.0);  // Dfin^-T r
+      w[1][d] = in ? fma(I.y, R[0][d], I.w * R[1][d]) : Num(0.0);
+    }
+  }
+  for (int k = nlev - 1; k >= 0; --k) {
+    const int s = 1 << k;
+    const Quad *src = reinterpret_cast<const Quad *>(mult + ((size_t)k * M + pj) * 8);
+    const Quad a = src[0], g = src[1];
+    const int ln = lane + s * LG::S, lp = lane - s * LG::S;
+    const bool hn = ln < kWave, hp = lp >= 0;
+#pragma unroll
+    for (int d = 0; d < DL; ++d) {
+      // a^T w and g^T w of this joint (zero on lanes without a joint: their w is zero)
+      const Num pa0 = fma(a.x, w[0][d], a.z * w[1][d]), pa1 = fma(a.y, w[0][d], a.w * w[1][d]);
+      const Num qg0 = fma(g.x, w[0][d], g.z * w[1][d]), qg1 = fma(g.y, w[0][d], g.w * w[1][d]);
+      const Num n0 = __shfl(pa0, hn ? ln : lane, kWave), n1 = __shfl(pa1, hn ? ln : lane, kWave);
+      const Num m0 = __shfl(qg0, hp ? lp : lane, kWave), m1 = __shfl(qg1, hp ? lp : lane, kWave);
+      if (in) {  // (minus: the multipliers are stored negated)
+        w[0][d] -= (hn ? n0 : Num(0.0)) + (hp ? m0 : Num(0.0));
+        w[1][d] -= (hn ? n1 : Num(0.0)) + (hp ? m1 : Num(0.0));
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DL; ++d) {
+    y[0][d] = w[0][d];
+    y[1][d] = w[1][d];
   }
 }
 
@@ -1223,7 +1297,7 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
           Up[i][j] = lane == t.M - 1 ? Num(0.0) : Up[i][j];
         }
       NEO_MARK("fwd_pcr_begin");
-      pcr_solve<DL, LG, Num>(t.M, Lo, Di, Up, R, y);
+      pcr_solve<DL, LG, Num>(t.M, Lo, Di, Up, R, y, t.pcr_mult);
       NEO_MARK("fwd_pcr_end");
     } else {
       thomas_solve<DL, LG, Num>((prm.dbg & (2 | 16)) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);
@@ -1541,6 +1615,9 @@ __device__ __forceinline__ void sample_accumulate(const Real (&c)[6][D], int j, 
   }
 }
 
+// floats per piece of the accumulator fold (minco_sample, fold_acc)
+__host__ __device__ constexpr int fold_acc_stride(int D) { return (6 * D + 1 + 3) / 4 * 4; }
+
 // sampled feasibility + collision terms (:392-466), SAMPLE layout.
 // SAMPLE_IO = false (fused kernels): in (PIECE layout) cp = coefficients of the lane's piece, ns_in = its sample
 //   count; out (PIECE layout) gC, gT = weighted partials of the two sampled terms.
@@ -1550,7 +1627,8 @@ __device__ __forceinline__ void sample_accumulate(const Real (&c)[6][D], int j, 
 template <typename Real, int D, class LookupT, int U, bool SAMPLE_IO = false, class LG = WaveLanes>
 __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int ns_in, const Real (&cp)[6][LG::dl(D)],
                                              const DevParams &prm, const LookupT &lk, Real (&gC)[6][LG::dl(D)], Real &gT,
-                                             double &cost_feas, double &cost_coll, Real *fold_rows = nullptr) {
+                                             double &cost_feas, double &cost_coll, Real *fold_rows = nullptr,
+                                             bool fold_acc = false) {
 #pragma clang fp contract(on)  // fuse a*b+c only as written: the same arithmetic whatever the unrolling around it
   const int lane = LG::lane();
   const int piece = sl.piece, r = sl.r, L = sl.L;  // (L: per lane when the pieces have different numbers of lanes)
@@ -1658,6 +1736,61 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
   NEO_MARK("loop_end");
   // (fp32 sampling only: the fp64 parity mode keeps the summation order below, the one its runs were pinned to the
   //  reference's recorded iterates with)
+  if constexpr (sizeof(Real) == 4 && !SAMPLE_IO && LG::S > 1) {
+    if (fold_rows != nullptr && fold_acc && sl.lmax != 0) {
+      // The same per-piece sums in 80 bytes a piece instead of 96 a sample lane (the kernels that keep the cyclic
+      // reduction's multipliers in LDS across this phase have no room for the rows): `fold_rows` is [M][fold_acc_stride(D)]
+      // = per piece [d][6] partials, the duration partial, padding to 16 bytes (D = 3: 20 floats).  The sample lanes of a piece add their values one after the other --
+      // residue 0 writes, residue 1 adds to what it reads back, ... -- which is the order the rows below are summed in:
+      // the same bits.  lmax * (5 reads + 19 adds + 5 writes) under an exec mask of one lane per piece.
+      typedef Real Quad __attribute__((ext_vector_type(4)));
+      constexpr int RS = fold_acc_stride(D), NQ = RS / 4;  // floats a piece: [d][6], the duration partial, padding
+      Quad v[NQ];
+      {
+        Real f[RS];
+#pragma unroll
+        for (int q = 0; q < RS; ++q) f[q] = Real(0);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+          for (int k = 0; k < 6; ++k) f[d * 6 + k] = aC[k][d];
+        f[6 * D] = aT;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[q] = Quad{f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]};
+      }
+      Quad *mine = reinterpret_cast<Quad *>(fold_rows + (size_t)(act ? piece : 0) * RS);
+      lds_wave_sync();
+      for (int i = 0; i < sl.lmax; ++i) {
+        if (act && r == i) {
+          if (i == 0) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) mine[q] = v[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) mine[q] = mine[q] + v[q];
+          }
+        }
+        lds_wave_sync();
+      }
+      {
+        const int pc = LG::piece();
+        const int Lp = __shfl(sl.Lp, pc < M ? pc : 0, kWave);
+        const bool have = pc < M && Lp > 0;
+        typedef Real Pair __attribute__((ext_vector_type(2)));
+        const Pair *src = reinterpret_cast<const Pair *>(fold_rows + (size_t)(have ? pc : 0) * RS + LG::dim0() * 6);
+        const Pair p0 = src[0], p1 = src[1], p2 = src[2];
+        const Real tpart = fold_rows[(size_t)(have ? pc : 0) * RS + 6 * D];
+        gC[0][0] = have ? p0.x : Real(0); gC[1][0] = have ? p0.y : Real(0);
+        gC[2][0] = have ? p1.x : Real(0); gC[3][0] = have ? p1.y : Real(0);
+        gC[4][0] = have ? p2.x : Real(0); gC[5][0] = have ? p2.y : Real(0);
+        gT = have ? tpart : Real(0);
+      }
+      lds_wave_sync();  // (the staging buffer is the caller's again)
+      cost_feas = (double)LG::sum(act ? aF : Real(0));
+      cost_coll = (double)LG::sum(act ? aK : Real(0));
+      return;
+    }
+  }
   if constexpr (sizeof(Real) == 4) {
     if (fold_rows != nullptr && sl.lmax != 0) {
       // Pieces with different numbers of sample lanes: the per-piece sums go through LDS.  Every sample lane writes its
@@ -1822,7 +1955,22 @@ __device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D), Num> &t, 
   for (int d = 0; d < DL; ++d) lam[0][d] = lam[1][d] = Num(0.0);
   constexpr bool kPcr = PCR;  // the transposed system by pcr_solve, too
   if constexpr (kPcr) {
-    if (M > 1) {
+    if (M > 1 && t.pcr_mult != nullptr) {
+      Num R[2][DL], y[2][DL];
+#pragma unroll
+      for (int d = 0; d < DL; ++d) {
+        R[0][d] = S[1][d];
+        R[1][d] = S[2][d];
+      }
+      NEO_MARK("bwd_pcr_begin");
+      pcr_solve_transposed<DL, LG, Num>(M, t.pcr_mult, R, y);
+      NEO_MARK("bwd_pcr_end");
+#pragma unroll
+      for (int d = 0; d < DL; ++d) {
+        lam[0][d] = (lane >= 1 && lane < M) ? y[0][d] : Num(0.0);
+        lam[1][d] = (lane >= 1 && lane < M) ? y[1][d] : Num(0.0);
+      }
+    } else if (M > 1) {
       Num LoT[2][2], DiT[2][2], UpT[2][2], R[2][DL], y[2][DL];
       LoT[0][0] = Num(24.0) * a2;  LoT[0][1] = -Num(168.0) * a3;   // Up_{p-1}^T (piece p-1 = "a")
       LoT[1][0] = -Num(3.0) * a1;  LoT[1][1] = Num(24.0) * a2;

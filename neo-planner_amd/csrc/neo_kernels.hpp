@@ -87,6 +87,8 @@ struct DevBackend {
                  // holds the lane assignment's segment table and the rows of the per-piece fold (minco_sample)
   static constexpr int kStage = stage_doubles<D, NS, Real>();
   bool fold_rows = true;  // xs has all kStage doubles (false: only NS * 64, the fold stays in registers)
+  bool fold_acc = false;  // xs holds [M][20] per-piece accumulators instead of the rows (minco_sample; the kernels that keep
+                          // the cyclic reduction's multipliers in LDS: launch_opt)
   double *sc;    // LDS [2m]: rho / alpha of the two-loop recursion
   LineSearch *lsp;  // LDS: line-search state (wave-uniform)
   double *cst;      // LDS [12]: cost terms of the last evaluation / current x / previous x
@@ -301,7 +303,7 @@ struct DevBackend {
       const SampleLanes sl = balanced_sample_lanes(t.M, ns_by_piece, reinterpret_cast<int *>(xs));
       NEO_MARK("assign_done");
       minco_sample<Real, D, LookupT, SU, false, LG>(t.M, sl, t.ns, cr, prm, lk, gCr, gTr, cf, ck,
-                                                    fold_rows ? reinterpret_cast<Real *>(xs) : nullptr);
+                                                    fold_rows ? reinterpret_cast<Real *>(xs) : nullptr, fold_acc);
 #pragma unroll
       for (int k = 0; k < 6; ++k)
 #pragma unroll
@@ -375,10 +377,14 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
   __shared__ LineSearch lsm;
   __shared__ double cst[12];
   __shared__ Num bnd[6 * D];
+  // all-fp32 mode, lane = (piece, dimension): the cyclic reduction's multipliers stay in LDS for the adjoint pass
+  constexpr bool kKeep = sizeof(Num) == 4 && LG::S > 1;
+  __shared__ __attribute__((aligned(16))) Num mult_s[kKeep ? (5 * 8 + 4) * (kWave / LG::S) : 4];
   const int b = blockIdx.x;
   if (b >= B) return;
   using BE = DevBackend<D, NS, Real, MapT, LookupT, NEO_FUSED_U, LG, false, Num>;
   BE be(prm, map);
+  if constexpr (kKeep) be.t.pcr_mult = mult_s;
   be.xs = xs;
   be.sc = sc;
   be.lsp = &lsm;
@@ -427,7 +433,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
                                                           int *__restrict__ status,
                                                           long long *__restrict__ nsamples,
                                                           const int *__restrict__ order, double *__restrict__ trace,
-                                                          double *__restrict__ trace_xg, int trace_cap, int stage) {
+                                                          double *__restrict__ trace_xg, int trace_cap, int stage, int pcr_off) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
   __shared__ double sc[2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm;
@@ -455,6 +461,15 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   BE be(prm, map);
   be.xs = dyn_lds;
   be.fold_rows = stage >= stage_doubles<D, NS, Real>();
+  // pcr_off != 0 (all-fp32 mode, lane = (piece, dimension), launch_opt): the multipliers of the forward cyclic reduction
+  // live at dyn_lds + pcr_off (doubles) for the adjoint pass, and the staging holds per-piece accumulators for the fold
+  if constexpr (sizeof(Num) == 4 && LG::S > 1) {
+    if (pcr_off != 0) {
+      be.t.pcr_mult = reinterpret_cast<Num *>(dyn_lds + pcr_off);
+      be.fold_rows = true;
+      be.fold_acc = true;
+    }
+  }
   be.sc = sc;
   be.lsp = &lsm;
   be.cst = cst;

@@ -19,12 +19,26 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
     const size_t pairs = pair_elems * ((pairs_in_f32<Real, NS, WAVES>() || sizeof(Num) == 4) ? sizeof(float) : sizeof(double)); \
     const int full = stage_doubles<D, NS, Real>(), small = NS * kWave;                                        \
     const size_t lds_share = (sizeof(Num) == 4 && NS <= 2) ? lds_share12 : lds_share8; /* all-fp32: twelve per CU */ \
-    const int stage = pairs + (size_t)full * 8 <= lds_share ? full : small;                                   \
+    int stage = pairs + (size_t)full * 8 <= lds_share ? full : small;                                         \
+    size_t dyn = pairs + (size_t)stage * 8;                                                                   \
+    int pcr_off = 0;                                                                                          \
+    if (sizeof(Num) == 4 && LG::S > 1 && !(c->params.flags & 4096)) {                                             \
+      /* all-fp32, lane = (piece, dimension): room for the reduction's multipliers next to the pairs when the fold   \
+         runs on per-piece accumulators (80 B a piece at D = 3) instead of rows (96 B a lane); flags bit 4096: off (comparison runs) */ \
+      const int acc = std::max(small, (a.M * fold_acc_stride(D) * 4 + 7) / 8);                                                    \
+      const size_t off = ((size_t)acc * 8 + pairs + 15) / 16 * 2;                                             \
+      const size_t need = off * 8 + (size_t)pcr_mult_elems(a.M) * sizeof(float);                              \
+      if (need <= lds_share) {                                                                                \
+        stage = acc;                                                                                          \
+        pcr_off = (int)off;                                                                                   \
+        dyn = need;                                                                                           \
+      }                                                                                                       \
+    }                                                                                                         \
     hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES, LG, Num>), grid, blk,                   \
-                       pairs + (size_t)stage * 8, c->stream, a.B, a.M, c->dev,                                \
+                       dyn, c->stream, a.B, a.M, c->dev,                                                      \
                        static_cast<const MapT *>(a.table), a.slots, a.nmaps, a.x0 ? a.x0 : a.x, a.x, a.head, a.tail, a.costs4,   \
                        a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter,                             \
-                       (c->order_B == a.B ? c->dispatch_order : nullptr), c->trace, c->trace_xg, c->trace_cap, stage);     \
+                       (c->order_B == a.B ? c->dispatch_order : nullptr), c->trace, c->trace_xg, c->trace_cap, stage, pcr_off); \
   } while (0)
   // lane = (piece, dimension) whenever D * M fits the wavefront (cfg2: 63 lanes busy in the PIECE-layout phases
   // instead of 21, a third of the per-dimension state per lane); lane = piece otherwise.  flags bit 512 forces the

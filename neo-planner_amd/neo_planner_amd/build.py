@@ -40,6 +40,9 @@ def _flags():
 
 def _newest_header():
     deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "neo_planner.h")]
+    if "NEO_SAMPLE_EXPERIMENTS" in os.environ.get("NEO_BUILD_DEFS", ""):     # neo_disp_sample.hip then includes these
+        probe = os.path.join(os.path.dirname(os.path.dirname(PKG)), "tools", "probe")
+        deps += [os.path.join(probe, h) for h in ("neo_sample_chunk.hpp", "neo_sample_wg.hpp")]
     return max(os.path.getmtime(d) for d in deps)
 
 
@@ -80,6 +83,10 @@ def _key(src=None):
 def build(force=False, verbose=False, jobs=None):
     """compile the translation units that are missing or older than their sources (in parallel), link; returns the
     library's path"""
+    if os.environ.get("NEO_BUILD_DEFS", "").strip() and not os.environ.get("NEO_BUILD_OUT"):
+        # an experiment build must never replace the in-tree product library: _lib.load() would silently use it
+        raise RuntimeError("NEO_BUILD_DEFS is for experiment builds: set NEO_BUILD_OUT=<path of the experiment library> as well "
+                           "(and NEO_PLANNER_LIB=<that path> when running it)")
     src_t = max([_newest_header()] + [os.path.getmtime(os.path.join(CSRC, s)) for s in SOURCES])
     stamp = open(STAMP).read().strip() if os.path.exists(STAMP) else ""
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= src_t and stamp == _key():

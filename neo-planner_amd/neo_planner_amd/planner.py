@@ -512,33 +512,49 @@ class BatchPlanner:
         ts[:, -1] *= 1.5
         return wp, ts
 
-    def plan(self, map, head, tail, int_wpts=None, ts=None, waypoints=None, max_attempts=5, rng=None, scene_ids=None):
+    def plan(self, map, head, tail, int_wpts=None, ts=None, waypoints=None, max_attempts=5, rng=None, scene_ids=None,
+             seed=None, return_launch_sizes=False):
         """warm_start_plan (:186-203) for a batch: every request gets up to `max_attempts` plan_once runs.  An attempt that
         ends the way the reference raises on -- OverflowError statuses or `collision cost too large` (:235-237) -- is
         re-seeded like the reference's retries (straight line + N(0, 0.5), :94, :201) and optimised again; only the
-        failed requests are launched again.  Returns the optimiser's dict plus `attempts` (B,) and `solved` (B,): a
-        request with solved False is one the reference answers with Exception("No solution for the given target")."""
+        failed requests are launched again (compacted re-launches).  The jitter of request i at attempt a comes from its
+        OWN stream, SeedSequence(seed, i, a): a retry does not depend on which other requests of the batch failed, as the
+        reference's warm_start_plan of one request does not depend on other requests (`seed`: an int; None draws one from
+        `rng` or from the OS).  Returns the optimiser's dict plus `attempts` (B,) and `solved` (B,): a request with solved
+        False is one the reference answers with Exception("No solution for the given target")."""
+        if (int_wpts is None) != (ts is None):
+            raise ValueError("BatchPlanner.plan: give both int_wpts and ts, or neither")
         head = _lib.as_f64(head); tail = _lib.as_f64(tail)
         B, D = head.shape[0], head.shape[2]
         if int_wpts is None:
             int_wpts, ts = self.init_guess(head, tail, waypoints if waypoints is not None else int(self.cfg.init_wpts_num))
         count = np.asarray(int_wpts).shape[2]
         out = self.optimize(map, self.pack_x(int_wpts, ts), head, tail, scene_ids=scene_ids)
+        if np.any(out["status"] == _lib.NEO_TRAJ_BAD_SCENE):
+            # not a planning failure: the request named a map-table slot that does not exist -- retrying cannot help
+            raise _lib.NeoError("BatchPlanner.plan: requests %s name a scene without a map (NEO_TRAJ_BAD_SCENE)"
+                                % np.flatnonzero(out["status"] == _lib.NEO_TRAJ_BAD_SCENE)[:8].tolist())
         out["attempts"] = np.ones(B, dtype=np.int32)
-        failed = lambda r: (r["status"] > _lib.NEO_TRAJ_MAXITER) | r["collision"]
+        failed = lambda r: ((r["status"] > _lib.NEO_TRAJ_MAXITER) & (r["status"] != _lib.NEO_TRAJ_BAD_SCENE)) | r["collision"]
         todo = np.flatnonzero(failed(out))
-        rng = rng if rng is not None else np.random.default_rng()
+        if seed is None:
+            seed = int((rng if rng is not None else np.random.default_rng()).integers(0, 2 ** 62))
+        launches = [B]
         for attempt in range(1, max_attempts):
             if todo.size == 0:
                 break
-            wp_n, ts_n = self.init_guess(head[todo], tail[todo], count, rng=rng, noise=0.5)
-            r = self.optimize(map, self.pack_x(wp_n, ts_n), head[todo], tail[todo],
+            noise = np.stack([np.random.default_rng([int(seed), int(i), attempt]).normal(0.0, 0.5, (D, count)) for i in todo])
+            wp_n, ts_n = self.init_guess(head[todo], tail[todo], count)
+            r = self.optimize(map, self.pack_x(wp_n + noise, ts_n), head[todo], tail[todo],
                               scene_ids=None if scene_ids is None else np.asarray(scene_ids)[todo])
+            launches.append(int(todo.size))
             for k in ("x", "costs", "costs_last", "nit", "nfev", "status", "collision", "final_cost"):
                 out[k][todo] = r[k]
             out["attempts"][todo] += 1
             todo = todo[failed(r)]
         out["solved"] = ~failed(out)
+        if return_launch_sizes:
+            out["launch_sizes"] = launches
         return out
 
     def expected_effort_order(self, head, tail, ts):
@@ -551,13 +567,14 @@ class BatchPlanner:
         return np.argsort(-slack, kind="stable").astype(np.int32)
 
     @staticmethod
-    def spatial_order(head, tail, xcds=8, cell=1.0, key=None):
+    def spatial_order(head, tail, xcds=8, cell=1.0, key=None, chunk=None):
         """XCD-aware spatial dispatch order for the ESDF-lookup kernel (neo_optimize_dispatch_order): requests are keyed by
         a coarse Morton code of where they fly -- the midpoint of start and goal in cells of `cell` metres -- sorted, and
         the sorted list is dealt so that workgroups i, i + 8, i + 16, ... (one XCD: the hardware dispatches workgroups
-        round-robin over the 8 XCDs, each with its own 4 MB L2) hold one contiguous run of it.  Requests whose
-        corridors overlap then share an L2 and run at about the same time.  Results are in the caller's order and
-        bit-identical whatever the order."""
+        round-robin over the 8 XCDs, each with its own 4 MB L2) hold contiguous runs of it.  Requests whose
+        corridors overlap then share an L2 and run at about the same time.  `chunk`: length of the runs dealt to the XCDs
+        in turn (None: min(512, B / xcds); runs shorter than B / xcds make every XCD sweep the whole scene, which evens out
+        their loads).  Results are in the caller's order and bit-identical whatever the order."""
         head = np.asarray(head); tail = np.asarray(tail)
         B = head.shape[0]
         if key is None:
@@ -570,26 +587,28 @@ class BatchPlanner:
                 for d in range(D):
                     key |= ((q[:, d] >> b) & 1) << (D * b + d)
         srt = np.argsort(key, kind="stable")
-        out = np.empty(B, dtype=np.int32)
-        # workgroup i -> XCD i mod xcds; XCD k takes the k-th contiguous share of the sorted list (shares differ by at
-        # most one request when xcds does not divide B)
-        bounds = (np.arange(xcds + 1) * B) // xcds
-        pos = np.arange(B)
+        if xcds <= 1:
+            return srt.astype(np.int32)
+        # default: runs of at most 512 requests -- what an XCD holds at four wavefronts per SIMD -- dealt to the XCDs in turn
+        # (measured on the MI355X, cfg2, 163 840 requests in one launch: one run of B / 8 per XCD 0.385 of the roofline
+        # figure, runs of 64 ... 512 0.401 ... 0.406, sorted without the deal 0.398; a 4096 launch has 512 per XCD either way)
+        chunk = int(chunk) if chunk else min(512, -(-B // xcds))
+        # run c of the sorted list goes to XCD c mod xcds; queue the runs per XCD, then workgroup i takes the next request
+        # of XCD i mod xcds (XCDs that run out early are served from the others' leftovers: still a permutation)
+        queues = [[] for _ in range(xcds)]
+        for c, lo in enumerate(range(0, B, chunk)):
+            queues[c % xcds].append(srt[lo:lo + chunk])
+        queues = [np.concatenate(q_) if q_ else np.zeros(0, dtype=srt.dtype) for q_ in queues]
+        out = np.full(B, -1, dtype=np.int64)
+        left = []
         for k in range(xcds):
-            mine = pos[k::xcds]
-            seg = srt[bounds[k]:bounds[k + 1]]
-            m = min(len(mine), len(seg))
-            out[mine[:m]] = seg[:m]
-        if B % xcds:
-            # uneven shares: fill what is left in index order (still a permutation)
-            used = np.zeros(B, dtype=bool)
-            filled = np.zeros(B, dtype=bool)
-            for k in range(xcds):
-                mine = pos[k::xcds]; seg = srt[bounds[k]:bounds[k + 1]]
-                m = min(len(mine), len(seg))
-                used[seg[:m]] = True; filled[mine[:m]] = True
-            out[~filled] = np.flatnonzero(~used)
-        return out
+            slots = np.arange(k, B, xcds)
+            m = min(len(slots), len(queues[k]))
+            out[slots[:m]] = queues[k][:m]
+            left.append(queues[k][m:])
+        rest = np.concatenate(left)
+        out[out < 0] = rest
+        return out.astype(np.int32)
 
     def optimize_dev(self, map, x, head, tail, costs, costs_last, nit, nfev, status, slots=None, x0=None):
         """torch CUDA tensors (float64 / int32), asynchronous on the context's stream.

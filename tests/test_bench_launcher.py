@@ -50,3 +50,18 @@ def test_usable_cpus_is_affinity_capped():
     import bench
     n = bench.usable_cpus()
     assert 1 <= n <= len(os.sched_getaffinity(0))
+
+
+def test_more_gpus_asked_for_than_visible_is_a_one_line_refusal():
+    """`bench.py --gpus N` on a node with fewer GPUs exits non-zero with one line, before any GPU call
+    and without launching ranks (this container has none)"""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        return
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8"], env=e, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    msg = [ln for ln in p.stderr.splitlines() if ln.startswith("bench.py:")]
+    assert len(msg) == 1 and "--gpus 8" in msg[0] and "nothing was run" in msg[0]

@@ -81,3 +81,45 @@ def test_pack_results_layout():
     assert torch.equal(r[:, 4:], costs.float())
     assert sharding.gather_results(r, 1) is r
     assert sharding.gather_results(r, 1, async_op=True) == (r, None) or sharding.gather_results(r, 1, async_op=True)[0] is r
+
+
+def test_cfg4_scene_split_and_scene_major_round_trip_for_every_world_size():
+    """BASELINE.json configs[3]: 256 scenes over the GPUs of a node -- bench.py's `--scenes` default 256 // max(world, 8) per
+    rank (32 on 8 GPUs; smaller worlds keep 32 per GPU: weak scaling) -- and for world in {2, 4, 8} the rank-major gathered
+    rows go back into scene order (sharding.scene_major_order) for round-robin ownership"""
+    import torch
+    from neo_planner_amd import sharding
+    for world in (2, 4, 8):
+        per_gpu = 256 // max(world, 8)
+        assert per_gpu == 32
+        n_scenes = per_gpu * world
+        owned = [sharding.owned_scenes(n_scenes, r, world) for r in range(world)]
+        assert sorted(s for o in owned for s in o) == list(range(n_scenes))
+        assert all(len(o) == per_gpu for o in owned)
+        assert all(sharding.owner_of(s, world) == r for r, o in enumerate(owned) for s in o)
+        rows, n = 3, 5
+        # what every rank packs: its scenes in increasing order, `rows` result rows each, tagged (scene, row)
+        local = [torch.tensor([[s, k, 0, 0, 0] for s in o for k in range(rows)], dtype=torch.float32) for o in owned]
+        gathered = torch.cat(local)                       # rank-major, as all_gather_into_tensor leaves it
+        back = sharding.scene_major_order(gathered, n_scenes, world, rows)
+        assert back.shape == (n_scenes * rows, n)
+        assert torch.equal(back[:, 0], torch.arange(n_scenes).repeat_interleave(rows).float())
+        assert torch.equal(back[:, 1], torch.arange(rows).repeat(n_scenes).float())
+
+
+def test_spatial_dispatch_order_is_a_permutation_with_contiguous_runs_per_xcd():
+    import numpy as np
+    from neo_planner_amd import synth
+    from neo_planner_amd.planner import BatchPlanner
+    for B in (4096, 1001, 9, 8, 1):
+        h, t, _, _ = synth.replan_requests(1, B, 20, D=3, **synth.VOLUME)
+        for chunk in (None, 64, 3):
+            o = BatchPlanner.spatial_order(h, t, chunk=chunk)
+            assert o.dtype == np.int32 and sorted(o.tolist()) == list(range(B))
+    h, t, _, _ = synth.replan_requests(1, 4096, 20, D=3, **synth.VOLUME)
+    o = BatchPlanner.spatial_order(h, t)
+    srt = BatchPlanner.spatial_order(h, t, xcds=1)
+    rank = np.empty(4096, dtype=np.int64); rank[srt] = np.arange(4096)
+    for k in range(8):                                      # XCD k = workgroups k, k + 8, ...: one contiguous eighth, in order
+        r = rank[o[k::8]]
+        assert r.min() == k * 512 and r.max() == (k + 1) * 512 - 1 and np.all(np.diff(r) == 1)

@@ -556,6 +556,17 @@ def test_batched_plan_with_retries_like_warm_start_plan():
     retried = out["attempts"] > 1
     assert out["solved"][retried & free].mean() >= 0.5               # ... and most of those found a way round
     assert np.all(out["final_cost"][out["solved"]] < 1e4)
+    # a request's re-seeded attempts do not depend on its batch neighbours: the pillar requests alone, same
+    # seed -> the same answers, although other requests fail around them in the full batch
+    a = bp.plan(m, head, tail, max_attempts=5, seed=11)
+    sub = np.r_[0:24:2]
+    b = bp.plan(m, head[sub], tail[sub], max_attempts=5, seed=11)
+    # (request i of the sub-batch has index i there: its stream is keyed by the index, so compare equal indices)
+    c = bp.plan(m, head[:12], tail[:12], max_attempts=5, seed=11)
+    assert np.array_equal(a["x"][:12], c["x"][:12]) and np.array_equal(a["attempts"][:12], c["attempts"][:12])
+    assert b["x"].shape[0] == 12
+    with pytest.raises(ValueError):
+        bp.plan(m, head, tail, int_wpts=np.zeros((48, 2, 2)))         # ts missing
     # the initial guess is the reference's (generate_init_variables, fixed mode, :82-101)
     pl = npa.MinJerkPlanner(npa.PlannerConfig())
     w, t = pl.generate_init_variables(head[0, :2], tail[0, :2])

@@ -75,7 +75,9 @@ def test_esdf_build_matches_scipy_on_odd_shapes(shape, seed):
 
 @pytest.mark.parametrize("shape,seed", [((48, 48, 48), 0), ((20, 33, 47), 1), ((5, 64, 9), 2),
                                         # long lines: the narrower LDS tiles of the y / z passes (16, 8 and 2 columns)
-                                        ((6, 600, 70), 3), ((700, 6, 40), 4), ((4, 3000, 10), 5), ((2, 2, 2), 6)])
+                                        ((6, 600, 70), 3), ((700, 6, 40), 4), ((4, 3000, 10), 5), ((2, 2, 2), 6),
+                                        # z lines whose tile would pass 64 KB only together with the kernel's static LDS
+                                        ((680, 5, 20), 7), ((1360, 3, 9), 8)])
 def test_esdf_build_3d_is_the_exact_edt(shape, seed):
     """device-side 3-D EDT against scipy.ndimage.distance_transform_edt: equal after the same fp32 rounding"""
     from scipy import ndimage

@@ -57,7 +57,7 @@ def main():
     trace_only = "--trace-only" in sys.argv[2:]
     os.makedirs(out, exist_ok=True)
     os.environ["TMPDIR"] = "/tmp"
-    bench = ["python3", "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-modes"] + extra
+    bench = ["python3", "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-modes", "--no-retries"] + extra
     d = os.path.join(out, "trace")
     rc = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + bench,
              os.path.join(out, "trace.log"), 420)

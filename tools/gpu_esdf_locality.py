@@ -57,7 +57,11 @@ def main():
     orders = {"index": None, "spatial 1 m": lambda h, t: npa.BatchPlanner.spatial_order(h, t, cell=1.0),
               "spatial 0.5 m": lambda h, t: npa.BatchPlanner.spatial_order(h, t, cell=0.5),
               "spatial 2 m": lambda h, t: npa.BatchPlanner.spatial_order(h, t, cell=2.0),
-              "sorted, no XCD deal": lambda h, t: npa.BatchPlanner.spatial_order(h, t, cell=1.0, xcds=1)}
+              "sorted, no XCD deal": lambda h, t: npa.BatchPlanner.spatial_order(h, t, cell=1.0, xcds=1),
+              "spatial, runs of 64": lambda h, t: npa.BatchPlanner.spatial_order(h, t, chunk=64),
+              "spatial, runs of 256": lambda h, t: npa.BatchPlanner.spatial_order(h, t, chunk=256),
+              "spatial, runs of 512": lambda h, t: npa.BatchPlanner.spatial_order(h, t, chunk=512),
+              "spatial, runs of 2048": lambda h, t: npa.BatchPlanner.spatial_order(h, t, chunk=2048)}
     if a.only_order:
         orders = {k: v for k, v in orders.items() if k == a.only_order}
     results = []

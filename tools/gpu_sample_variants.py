@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Times the variants of the workgroup-per-trajectory ESDF-lookup kernel (csrc/neo_sample_wg.hpp; a library built with
+"""Times the variants of the workgroup-per-trajectory ESDF-lookup kernel (tools/probe/neo_sample_wg.hpp; a library built with
 -DNEO_SAMPLE_EXPERIMENTS) against the one-wavefront sample_kernel on bench.py's cfg2 workload (300^3 fp32 field, yz-quad
 layout, requests filling the volume), one launch of 4096 trajectories and one of 65 536, and checks every variant's
 outputs against the one-wavefront kernel's.
 
-    NEO_BUILD_DEFS=-DNEO_SAMPLE_EXPERIMENTS python -m neo_planner_amd.build      (here)
+    NEO_BUILD_DEFS=-DNEO_SAMPLE_EXPERIMENTS NEO_BUILD_OUT=_build/libneo_sample_exp.so python -m neo_planner_amd.build      (here)
+    NEO_PLANNER_LIB=_build/libneo_sample_exp.so python tools/gpu_sample_variants.py                                (GPU box)
     python tools/gpu_sample_variants.py [variant ...]                            (GPU box)
 """
 import ctypes

@@ -75,7 +75,7 @@ def reference_jump(d, M, rel_noise=4e-6, trials=12):
     return float(jump)
 
 
-def g1_report(modes=MODES):
+def g1_report(modes=MODES, with_reference_jump=True):
     """the 8 fixtures x M in {3, 21, 41}: relative deviations of one evaluation from the reference's, per mode the maximum,
     the median and every case beyond the mode's tolerance -- with the reference objective's own jump there"""
     import neo_planner_amd as npa
@@ -97,7 +97,9 @@ def g1_report(modes=MODES):
                     o[k].append(float(v))
                 if max(e["cost"], e["costs"], e["grad"]) > G1_TOL[mode]:
                     o["beyond"].append(dict(fixture=os.path.basename(path), M=M, cost=float(e["cost"]), costs=float(e["costs"]),
-                                            grad=float(e["grad"]), reference_jump_under_4e_6_noise=reference_jump(d, M)))
+                                            grad=float(e["grad"])))
+                    if with_reference_jump:      # (the oracle: tests and the stand-alone report only, never bench.py's GPU process)
+                        o["beyond"][-1]["reference_jump_under_4e_6_noise"] = reference_jump(d, M)
     for o in out.values():
         o["n"] = len(o["cost"])
         for k in ("cost", "costs", "grad", "coeffs"):
