@@ -1052,6 +1052,91 @@ __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2]
     for (int d = 0; d < DL; ++d) R[i][d] = in ? R[i][d] : Num(0.0);
   }
   const int lane = lane_id();
+  // fp32: at most five levels.  The coupling left after a level is the square of the one before (measured over random
+  // durations in [0.1, 5] s: <= 19, 4.8, 0.14, 8e-5, 6e-11 relative to the diagonal after levels 1 .. 5), so what a
+  // sixth level (M > 33: cfg5) would eliminate is five orders below the rounding of the fp32 solve.
+  const int s_end = sizeof(Num) == 4 ? min(M - 1, 32) : M - 1;
+  typedef Num Quad __attribute__((ext_vector_type(4)));
+  const bool writer = mult != nullptr && in && LG::dim0() == 0;  // one lane per joint writes
+  int level = 0;
+  if constexpr (sizeof(Num) == 4) {
+    // fp32: the 2 x 2 blocks as ROWS in register pairs, their products as packed operations (v_pk_mul_f32 / v_pk_fma_f32
+    // with the left factor's element broadcast through op_sel): 4 instructions a 2 x 2 product instead of 8 -- 39 vector
+    // instructions a level instead of 63, in a kernel bound by the issue of its vector instructions.  Every product is
+    // formed by the same multiply / fused multiply-adds in the same order as the scalar form below: the same bits.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    auto fma2 = [](f2 x, f2 y, f2 z) { return __builtin_elementwise_fma(x, y, z); };
+    f2 Lr[2] = {{L[0][0], L[0][1]}, {L[1][0], L[1][1]}}, Dr[2] = {{Dg[0][0], Dg[0][1]}, {Dg[1][0], Dg[1][1]}};
+    f2 Ur[2] = {{U[0][0], U[0][1]}, {U[1][0], U[1][1]}}, Ir[2];
+    auto invert = [&]() {
+      const float det = fmaf(Dr[0].x, Dr[1].y, -(Dr[0].y * Dr[1].x));
+      const float r = precise_rcp(det);
+      Ir[0].x = Dr[1].y * r;
+      Ir[0].y = -Dr[0].y * r;
+      Ir[1].x = -Dr[1].x * r;
+      Ir[1].y = Dr[0].x * r;
+    };
+    auto fetch = [&](const f2 v, int src) { return f2{__shfl(v.x, src, kWave), __shfl(v.y, src, kWave)}; };
+    // Lanes without a neighbour at distance s fetch from whatever lane the index wraps to: their coupling block is an exact
+    // zero by then (L_i = 0 for i <= s, U_i = 0 for i + s >= M, by induction over the levels), and zero times a finite
+    // value is the zero the clamped fetch gave.  The last level's L' and U' (zero up to rounding, never used) are formed
+    // like the others: cheaper than the selects that kept them out.  Every lane stores its multipliers -- the lanes of a
+    // joint the same values to the same place, the lanes without a joint into slots nobody reads (piece 0, and the one slot past
+    // the level, which the next level's writes or pcr_mult_elems' slack cover).
+    const bool keep = mult != nullptr;
+    const int ps = min(p, M);  // (store slot: every lane beyond the last piece shares the one past it)
+    for (int s = 1; s < s_end; s <<= 1, ++level) {
+      invert();
+      const int sp = lane - s * LG::S, sn = lane + s * LG::S;
+      f2 Ip[2], Lp[2], Upv[2], In[2], Ln[2], Un[2];
+      Num Rp[2][DL], Rn[2][DL];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        Ip[i] = fetch(Ir[i], sp);
+        Upv[i] = fetch(Ur[i], sp);
+        In[i] = fetch(Ir[i], sn);
+        Ln[i] = fetch(Lr[i], sn);
+        Lp[i] = fetch(Lr[i], sp);
+        Un[i] = fetch(Ur[i], sn);
+#pragma unroll
+        for (int d = 0; d < DL; ++d) {
+          Rp[i][d] = __shfl(R[i][d], sp, kWave);
+          Rn[i][d] = __shfl(R[i][d], sn, kWave);
+        }
+      }
+      f2 pa[2], pg[2];  // -a, -g: the products as they come (a = -L Ip, g = -U In)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        pa[i] = fma2(Lr[i].xx, Ip[0], Lr[i].yy * Ip[1]);
+        pg[i] = fma2(Ur[i].xx, In[0], Ur[i].yy * In[1]);
+      }
+      if (keep) {
+        Quad *dst = reinterpret_cast<Quad *>(mult + ((size_t)level * M + ps) * 8);
+        dst[0] = Quad{pa[0].x, pa[0].y, pa[1].x, pa[1].y};  // (stored negated: what sits in the registers)
+        dst[1] = Quad{pg[0].x, pg[0].y, pg[1].x, pg[1].y};
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f2 ai = -pa[i], gi = -pg[i];
+        const f2 ln2 = fma2(ai.xx, Lp[0], ai.yy * Lp[1]);
+        const f2 un2 = fma2(gi.xx, Un[0], gi.yy * Un[1]);
+        Dr[i] = fma2(gi.yy, Ln[1], fma2(gi.xx, Ln[0], fma2(ai.yy, Upv[1], fma2(ai.xx, Upv[0], Dr[i]))));
+#pragma unroll
+        for (int d = 0; d < DL; ++d)
+          R[i][d] = fmaf(gi.y, Rn[1][d], fmaf(gi.x, Rn[0][d], fmaf(ai.y, Rp[1][d], fmaf(ai.x, Rp[0][d], R[i][d]))));
+        Lr[i] = ln2;
+        Ur[i] = un2;
+      }
+    }
+    invert();
+    if (keep) *reinterpret_cast<Quad *>(mult + (size_t)level * M * 8 + (size_t)ps * 4) = Quad{Ir[0].x, Ir[0].y, Ir[1].x, Ir[1].y};
+#pragma unroll
+    for (int d = 0; d < DL; ++d) {
+      y[0][d] = fmaf(Ir[0].x, R[0][d], Ir[0].y * R[1][d]);
+      y[1][d] = fmaf(Ir[1].x, R[0][d], Ir[1].y * R[1][d]);
+    }
+    return;
+  }
   Num I[2][2];
   auto invert = [&]() {
     const Num det = fma(Dg[0][0], Dg[1][1], -(Dg[0][1] * Dg[1][0]));
@@ -1061,13 +1146,6 @@ __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2]
     I[1][0] = -Dg[1][0] * r;
     I[1][1] = Dg[0][0] * r;
   };
-  // fp32: at most five levels.  The coupling left after a level is the square of the one before (measured over random
-  // durations in [0.1, 5] s: <= 19, 4.8, 0.14, 8e-5, 6e-11 relative to the diagonal after levels 1 .. 5), so what a
-  // sixth level (M > 33: cfg5) would eliminate is five orders below the rounding of the fp32 solve.
-  const int s_end = sizeof(Num) == 4 ? min(M - 1, 32) : M - 1;
-  typedef Num Quad __attribute__((ext_vector_type(4)));
-  const bool writer = mult != nullptr && in && LG::dim0() == 0;  // one lane per joint writes
-  int level = 0;
   for (int s = 1; s < s_end; s <<= 1, ++level) {
     invert();
     // neighbours at distance s (lanes without one read themselves: their coupling block is zero by then)
@@ -1150,7 +1228,8 @@ __host__ __device__ __forceinline__ int pcr_levels(int M, bool f32 = true) {
   for (int s = 1; s < s_end; s <<= 1) ++n;
   return n;
 }
-__host__ __device__ __forceinline__ int pcr_mult_elems(int M) { return (pcr_levels(M) * 8 + 4) * M; }
+// (+ 8: the lanes beyond the last piece write one slot past each region)
+__host__ __device__ __forceinline__ int pcr_mult_elems(int M) { return (pcr_levels(M) * 8 + 4) * M + 8; }
 
 // The adjoint system K^T lambda = r from the multipliers pcr_solve left in `mult`:
 //     lambda = P_1^T ... P_last^T (Dfin^-T r),     (P_k^T w)_j = w_j + a_{j+s}^T w_{j+s} + g_{j-s}^T w_{j-s},   s = 2^k.

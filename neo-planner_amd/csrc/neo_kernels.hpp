@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
   __shared__ Num bnd[6 * D];
   // all-fp32 mode, lane = (piece, dimension): the cyclic reduction's multipliers stay in LDS for the adjoint pass
   constexpr bool kKeep = sizeof(Num) == 4 && LG::S > 1;
-  __shared__ __attribute__((aligned(16))) Num mult_s[kKeep ? (5 * 8 + 4) * (kWave / LG::S) : 4];
+  __shared__ __attribute__((aligned(16))) Num mult_s[kKeep ? (5 * 8 + 4) * (kWave / LG::S) + 8 : 4];
   const int b = blockIdx.x;
   if (b >= B) return;
   using BE = DevBackend<D, NS, Real, MapT, LookupT, NEO_FUSED_U, LG, false, Num>;
