@@ -796,6 +796,8 @@ struct WaveLanesPD {
   static __device__ __forceinline__ int sum(int v) { return wave_sum(v); }
   static __device__ __forceinline__ int any(int pred) { return __any(pred); }
   static __device__ __forceinline__ float read(float v, int q) { return rdlane(v, S * q); }
+  // (one ds_bpermute instead of the S chained shifts was measured on the MI355X and lost: cfg2 1.39 -> 1.37 M traj/s, a
+  //  single batch 692 k -> 660 k -- the LDS round trip sits on the dependent chain, and the LDS pipe is busy too)
   static __device__ __forceinline__ float prev(float v, float fill) {
 #pragma unroll
     for (int k = 0; k < S; ++k) v = dpp_f<0x138>(v);
@@ -1531,6 +1533,7 @@ struct SampleLanes {
   int lmax;    // wave-uniform: largest L (fold depth); 0 = every piece has the same L (fast DPP folds)
   int first;   // PIECE layout (lane p < M): first sample lane of piece p
   int Lp;      // PIECE layout (lane p < M): number of sample lanes of piece p
+  int total;   // wave-uniform: samples of the whole trajectory (balanced_sample_lanes; -1: not formed)
 };
 
 // the same L = sample_lanes_per_piece(M) lanes for every piece (lane groups; pieces with equal sample counts)
@@ -1547,6 +1550,7 @@ __device__ __forceinline__ SampleLanes fixed_sample_lanes(int M, int L, int ns_o
   sl.lmax = 0;
   sl.first = lane * L;
   sl.Lp = L;
+  sl.total = -1;
   return sl;
 }
 
@@ -1587,6 +1591,7 @@ __device__ __forceinline__ SampleLanes group_sample_lanes(int M, int ns_piece) {
   sl.rounds = -1;  // from the sample counts, in minco_sample
   sl.lmax = L0 + 1;
   sl.Lp = Lp;
+  sl.total = -1;
   return sl;
 }
 
@@ -1626,6 +1631,7 @@ __device__ __forceinline__ SampleLanes balanced_sample_lanes(int M, int ns_piece
   sl.lmax = wave_max_nonneg(Lp);
   sl.first = start;
   sl.Lp = Lp;
+  sl.total = total;
   return sl;
 }
 

@@ -268,8 +268,6 @@ struct DevBackend {
       for (int k = 0; k < 4; ++k) costs[k] = 0.0;
       return st;
     }
-    last_ns = wave_sum((p < t.M && LG::dim0() == 0) ? t.ns : 0);
-    samples += (long long)last_ns;
     if (coeff_out != nullptr && p < t.M) {
 #pragma unroll
       for (int k = 0; k < 6; ++k)
@@ -301,6 +299,8 @@ struct DevBackend {
       if constexpr (LG::S > 1) ns_by_piece = __shfl(t.ns, min(LG::S * lane, kWave - 1), kWave);
       NEO_MARK("assign_begin");
       const SampleLanes sl = balanced_sample_lanes(t.M, ns_by_piece, reinterpret_cast<int *>(xs));
+      last_ns = sl.total;  // (the lane assignment has summed the sample counts already)
+      samples += (long long)last_ns;
       NEO_MARK("assign_done");
       minco_sample<Real, D, LookupT, SU, false, LG>(t.M, sl, t.ns, cr, prm, lk, gCr, gTr, cf, ck,
                                                     fold_rows ? reinterpret_cast<Real *>(xs) : nullptr, fold_acc);

@@ -212,7 +212,7 @@ def test_cfg2_fp64_mode_against_scipys_own_optimiser_on_the_cpp_objective():
 
 
 def test_cfg5_fp16_field_600_cubed_optimiser_against_cpu():
-    n, M, B = 600, 41, 256
+    n, M, B = 600, 41, 4096          # (the property half on the whole cfg5 batch: VERDICT r3 item 4)
     res = 30.0 / n
     dev = torch.device("cuda", 0)
     occ = synth.occupancy_3d(3, n=n, res=res, canopy=80)
@@ -221,7 +221,7 @@ def test_cfg5_fp16_field_600_cubed_optimiser_against_cpu():
     field16 = g32.dist.astype(np.float16).astype(np.float32)       # what an fp16 store holds, widened
     ctx.check(ctx.lib.neo_esdf_drop(ctx.h, g32.scene_id))
     head, tail, wp, ts = synth.replan_requests(3, B, M - 1, D=3, **synth.VOLUME)
-    for layout in ("linear", "yz4"):
+    for layout in ("linear", "brick"):
         g16 = npa.ESDF3D(torch.from_numpy(g32.dist).to(dev), res, synth.DOMAIN_ORIGIN, store="f16", layout=layout, ctx=ctx)
         bp = npa.BatchPlanner(ctx=ctx, sample_dtype="f64")
         x0 = bp.pack_x(wp, ts)
@@ -244,7 +244,7 @@ def test_cfg5_fp16_field_600_cubed_optimiser_against_cpu():
         e0 = npa.BatchPlanner(ctx=ctx, sample_dtype="f32").cost_grad(g16, x0, head, tail)
         ok = r["status"] <= 2
         assert ok.mean() > 0.9 and np.all(r["final_cost"][ok] <= e0["cost"][ok] * (1 + 1e-9))
-        if layout == "yz4":
+        if layout == "brick":
             # the all-fp32 mode at n = 161 (four FLAT slots; the mode cfg5's bench number is quoted in): one evaluation
             # against the CPU oracle to the mode's tolerance, the optimiser against the CPU with the CPU-vs-CPU control
             # perturbed as the all-fp32 kernels are per evaluation, and the batch properties

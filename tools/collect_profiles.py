@@ -53,8 +53,15 @@ def run(cmd, log, timeout):
 
 def main():
     out = os.path.abspath(sys.argv[1])
-    extra = [a for a in sys.argv[2:] if a != "--trace-only"]
-    trace_only = "--trace-only" in sys.argv[2:]
+    args = sys.argv[2:]
+    trace_only = "--trace-only" in args
+    # --pmc-groups i,j,...: only these counter groups (indices into PMC_GROUPS; cfg5: instruction mix and pipe activity)
+    only = None
+    if "--pmc-groups" in args:
+        k = args.index("--pmc-groups")
+        only = [int(v) for v in args[k + 1].split(",")]
+        args = args[:k] + args[k + 2:]
+    extra = [a for a in args if a != "--trace-only"]
     os.makedirs(out, exist_ok=True)
     os.environ["TMPDIR"] = "/tmp"
     bench = ["python3", "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-modes", "--no-retries"] + extra
@@ -84,6 +91,8 @@ def main():
     print("kernel trace rc", rc, "stats", bool(stats), "trace", bool(traces))
     agg = {}
     for gi, group in enumerate([] if trace_only else PMC_GROUPS):
+        if only is not None and gi not in only:
+            continue
         d = os.path.join(out, f"pmc{gi}")
         rc = run(["rocprofv3", "--pmc"] + group + ["--output-format", "csv", "-d", d, "--"] + bench,
                  os.path.join(out, f"pmc{gi}.log"), 180)
