@@ -39,7 +39,7 @@ PMC_GROUPS = [
     # half of them on gfx950: tools/gpu_gather_calib.py)
     ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"],
 ]
-KERNELS = ["optimize_group_kernel", "optimize_kernel", "sample_kernel", "eval_kernel", "edt3_x", "edt3_y", "edt3_z", "pack3d"]
+KERNELS = ["optimize_group_kernel", "optimize_kernel", "sample_kernel", "eval_kernel", "edt3_x", "edt3_line", "pack3d"]
 
 
 def run(cmd, log, timeout):
