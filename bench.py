@@ -719,62 +719,68 @@ def main():
 
     # ---- the reference's ACCEPTED result is warm_start_plan's: up to five plan_once attempts, the failed ones re-seeded
     # with N(0, 0.5) jitter (expert_planner.py:186-203); `value` counts first attempts.  Here the whole chain is timed
-    # under the same protocol: per request batch the first launch of B trajectories, then the compacted re-launches of
-    # the requests that failed (BatchPlanner.plan's chain).  Which requests fail, and their re-seeded guesses, are found in
-    # an untimed pass (a caller learns them from the status array between launches); the timed region replays every
-    # launch of the chain, first attempts included, `--streams` batches in flight.
+    # under the same protocol, as BatchPlanner.plan runs it on the requests of a step: the first launches of the step's
+    # batches, then ONE compacted re-launch per attempt of every request that failed so far.  Which requests fail, and
+    # their re-seeded guesses, are found in an untimed pass (a caller learns them from the status arrays between
+    # attempts); the timed region replays every launch of the chain, first attempts included, and an attempt's launch
+    # waits for every launch of the attempt before it (stream events), as it would for the statuses.
     retries = None
     if rank == 0 and not use_dist and a.config == "cfg2" and init is None and n_scenes == 1 and not a.no_retries:
         bp._sync()
         fence()
         failed_of = lambda st_: ((st_ & 0xff) > 3) | ((st_ & 0x100) != 0)
-        chains = []
-        solved_total, attempts_sum = 0, 0
         t_prep = time.time()
-        for r_, bt in enumerate(batches):
+        for bt in batches:
             launch(bt, bp)
         fence()
-        for r_, bt in enumerate(batches):
-            h_, t_, wp_, ts_ = sets[r_]
-            st_ = bt["status"].cpu().numpy()
-            todo = np.flatnonzero(failed_of(st_))
-            attempts = np.ones(B, dtype=np.int64)
-            chain = []
-            for att in range(1, 5):
-                if todo.size == 0:
-                    break
-                wp_n, ts_n = bp.init_guess(h_[todo], t_[todo], M - 1)
-                noise = np.stack([np.random.default_rng([20260, r_, int(i), att]).normal(0.0, 0.5, (D, M - 1)) for i in todo])
-                nb_ = int(todo.size)
-                with torch.cuda.stream(bt["st"]):
-                    e_ = dict(B=nb_, x0=torch.from_numpy(bp.pack_x(wp_n + noise, ts_n)).to(dev),
-                              head=torch.from_numpy(np.ascontiguousarray(h_[todo])).to(dev),
-                              tail=torch.from_numpy(np.ascontiguousarray(t_[todo])).to(dev),
-                              costs=torch.zeros(nb_, 4, dtype=torch.float64, device=dev), last=torch.zeros(nb_, 4, dtype=torch.float64, device=dev),
-                              nit=torch.zeros(nb_, dtype=torch.int32, device=dev), nfev=torch.zeros(nb_, dtype=torch.int32, device=dev),
-                              status=torch.zeros(nb_, dtype=torch.int32, device=dev), nsamp=torch.zeros(nb_, dtype=torch.int64, device=dev))
-                    e_["x"] = torch.empty_like(e_["x0"])
-                chain.append(e_)
-                ctx.set_stream(bt["st"].cuda_stream)
+        head_all = np.concatenate([st_[0] for st_ in sets]); tail_all = np.concatenate([st_[1] for st_ in sets])
+        n_req = B * n_sets
+        todo = np.flatnonzero(failed_of(torch.stack([bt["status"] for bt in batches]).cpu().numpy().reshape(-1)))
+        attempts = np.ones(n_req, dtype=np.int64)
+        chain = []
+        for att in range(1, 5):
+            if todo.size == 0:
+                break
+            wp_n, ts_n = bp.init_guess(head_all[todo], tail_all[todo], M - 1)
+            noise = np.stack([np.random.default_rng([20260, int(i), att]).normal(0.0, 0.5, (D, M - 1)) for i in todo])
+            nb_ = int(todo.size)
+            st_ = streams[att % n_lanes]
+            with torch.cuda.stream(st_):
+                e_ = dict(B=nb_, st=st_, x0=torch.from_numpy(bp.pack_x(wp_n + noise, ts_n)).to(dev),
+                          head=torch.from_numpy(np.ascontiguousarray(head_all[todo])).to(dev),
+                          tail=torch.from_numpy(np.ascontiguousarray(tail_all[todo])).to(dev),
+                          costs=torch.zeros(nb_, 4, dtype=torch.float64, device=dev), last=torch.zeros(nb_, 4, dtype=torch.float64, device=dev),
+                          nit=torch.zeros(nb_, dtype=torch.int32, device=dev), nfev=torch.zeros(nb_, dtype=torch.int32, device=dev),
+                          status=torch.zeros(nb_, dtype=torch.int32, device=dev), nsamp=torch.zeros(nb_, dtype=torch.int64, device=dev),
+                          order=torch.from_numpy(bp.expected_effort_order(head_all[todo], tail_all[todo], ts_n)).to(dev))
+                e_["x"] = torch.empty_like(e_["x0"])
+            chain.append(e_)
+
+            def launch_retry(e_):
+                ctx.set_stream(e_["st"].cuda_stream)
                 ctx.check(ctx.lib.neo_optimize_sample_counter(ctx.h, ctypes.c_void_p(e_["nsamp"].data_ptr())))
-                with torch.cuda.stream(bt["st"]):
-                    bp.optimize_dev(g3, e_["x"], e_["head"], e_["tail"], e_["costs"], e_["last"], e_["nit"], e_["nfev"], e_["status"], x0=e_["x0"])
-                bt["st"].synchronize()
-                attempts[todo] += 1
-                todo = todo[failed_of(e_["status"].cpu().numpy())]
-            chains.append(chain)
-            solved_total += B - int(todo.size)
-            attempts_sum += int(attempts.sum())
+                ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, ctypes.c_void_p(e_["order"].data_ptr()), e_["B"]))
+                with torch.cuda.stream(e_["st"]):
+                    bp.optimize_dev(g3, e_["x"], e_["head"], e_["tail"], e_["costs"], e_["last"], e_["nit"], e_["nfev"],
+                                    e_["status"], x0=e_["x0"])
+            launch_retry(e_)
+            st_.synchronize()
+            attempts[todo] += 1
+            todo = todo[failed_of(e_["status"].cpu().numpy())]
+        solved_total = n_req - int(todo.size)
         prep_s = time.time() - t_prep
 
         def chain_step():
-            for bt, chain in zip(batches, chains):
+            for bt in batches:
                 launch(bt, bp)
-                for e_ in chain:
-                    ctx.check(ctx.lib.neo_optimize_sample_counter(ctx.h, ctypes.c_void_p(e_["nsamp"].data_ptr())))
-                    with torch.cuda.stream(bt["st"]):
-                        bp.optimize_dev(g3, e_["x"], e_["head"], e_["tail"], e_["costs"], e_["last"], e_["nit"], e_["nfev"],
-                                        e_["status"], x0=e_["x0"])
+            done_prev = []
+            for st_ in streams:                      # attempt 2 needs the statuses of every first launch
+                ev_ = torch.cuda.Event(); ev_.record(st_); done_prev.append(ev_)
+            for e_ in chain:
+                for ev_ in done_prev:
+                    e_["st"].wait_event(ev_)
+                launch_retry(e_)
+                ev_ = torch.cuda.Event(); ev_.record(e_["st"]); done_prev = [ev_]
         fence()
         chain_step()
         fence()
@@ -785,17 +791,18 @@ def main():
         fence()
         el_r = time.perf_counter() - t0
         ctx.set_stream(None)
-        n_req = B * n_sets
-        retries = {"what": "warm_start_plan for every request (expert_planner.py:186-203): first launch of every batch plus the compacted "
-                           "re-launches of its failed requests (OverflowError statuses or `collision cost too large`), re-seeded "
-                           "straight line + N(0, 0.5), at most 5 attempts; all launches of the chain inside the timed region, "
-                           f"{n_lanes} batches in flight; the failed sets and their re-seeded guesses come from an untimed pass",
+        retries = {"what": "warm_start_plan for every request of a step (expert_planner.py:186-203; BatchPlanner.plan's chain): the first "
+                           "launch of every batch, then ONE compacted re-launch per attempt of the requests that failed so far "
+                           "(OverflowError statuses or `collision cost too large`), re-seeded straight line + N(0, 0.5), at most 5 "
+                           f"attempts; every launch of the chain inside the timed region, {n_lanes} batches in flight, an attempt waits "
+                           "for the attempt before it; the failed sets and their re-seeded guesses come from an untimed pass",
                    "max_attempts": 5, "steps": k_steps, "ms_per_step": 1e3 * el_r / k_steps,
                    "requests_per_s": n_req * k_steps / el_r,
                    "accepted_after_retries_traj_per_s": solved_total * k_steps / el_r,
                    "accepted_frac_first_attempt": main_run["accepted_frac"], "accepted_frac_after_retries": solved_total / n_req,
-                   "mean_attempts": attempts_sum / n_req, "launches_per_step": n_sets + sum(len(c_) for c_ in chains),
-                   "retry_trajectories_per_step": int(sum(e_["B"] for c_ in chains for e_ in c_)), "untimed_preparation_s": prep_s}
+                   "mean_attempts": float(attempts.sum()) / n_req, "launches_per_step": n_sets + len(chain),
+                   "retry_launch_sizes": [int(e_["B"]) for e_ in chain],
+                   "retry_trajectories_per_step": int(sum(e_["B"] for e_ in chain)), "untimed_preparation_s": prep_s}
     kernel_ms = main_run["kernel_ms"]
     launches = ctypes.c_int64(main_run["launches"])
     pp = lambda t: ctypes.c_void_p(t.data_ptr())

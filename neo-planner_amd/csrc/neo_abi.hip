@@ -373,21 +373,32 @@ template <typename SrcT, typename DstT>
 __global__ void pack3d_brick_kernel(const SrcT *__restrict__ src, int nx, int ny, int nz, int nbx, int nby, size_t total,
                                     DstT *__restrict__ dst) {
   constexpr int SHX = sizeof(DstT) == 4 ? 1 : 2, CX = (1 << SHX) + 1, PER = 128 / (int)sizeof(DstT);
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // four stored elements a thread: one 16-byte (fp32) or 8-byte (fp16) store (total is a multiple of PER)
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= total) return;
   const size_t blk = i / PER;
-  const int e = (int)(i - blk * PER);
-  float v = 0.0f;
-  if (e < 9 * CX) {
-    const int cz = e / (3 * CX), cy = (e / CX) % 3, cx = e % CX;
-    const int bx = (int)(blk % nbx), by = (int)((blk / nbx) % nby), bz = (int)(blk / ((size_t)nbx * nby));
-    const int x = min((bx << SHX) + cx, nx - 1), y = min(2 * by + cy, ny - 1), z = min(2 * bz + cz, nz - 1);
-    v = (float)src[((size_t)z * ny + y) * nx + x];
+  const int e0 = (int)(i - blk * PER);
+  const int bx = (int)(blk % nbx), by = (int)((blk / nbx) % nby), bz = (int)(blk / ((size_t)nbx * nby));
+  float v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = e0 + k;
+    v[k] = 0.0f;
+    if (e < 9 * CX) {
+      const int cz = e / (3 * CX), cy = (e / CX) % 3, cx = e % CX;
+      const int x = min((bx << SHX) + cx, nx - 1), y = min(2 * by + cy, ny - 1), z = min(2 * bz + cz, nz - 1);
+      v[k] = (float)src[((size_t)z * ny + y) * nx + x];
+    }
   }
-  if constexpr (sizeof(DstT) == 2)
-    dst[i] = __float2half(v);
-  else
-    dst[i] = (DstT)v;
+  if constexpr (sizeof(DstT) == 2) {
+    const __half2 lo = __floats2half2_rn(v[0], v[1]), hi = __floats2half2_rn(v[2], v[3]);
+    uint2 u;
+    u.x = *reinterpret_cast<const unsigned int *>(&lo);
+    u.y = *reinterpret_cast<const unsigned int *>(&hi);
+    *reinterpret_cast<uint2 *>(dst + i) = u;
+  } else {
+    *reinterpret_cast<float4 *>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
+  }
 }
 
 // get_full_state_cmd (traj_utils.py:85-195): one wavefront per trajectory solves the
@@ -919,7 +930,7 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
       hipLaunchKernelGGL((KERNEL<float, __half>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz, (__half *)field.p);   \
   } while (0)
   if (layout == NEO_LAYOUT_BRICK) {
-    const dim3 gb((unsigned)((nstore + 255) / 256));
+    const dim3 gb((unsigned)((nstore / 4 + 255) / 256));
     if (src_dtype == NEO_F64 && store_dtype == NEO_F32)
       hipLaunchKernelGGL((pack3d_brick_kernel<double, float>), gb, blk, 0, c->stream, (const double *)src, nx, ny, nz, nbx, nby, nstore, (float *)field.p);
     else if (src_dtype == NEO_F64)
