@@ -1118,7 +1118,7 @@ def main():
                 sys.path.insert(0, os.path.join(REPO, "tools"))
                 import ref_fixture_parity as rfp
                 g6 = rfp.g6_report()
-                g1 = rfp.g1_report(with_reference_jump=False)
+                g1 = rfp.g1_report()
                 g3 = rfp.g3_summary(rfp.g3_report())
                 keep = ("n", "finals_within_1e_4", "finals_within_1e_2", "cost_within_1e_4", "cost_within_1e_2", "same_nfev",
                         "x_rel_median", "cost_rel_median", "mean_nfev", "same_exception", "exceptions", "exits")

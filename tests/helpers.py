@@ -22,3 +22,22 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     denom = max(np.max(np.abs(b)), 1e-300)
     return float(np.max(np.abs(a - b)) / denom)
+
+
+def reference_jump(d, M, rel_noise=4e-6, trials=12):
+    """how far the REFERENCE's own cost moves when x moves by fp32-sized noise: the objective is discontinuous (nearest
+    cell lookups, esdf.py:61-62; int(T / delta_t) sample counts, expert_planner.py:401) -- a point within ~1e-4 m of a
+    cell face or a duration within 1e-6 of a multiple of delta_t is a point where ANY fp32 evaluation may land on the other
+    side.  Evaluated with the pinned NumPy oracle (bit-equal to the reference on G1)."""
+    from oracle import minco_np as onp
+    t = f"M{M}_"
+    x = d[t + "x"]
+    o2 = onp.GridESDF(d["occ"], float(d["res"]), d["occ"].shape[1], d["occ"].shape[0], d["origin"])
+    pl = onp.OraclePlanner(onp.PlannerParams())
+    pl.read_planning_conditions(o2, d[t + "head"], d[t + "tail"], x[:2 * (M - 1)].reshape(2, M - 1), np.ones(M))
+    c0 = pl.get_cost(x)
+    rng = np.random.default_rng(M)
+    jump = 0.0
+    for _ in range(trials):
+        jump = max(jump, abs(pl.get_cost(x * (1.0 + rel_noise * rng.standard_normal(x.shape))) - c0) / abs(c0))
+    return float(jump)

@@ -28,7 +28,8 @@ def test_g1_every_mode_against_the_reference_evaluation():
     nearest-cell map or a duration next to a multiple of delta_t.  Those cases are held to the reference's OWN jump
     under fp32-sized noise on x (measured with the pinned oracle): the device may not be further from the reference than
     the reference is from itself a few 1e-6 away."""
-    r = rfp.g1_report()
+    from helpers import reference_jump
+    r = rfp.g1_report(jump_fn=reference_jump)
     print({m: (v["cost_max"], v["cost_median"], len(v["beyond"])) for m, v in r.items()})
     assert r["f64"]["n"] == 24
     assert not r["f64"]["beyond"] and not r["f32"]["beyond"], (r["f64"]["beyond"], r["f32"]["beyond"])

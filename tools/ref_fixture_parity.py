@@ -56,28 +56,11 @@ def _gpu_map(npa, synth, occ, res, origin):
 G1_TOL = {"f64": 1e-10, "f32": 2e-5, "f32x": 4e-5}
 
 
-def reference_jump(d, M, rel_noise=4e-6, trials=12):
-    """how far the REFERENCE's own cost moves when x moves by fp32-sized noise: the objective is discontinuous (nearest
-    cell lookups, esdf.py:61-62; int(T / delta_t) sample counts, expert_planner.py:401) -- a point within ~1e-4 m of a
-    cell face or a duration within 1e-6 of a multiple of delta_t is a point where ANY fp32 evaluation may land on the other
-    side.  Evaluated with the pinned NumPy oracle (bit-equal to the reference on G1)."""
-    from oracle import minco_np as onp
-    t = f"M{M}_"
-    x = d[t + "x"]
-    o2 = onp.GridESDF(d["occ"], float(d["res"]), d["occ"].shape[1], d["occ"].shape[0], d["origin"])
-    pl = onp.OraclePlanner(onp.PlannerParams())
-    pl.read_planning_conditions(o2, d[t + "head"], d[t + "tail"], x[:2 * (M - 1)].reshape(2, M - 1), np.ones(M))
-    c0 = pl.get_cost(x)
-    rng = np.random.default_rng(M)
-    jump = 0.0
-    for _ in range(trials):
-        jump = max(jump, abs(pl.get_cost(x * (1.0 + rel_noise * rng.standard_normal(x.shape))) - c0) / abs(c0))
-    return float(jump)
-
-
-def g1_report(modes=MODES, with_reference_jump=True):
+def g1_report(modes=MODES, jump_fn=None):
     """the 8 fixtures x M in {3, 21, 41}: relative deviations of one evaluation from the reference's, per mode the maximum,
-    the median and every case beyond the mode's tolerance -- with the reference objective's own jump there"""
+    the median and every case beyond the mode's tolerance -- with the reference objective's own jump there when the caller
+    supplies `jump_fn(d, M)` (tests/helpers.py:reference_jump evaluates it with the pinned oracle; this module, which
+    bench.py's GPU process imports, never touches oracle/)"""
     import neo_planner_amd as npa
     from neo_planner_amd import synth
     out = {m: dict(tolerance=G1_TOL[m], cost=[], costs=[], grad=[], coeffs=[], beyond=[]) for m in modes}
@@ -98,8 +81,8 @@ def g1_report(modes=MODES, with_reference_jump=True):
                 if max(e["cost"], e["costs"], e["grad"]) > G1_TOL[mode]:
                     o["beyond"].append(dict(fixture=os.path.basename(path), M=M, cost=float(e["cost"]), costs=float(e["costs"]),
                                             grad=float(e["grad"])))
-                    if with_reference_jump:      # (the oracle: tests and the stand-alone report only, never bench.py's GPU process)
-                        o["beyond"][-1]["reference_jump_under_4e_6_noise"] = reference_jump(d, M)
+                    if jump_fn is not None:
+                        o["beyond"][-1]["reference_jump_under_4e_6_noise"] = jump_fn(d, M)
     for o in out.values():
         o["n"] = len(o["cost"])
         for k in ("cost", "costs", "grad", "coeffs"):
@@ -301,7 +284,9 @@ def g6_report(modes=MODES, limit=None):
 
 
 def main():
-    rep = dict(g1=g1_report(), g3_rows=None, g3=None, g6=None)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from helpers import reference_jump          # (the pinned oracle: test infrastructure)
+    rep = dict(g1=g1_report(jump_fn=reference_jump), g3_rows=None, g3=None, g6=None)
     rows = g3_report()
     rep["g3_rows"] = rows
     rep["g3"] = g3_summary(rows)
