@@ -37,7 +37,12 @@ def test_g1_every_mode_against_the_reference_evaluation():
     x = r["f32x"]
     assert x["within_tolerance"] >= 20 and x["cost_median"] < 2e-6 and x["grad_median"] < 2e-5, x
     for b in x["beyond"]:
-        assert b["reference_jump_under_4e_6_noise"] >= 0.3 * b["cost"], b
+        # cost and cost terms against the reference's own cost jump, the gradient against its own gradient jump (the
+        # nearest-cell gradient is piecewise constant: it jumps at faces where the distance does not)
+        if max(b["cost"], b["costs"]) > rfp.G1_TOL["f32x"]:
+            assert b["reference_jump_under_4e_6_noise"] >= 0.3 * b["cost"], b
+        if b["grad"] > rfp.G1_TOL["f32x"]:
+            assert b["reference_gradient_jump_under_4e_6_noise"] >= 0.3 * b["grad"], b
 
 
 def test_g3_every_recorded_reference_run_in_every_mode():

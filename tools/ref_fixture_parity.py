@@ -82,7 +82,9 @@ def g1_report(modes=MODES, jump_fn=None):
                     o["beyond"].append(dict(fixture=os.path.basename(path), M=M, cost=float(e["cost"]), costs=float(e["costs"]),
                                             grad=float(e["grad"])))
                     if jump_fn is not None:
-                        o["beyond"][-1]["reference_jump_under_4e_6_noise"] = jump_fn(d, M)
+                        cj, gj = jump_fn(d, M)
+                        o["beyond"][-1]["reference_jump_under_4e_6_noise"] = cj
+                        o["beyond"][-1]["reference_gradient_jump_under_4e_6_noise"] = gj
     for o in out.values():
         o["n"] = len(o["cost"])
         for k in ("cost", "costs", "grad", "coeffs"):
