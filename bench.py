@@ -78,7 +78,10 @@ def pmc_profile(kernel, default_workload):
     if not files or not default_workload:
         return {}, None
     try:
-        ks = json.load(open(files[-1]))["kernels"]
+        prof = json.load(open(files[-1]))
+        if "--config" in prof.get("command", "") and "--config cfg2" not in prof.get("command", ""):
+            return {}, None          # (counters of another configuration: profiles/*_counters.json is where they belong)
+        ks = prof["kernels"]
         k = ks[kernel] if kernel in ks else ks[kernel.split("@")[0]]    # (profiles before round 3 are not keyed by grid)
         return {c: v["mean_per_dispatch"] for c, v in k.items() if "mean_per_dispatch" in v}, os.path.relpath(files[-1], REPO)
     except Exception:
