@@ -21,6 +21,7 @@ int launch_eval(neo_ctx *c, const MapT &map, const EvalArgs &a) {
   switch (slots_for(a.M, D)) {
     case 1: NEO_EVAL(1); break;
     case 2: NEO_EVAL(2); break;
+    case 3: NEO_EVAL_LG(3, WaveLanes); break;
     default: NEO_EVAL_LG(4, WaveLanes); break;
   }
 #undef NEO_EVAL_LG

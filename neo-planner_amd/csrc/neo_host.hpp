@@ -147,11 +147,11 @@ struct SampleArgs {
   double *costs2, *grad_C, *grad_T;
 };
 
-// FLAT slots of the optimiser vectors: n <= 64, 128 or 256 variables
+// FLAT slots of the optimiser vectors: n <= 64, 128, 192 or 256 variables
 inline int slots_for(int M, int D) {
   const int n = D * (M - 1) + M;
   const int ns = (n + kWave - 1) / kWave;
-  return ns <= 1 ? 1 : (ns == 2 ? 2 : 4);
+  return ns <= 3 ? (ns < 1 ? 1 : ns) : 4;  // (3: cfg5's n = 161 -- a quarter fewer optimiser-vector instructions than 4 slots)
 }
 
 // ---- per-family dispatch (neo_disp_*.hip)

@@ -31,6 +31,9 @@
 // 889 k at two per SIMD without spills; LDS: fp32 pairs + staging = 12.6 KB of the 13.3 KB a twelfth of a CU has
 #define NEO_X_OCC 3
 #endif
+#ifndef NEO_SM_MAX_SLOTS
+#define NEO_SM_MAX_SLOTS 2  // FLAT slots up to which the optimiser runs as the resumable state machine (neo_lbfgs_sm.hpp)
+#endif
 #ifndef NEO_W2_MAX_SLOTS
 #define NEO_W2_MAX_SLOTS 4  // two waves per SIMD for every n <= 256 (four FLAT slots: with fp32 pairs, pairs_in_f32)
 #endif
@@ -147,9 +150,11 @@ struct DevBackend {
 #pragma unroll
     for (int k = 0; k < NS; ++k) v.v[k] *= (Num)s;
   }
-  // element k * 64 + lane of a FLAT vector exists.  The kernel with NS slots is launched for (NS / 2) * 64 < n <=
-  // NS * 64 (slots_for), so the first NS / 2 slots are full in every lane: no exec masking around their LDS accesses.
-  __device__ __forceinline__ bool in_range(int k, int lane) const { return k < NS / 2 || k * kWave + lane < t.n; }
+  // element k * 64 + lane of a FLAT vector exists.  The kernel with NS slots is launched for kFull * 64 < n <= NS * 64
+  // (slots_for: kFull = 0, 1, 2, 2 for NS = 1, 2, 3, 4), so the first kFull slots are full in every lane: no exec masking
+  // around their LDS accesses.
+  static constexpr int kFull = NS == 3 ? 2 : NS / 2;
+  __device__ __forceinline__ bool in_range(int k, int lane) const { return k < kFull || k * kWave + lane < t.n; }
   __device__ __forceinline__ void hist_put(int slot, const Vec &s, const Vec &y) {
     const int lane = lane_id();
 #pragma unroll
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   // lbfgs_minimize) -- ONE inlined copy of the evaluation instead of two: 36 % less code and no spills in the cfg2
   // two-waves kernel.  Four FLAT slots (n > 128, cfg5): the compiler keeps the machine's vectors in private memory
   // (1 KB of scratch, 3x slower), so those instantiations run the straight-line form.
-  if constexpr (NS <= 2) {
+  if constexpr (NS <= NEO_SM_MAX_SLOTS) {
     LbfgsMachine<BE> mach(be, o);
     mach.x = xv;
     mach.begin();

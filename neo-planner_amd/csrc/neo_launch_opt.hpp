@@ -54,6 +54,12 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
   switch (slots_for(a.M, D)) {
     case 1: NEO_OPT(1); break;
     case 2: NEO_OPT(2); break;
+    case 3:
+      if constexpr (WAVES == 1 || NEO_W2_MAX_SLOTS >= 4)
+        NEO_OPT_LG(3, WaveLanes);  // (n > 128 means D * M > 64: lane = piece)
+      else
+        return fail(c, NEO_ERR_INVALID, "n > 128 variables: this build has no two-waves kernel for three FLAT slots");
+      break;
     default:
       if constexpr (WAVES == 1 || NEO_W2_MAX_SLOTS >= 4)
         NEO_OPT_LG(4, WaveLanes);  // (two waves only up to NEO_W2_MAX_SLOTS)

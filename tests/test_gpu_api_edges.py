@@ -572,3 +572,40 @@ def test_batched_plan_with_retries_like_warm_start_plan():
     w, t = pl.generate_init_variables(head[0, :2], tail[0, :2])
     wb, tb = bp.init_guess(head[:1], tail[:1], 2)
     assert np.allclose(wb[0], w, rtol=1e-14, atol=0) and np.array_equal(tb[0], t)
+
+
+def test_dispatch_order_changes_nothing_but_the_order_of_execution():
+    """neo_optimize_dispatch_order (effort order of the optimiser, XCD-aware spatial order of the ESDF-lookup kernel,
+    BatchPlanner.spatial_order): results stay in the caller's order and are bit-identical under any permutation, for the
+    stand-alone sampled-terms kernel and for whole optimiser runs; a permutation of another batch size is ignored"""
+    import ctypes
+    import torch
+    dev = torch.device("cuda", 0)
+    dist = synth.esdf_3d(2, n=100, res=0.3, canopy=20)
+    ctx = _lib.Context(0)
+    g3 = npa.ESDF3D(torch.from_numpy(dist).to(dev), 0.3, synth.DOMAIN_ORIGIN, store="f32", layout="brick", ctx=ctx)
+    B, M, D = 1000, 21, 3
+    head, tail, wp, ts = synth.replan_requests(7, B, M - 1, D=3, **synth.VOLUME)
+    bp = npa.BatchPlanner(ctx=ctx, sample_dtype="f32x")
+    x0 = bp.pack_x(wp, ts)
+    e = bp.cost_grad(g3, x0, head, tail, want_coeffs=True)
+    ref_s = bp.sampled_terms(g3, e["coeffs"], ts)
+    ref_o = bp.optimize(g3, x0, head, tail, order=False)
+    rng = np.random.default_rng(3)
+    for perm in (npa.BatchPlanner.spatial_order(head, tail), npa.BatchPlanner.spatial_order(head, tail, chunk=16),
+                 rng.permutation(B).astype(np.int32)):
+        assert sorted(perm.tolist()) == list(range(B))
+        ctx.check(ctx.lib.neo_optimize_dispatch_order_host(ctx.h, _lib.ptr(np.ascontiguousarray(perm, dtype=np.int32)), B))
+        got = bp.sampled_terms(g3, e["coeffs"], ts)
+        for k in ("costs2", "grad_C", "grad_T"):
+            assert np.array_equal(got[k], ref_s[k]), k
+        # (BatchPlanner.optimize installs its own order; drive the ABI directly to keep this one)
+        x = x0.copy()
+        costs = np.zeros((B, 4)); last = np.zeros((B, 4)); nit = np.zeros(B, np.int32); nfev = np.zeros(B, np.int32); st = np.zeros(B, np.int32)
+        ctx.check(ctx.lib.neo_optimize_batch(ctx.h, g3.scene_id, None, B, M, D, _lib.ptr(x), _lib.ptr(head), _lib.ptr(tail), _lib.ptr(costs),
+                                             _lib.ptr(last), _lib.ptr(nit), _lib.ptr(nfev), _lib.ptr(st)))
+        assert np.array_equal(x, ref_o["x"]) and np.array_equal(nfev, ref_o["nfev"]) and np.array_equal(costs, ref_o["costs"])
+    # a permutation given for another batch size does not apply
+    got = bp.sampled_terms(g3, e["coeffs"][:500], ts[:500])
+    assert np.array_equal(got["grad_C"], ref_s["grad_C"][:500])
+    ctx.check(ctx.lib.neo_optimize_dispatch_order_host(ctx.h, None, 0))
