@@ -609,3 +609,53 @@ def test_dispatch_order_changes_nothing_but_the_order_of_execution():
     got = bp.sampled_terms(g3, e["coeffs"][:500], ts[:500])
     assert np.array_equal(got["grad_C"], ref_s["grad_C"][:500])
     ctx.check(ctx.lib.neo_optimize_dispatch_order_host(ctx.h, None, 0))
+
+
+def test_optimiser_and_evaluation_kernels_compute_the_same_bits_in_the_all_fp32_mode():
+    """The all-fp32 optimiser kernel keeps the cyclic reduction's multipliers in dynamic LDS and folds the sampled partials
+    through per-piece accumulators; the evaluation kernel keeps them in static LDS and folds through rows.  Both must be
+    the same arithmetic: every point a run evaluates (neo_optimize_trace_xg) gives, re-evaluated by neo_cost_grad_batch,
+    the gradient the run saw, bit for bit.  With the multiplier reuse switched off (flags bit 4096: the adjoint reduces
+    K^T itself) the gradients agree to fp32 round-off and the batch statistics are the same."""
+    import ctypes
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx = _lib.Context(0)
+    dist = synth.esdf_3d(5, n=120, res=0.25, canopy=30)
+    g3 = npa.ESDF3D(torch.from_numpy(dist).to(dev), 0.25, synth.DOMAIN_ORIGIN, store="f32", layout="brick", ctx=ctx)
+    B, M, D, CAP = 64, 21, 3, 600
+    n = D * (M - 1) + M
+    head, tail, wp, ts = synth.replan_requests(11, B, M - 1, D=3, **synth.VOLUME)
+    bp = npa.BatchPlanner(ctx=ctx, sample_dtype="f32x")
+    bp._sync()
+    x0 = bp.pack_x(wp, ts)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_x0, d_x, d_h, d_t = t(x0), torch.empty(B, n, dtype=torch.float64, device=dev), t(head), t(tail)
+    costs = torch.zeros(B, 4, dtype=torch.float64, device=dev); last = torch.zeros_like(costs)
+    nit = torch.zeros(B, dtype=torch.int32, device=dev); nfev = torch.zeros_like(nit); st = torch.zeros_like(nit)
+    xg = torch.zeros(B, CAP, 2, n, dtype=torch.float64, device=dev)
+    ctx.check(ctx.lib.neo_optimize_trace_xg(ctx.h, ctypes.c_void_p(xg.data_ptr()), CAP))
+    bp.optimize_dev(g3, d_x, d_h, d_t, costs, last, nit, nfev, st, x0=d_x0)
+    ctx.synchronize()
+    ctx.check(ctx.lib.neo_optimize_trace_xg(ctx.h, None, 0))
+    nf = nfev.cpu().numpy(); xgh = xg.cpu().numpy()
+    checked = 0
+    for b in range(0, B, 4):
+        E = min(int(nf[b]), CAP)
+        pts = xgh[b, :E, 0]
+        e = bp.cost_grad(g3, pts, np.repeat(head[b:b + 1], E, axis=0), np.repeat(tail[b:b + 1], E, axis=0))
+        ok = e["status"] == 0
+        assert np.array_equal(e["grad"][ok], xgh[b, :E, 1][ok]), b
+        checked += int(ok.sum())
+    assert checked > 1000
+    # the same batch without the reuse
+    bq = npa.BatchPlanner(ctx=ctx, sample_dtype="f32x")
+    bq.flags |= 4096
+    r_on = bp.optimize(g3, x0, head, tail)
+    r_off = bq.optimize(g3, x0, head, tail)
+    e_on = bp.cost_grad(g3, x0, head, tail)       # (the evaluation kernel reuses whatever the flags say nothing about: compare the optimisers)
+    assert abs(r_on["nfev"].mean() - r_off["nfev"].mean()) <= 0.1 * r_off["nfev"].mean()
+    both = (r_on["status"] <= 1) & (r_off["status"] <= 1)
+    assert both.mean() > 0.7
+    assert abs(np.median(r_on["final_cost"][both]) - np.median(r_off["final_cost"][both])) <= 2e-2 * np.median(r_off["final_cost"][both])
+    assert np.all(np.isfinite(e_on["grad"]))
