@@ -182,8 +182,12 @@ constexpr int kSqInf = 1 << 28;
 // SrcT = uint16_t: plane distances from row distances (squared while the tile is loaded); uint32_t: volume distances
 // from plane distances.  `stride_line` = elements between consecutive voxels of a line, `stride_slab` = elements
 // between the slabs a block row works on (grid.y), nline = voxels per line.  Dynamic LDS: nline * TX * 4 (uint16 source) or 6 bytes.
+#ifndef NEO_EDT_THREADS
+#define NEO_EDT_THREADS 256  // threads of a line-pass block (experiments: 512, 1024)
+#endif
+constexpr int kEdtThreads = NEO_EDT_THREADS;
 template <typename SrcT, int TX, bool FINAL>
-__global__ __launch_bounds__(256) void edt3_line_kernel(const SrcT *__restrict__ src, int nx, int nline, size_t stride_line,
+__global__ __launch_bounds__(kEdtThreads) void edt3_line_kernel(const SrcT *__restrict__ src, int nx, int nline, size_t stride_line,
                                                         size_t stride_slab, double res, uint32_t *__restrict__ out_sq,
                                                         float *__restrict__ out_dist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256) void edt3_line_kernel(const SrcT *__restrict__
   };
   const int x0 = blockIdx.x * TX;
   const size_t base = (size_t)blockIdx.y * stride_slab;
-  for (int i = threadIdx.x; i < nline * TX; i += 256) {
+  for (int i = threadIdx.x; i < nline * TX; i += kEdtThreads) {
     const int q = i / TX, xl = i - q * TX;
     FT v = sizeof(SrcT) == 2 ? (FT)kXInf : (FT)kSqInf;
     if (x0 + xl < nx) v = (FT)src[base + (size_t)q * stride_line + x0 + xl];
@@ -228,11 +232,11 @@ __global__ __launch_bounds__(256) void edt3_line_kernel(const SrcT *__restrict__
       if (c < best) { best = c; arg = q; }
     }
   };
-  __shared__ int part_best[256];
-  __shared__ int part_arg[256];
+  __shared__ int part_best[kEdtThreads];
+  __shared__ int part_arg[kEdtThreads];
   auto level = [&](int npts, int p0, int dp, int S) {
     int G = 1;
-    while (G < 8 && npts * TX * G * 2 <= 256) G *= 2;
+    while (G < 8 && npts * TX * G * 2 <= kEdtThreads) G *= 2;
     const int items = npts * TX * G;
     int p = 0, xl = 0, g = 0;
     const bool mine = (int)threadIdx.x < items || G == 1;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void edt3_line_kernel(const SrcT *__restrict__
         am[p * TX + xl] = (uint16_t)arg;
       }
     } else {
-      for (int it = threadIdx.x; it < items; it += 256) {
+      for (int it = threadIdx.x; it < items; it += kEdtThreads) {
         const int k = it / TX;
         xl = it - k * TX;
         p = min(p0 + k * dp, nline - 1);
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256) void edt3_line_kernel(const SrcT *__restrict__
   while (top < nline - 1) top <<= 1;
   for (int S = top >> 1; S >= 1; S >>= 1)
     level((nline - 1 - S + 2 * S - 1) / (2 * S), S, 2 * S, S);  // points p = S + 2 S k < nline - 1
-  for (int i = threadIdx.x; i < nline * TX; i += 256) {
+  for (int i = threadIdx.x; i < nline * TX; i += kEdtThreads) {
     const int p = i / TX, xl = i - p * TX;
     if (x0 + xl >= nx) continue;
     const int q = am[i], dq = p - q;
@@ -990,11 +994,11 @@ int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_d
                          c->stream, src, nx, rows, d_gx);
       // tiles of at most 64 KB of LDS INCLUDING the kernel's 2 KB of static part_best / part_arg (4 bytes a voxel in the y
       // pass, 6 in the z pass): TX x-columns by the whole line
-      constexpr size_t kEdtTile = 65536 - 2 * 256 * sizeof(int);
+      constexpr size_t kEdtTile = 65536 - 2 * kEdtThreads * sizeof(int);
       const size_t plane = (size_t)nx * ny;
 #define NEO_EDT_LINE(SRC, TXV, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd)                                 \
   hipLaunchKernelGGL((edt3_line_kernel<SRC, TXV, FINAL>), dim3((unsigned)((nx + TXV - 1) / TXV), (unsigned)(nslab)), \
-                     dim3(256), (size_t)(nline) * TXV * (sizeof(SRC) == 2 ? 4 : 6), c->stream, srcp, nx, nline, sline,    \
+                     dim3(kEdtThreads), (size_t)(nline) * TXV * (sizeof(SRC) == 2 ? 4 : 6), c->stream, srcp, nx, nline, sline, \
                      sslab, res, outsq, outd)
       // 16 columns a tile while that keeps four or more blocks on a CU (measured at 300^3: y pass 248 -> 204 us, z pass
       // 384 -> 252 us against 32 columns; 8 columns in the z pass: 278), else the widest tile that fits 64 KB
