@@ -122,7 +122,9 @@ typedef struct neo_params {
  * fp64 solve to ~1e-5 instead of 2e-6; the optimiser's statistics (evaluations, final costs) are those of the default
  * mode.  Opt-in throughput mode. */
 #define NEO_FLAG_F32_SOLVE 2048
-/* bits 1..16 switch phases off for timing experiments (tools/): leave them 0 */
+/* bits 1..16 switch phases off for timing experiments (tools/), 512 forces lane = piece, 4096 makes the all-fp32
+ * adjoint pass reduce the transposed joint system itself instead of reusing the forward reduction's multipliers
+ * (comparison runs): leave them 0 */
 
 /* ---- lifetime ------------------------------------------------------------- */
 int neo_abi_version(void);

@@ -90,7 +90,7 @@ struct DevBackend {
                  // holds the lane assignment's segment table and the rows of the per-piece fold (minco_sample)
   static constexpr int kStage = stage_doubles<D, NS, Real>();
   bool fold_rows = true;  // xs has all kStage doubles (false: only NS * 64, the fold stays in registers)
-  bool fold_acc = false;  // xs holds [M][20] per-piece accumulators instead of the rows (minco_sample; the kernels that keep
+  bool fold_acc = false;  // xs holds [M][fold_acc_stride(D)] per-piece accumulators instead of the rows (minco_sample; the kernels that keep
                           // the cyclic reduction's multipliers in LDS: launch_opt)
   double *sc;    // LDS [2m]: rho / alpha of the two-loop recursion
   LineSearch *lsp;  // LDS: line-search state (wave-uniform)
