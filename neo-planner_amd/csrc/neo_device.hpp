@@ -847,6 +847,8 @@ struct Traj {
   Num N[2][2];                 // pivot-block inverse of the joint system (lane = joint)
   const double *head, *tail;      // boundary states [3][D] in global memory (wave-uniform scalar loads)
   const Num *bnd;                 // lane = (piece, dimension) and lane groups: head [3][D] then tail [3][D] in LDS
+  Num *pcr_xch = nullptr;         // LDS [pcr_xch_elems]: exchange table of the cyclic reduction (the caller's staging buffer; nullptr:
+                                  // the neighbours' blocks travel by ds_bpermute)
   Num *pcr_mult = nullptr;        // LDS [levels][M][8] + [M][4]: the multipliers of the forward cyclic reduction, kept for the
                                   // adjoint pass (pcr_solve / pcr_solve_transposed); nullptr: the adjoint reduces K^T itself
 };
@@ -1038,7 +1040,7 @@ __device__ __forceinline__ void thomas_solve(int M, const Num (&Lo)[2][2], const
 // level k), hence K^-T = P_1^T ... P_last^T Dfin^-T, and the adjoint system K^T lambda = r needs no reduction of its own.
 template <int DL, class LG, typename Num>
 __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2], Num (&U)[2][2], Num (&R)[2][DL],
-                                          Num (&y)[2][DL], Num *mult = nullptr) {
+                                          Num (&y)[2][DL], Num *mult = nullptr, Num *xch = nullptr) {
   static_assert(LG::W == kWave, "written for lane groups that span the wavefront");
   const int p = LG::piece();
   const bool in = p >= 1 && p < M;
@@ -1092,18 +1094,50 @@ __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2]
       const int sp = lane - s * LG::S, sn = lane + s * LG::S;
       f2 Ip[2], Lp[2], Upv[2], In[2], Ln[2], Un[2];
       Num Rp[2][DL], Rn[2][DL];
+      if (xch != nullptr) {
+        // The neighbours' blocks through an LDS table instead of 24 + 4 DL ds_bpermute: every piece writes its I, L, U as
+        // three 16-byte stores (the lanes of a piece the same values), every lane reads the two neighbouring pieces'
+        // with six 16-byte loads; the right-hand sides travel as 8-byte pairs per lane.  Measured on the MI355X
+        // (tools/probe/valu_rate.hip): a ds_bpermute_b32 occupies the CU's LDS for as long as three quarters of a
+        // 16-byte access that moves four values -- and with four launches in flight the LDS pipe is what this kernel
+        // waits for (SQ_LDS_IDX_ACTIVE per evaluation x evaluations in flight ~ the CU's cycles).  Pieces without a
+        // neighbour at distance s read piece 0 / M - 1 instead: finite values times their exact-zero coupling block.
+        Quad *tab = reinterpret_cast<Quad *>(xch);
+        f2 *rx = reinterpret_cast<f2 *>(xch + (size_t)(M + 1) * 12);
+        lds_wave_sync();
+        tab[ps * 3 + 0] = Quad{Ir[0].x, Ir[0].y, Ir[1].x, Ir[1].y};
+        tab[ps * 3 + 1] = Quad{Lr[0].x, Lr[0].y, Lr[1].x, Lr[1].y};
+        tab[ps * 3 + 2] = Quad{Ur[0].x, Ur[0].y, Ur[1].x, Ur[1].y};
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        Ip[i] = fetch(Ir[i], sp);
-        Upv[i] = fetch(Ur[i], sp);
-        In[i] = fetch(Ir[i], sn);
-        Ln[i] = fetch(Lr[i], sn);
-        Lp[i] = fetch(Lr[i], sp);
-        Un[i] = fetch(Ur[i], sn);
+        for (int d = 0; d < DL; ++d) rx[lane * DL + d] = f2{R[0][d], R[1][d]};
+        lds_wave_sync();
+        // (both clamped into 0 .. M - 1, the slots that are always written -- also for the lanes beyond the last piece,
+        //  whose own values must stay finite: wrapped right-hand-side reads of real joints land on them)
+        const int pp = min(max(p - s, 0), M - 1), pn = min(p + s, M - 1);
+        const Quad qi = tab[pp * 3 + 0], ql = tab[pp * 3 + 1], qu = tab[pp * 3 + 2];
+        const Quad ni = tab[pn * 3 + 0], nl = tab[pn * 3 + 1], nu = tab[pn * 3 + 2];
+        Ip[0] = qi.xy; Ip[1] = qi.zw; Lp[0] = ql.xy; Lp[1] = ql.zw; Upv[0] = qu.xy; Upv[1] = qu.zw;
+        In[0] = ni.xy; In[1] = ni.zw; Ln[0] = nl.xy; Ln[1] = nl.zw; Un[0] = nu.xy; Un[1] = nu.zw;
 #pragma unroll
         for (int d = 0; d < DL; ++d) {
-          Rp[i][d] = __shfl(R[i][d], sp, kWave);
-          Rn[i][d] = __shfl(R[i][d], sn, kWave);
+          const f2 rp = rx[(sp & (kWave - 1)) * DL + d], rn = rx[(sn & (kWave - 1)) * DL + d];
+          Rp[0][d] = rp.x; Rp[1][d] = rp.y;
+          Rn[0][d] = rn.x; Rn[1][d] = rn.y;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          Ip[i] = fetch(Ir[i], sp);
+          Upv[i] = fetch(Ur[i], sp);
+          In[i] = fetch(Ir[i], sn);
+          Ln[i] = fetch(Lr[i], sn);
+          Lp[i] = fetch(Lr[i], sp);
+          Un[i] = fetch(Ur[i], sn);
+#pragma unroll
+          for (int d = 0; d < DL; ++d) {
+            Rp[i][d] = __shfl(R[i][d], sp, kWave);
+            Rn[i][d] = __shfl(R[i][d], sn, kWave);
+          }
         }
       }
       f2 pa[2], pg[2];  // -a, -g: the products as they come (a = -L Ip, g = -U In)
@@ -1131,6 +1165,7 @@ __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2]
       }
     }
     invert();
+    if (xch != nullptr) lds_wave_sync();  // (the exchange table is the caller's staging buffer again)
     if (keep) *reinterpret_cast<Quad *>(mult + (size_t)level * M * 8 + (size_t)ps * 4) = Quad{Ir[0].x, Ir[0].y, Ir[1].x, Ir[1].y};
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
@@ -1231,6 +1266,8 @@ __host__ __device__ __forceinline__ int pcr_levels(int M, bool f32 = true) {
   return n;
 }
 // (+ 8: the lanes beyond the last piece write one slot past each region)
+// floats of LDS the exchange table of pcr_solve takes: I, L, U of pieces 0 .. M, then one pair per lane and held dimension
+__host__ __device__ __forceinline__ int pcr_xch_elems(int M, int DL) { return (M + 1) * 12 + kWave * 2 * DL; }
 __host__ __device__ __forceinline__ int pcr_mult_elems(int M) { return (pcr_levels(M) * 8 + 4) * M + 8; }
 
 // The adjoint system K^T lambda = r from the multipliers pcr_solve left in `mult`:
@@ -1378,7 +1415,7 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
           Up[i][j] = lane == t.M - 1 ? Num(0.0) : Up[i][j];
         }
       NEO_MARK("fwd_pcr_begin");
-      pcr_solve<DL, LG, Num>(t.M, Lo, Di, Up, R, y, t.pcr_mult);
+      pcr_solve<DL, LG, Num>(t.M, Lo, Di, Up, R, y, t.pcr_mult, t.pcr_xch);
       NEO_MARK("fwd_pcr_end");
     } else {
       thomas_solve<DL, LG, Num>((prm.dbg & (2 | 16)) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);

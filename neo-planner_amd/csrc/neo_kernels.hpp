@@ -391,6 +391,8 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
   BE be(prm, map);
   if constexpr (kKeep) be.t.pcr_mult = mult_s;
   be.xs = xs;
+  if constexpr (sizeof(Num) == 4 && LG::W == kWave)   // (the staging doubles as the cyclic reduction's exchange table)
+    if (pcr_xch_elems(M, LG::dl(D)) * (int)sizeof(Num) <= stage_doubles<D, NS, Real>() * 8) be.t.pcr_xch = reinterpret_cast<Num *>(xs);
   be.sc = sc;
   be.lsp = &lsm;
   be.cst = cst;
@@ -475,6 +477,8 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
       be.fold_acc = true;
     }
   }
+  if constexpr (sizeof(Num) == 4 && LG::W == kWave)   // (the staging doubles as the cyclic reduction's exchange table)
+    if (be.fold_rows && pcr_xch_elems(M, LG::dl(D)) * (int)sizeof(Num) <= stage * 8) be.t.pcr_xch = reinterpret_cast<Num *>(dyn_lds);
   be.sc = sc;
   be.lsp = &lsm;
   be.cst = cst;

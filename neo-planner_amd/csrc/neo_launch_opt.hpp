@@ -25,7 +25,7 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
     if (sizeof(Num) == 4 && LG::S > 1 && !(c->params.flags & 4096)) {                                             \
       /* all-fp32, lane = (piece, dimension): room for the reduction's multipliers next to the pairs when the fold   \
          runs on per-piece accumulators (80 B a piece at D = 3) instead of rows (96 B a lane); flags bit 4096: off (comparison runs) */ \
-      const int acc = std::max(small, (a.M * fold_acc_stride(D) * 4 + 7) / 8);                                                    \
+      const int acc = std::max(std::max(small, (a.M * fold_acc_stride(D) * 4 + 7) / 8), (pcr_xch_elems(a.M, 1) * 4 + 7) / 8);                                                    \
       const size_t off = ((size_t)acc * 8 + pairs + 15) / 16 * 2;                                             \
       const size_t need = off * 8 + (size_t)pcr_mult_elems(a.M) * sizeof(float);                              \
       if (need <= lds_share) {                                                                                \
