@@ -1765,6 +1765,9 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
     ns = act ? ns_in : 0;
   } else {
     // hand the piece data to its L sample lanes (every sample lane needs all D dimensions of its piece)
+    // (round 4: through a table in the staging buffer -- two stores, five 16-byte loads, three syncs -- instead of the 6 D + 1
+    //  ds_bpermute, and the adjoint's four fetches a level the same way: measured slower, cfg2 1.413 -> 1.405 M traj/s and a
+    //  single batch 705 -> 643 k: the write -> read round trips sit on the dependent chain)
 #pragma unroll
     for (int k = 0; k < 6; ++k)
 #pragma unroll
@@ -1900,7 +1903,8 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
         const int pc = LG::piece();
         const int Lp = __shfl(sl.Lp, pc < M ? pc : 0, kWave);
         const bool have = pc < M && Lp > 0;
-        typedef Real Pair __attribute__((ext_vector_type(2)));
+        // (may_alias: the accumulators were written as 16-byte vectors)
+        typedef Real Pair __attribute__((ext_vector_type(2), may_alias));
         const Pair *src = reinterpret_cast<const Pair *>(fold_rows + (size_t)(have ? pc : 0) * RS + LG::dim0() * 6);
         const Pair p0 = src[0], p1 = src[1], p2 = src[2];
         const Real tpart = fold_rows[(size_t)(have ? pc : 0) * RS + 6 * D];
