@@ -659,3 +659,44 @@ def test_optimiser_and_evaluation_kernels_compute_the_same_bits_in_the_all_fp32_
     assert both.mean() > 0.7
     assert abs(np.median(r_on["final_cost"][both]) - np.median(r_off["final_cost"][both])) <= 2e-2 * np.median(r_off["final_cost"][both])
     assert np.all(np.isfinite(e_on["grad"]))
+
+
+def test_all_fp32_multiplier_reuse_for_every_piece_count_and_both_maps():
+    """The adjoint from the forward reduction's multipliers, the LDS exchange table and the accumulator fold, for every
+    piece count of the lane = (piece, dimension) layout (M = 2 .. 21 at D = 3, up to 32 on the 2-D map with D = 2) and
+    beyond it (lane = piece: exchange table only): against the same runs with the reuse switched off (flags bit 4096) --
+    per evaluation the two gradients agree to fp32 round-off, whole batches end with the same statistics, nothing is
+    ever non-finite -- after a kernel that leaves NaN patterns in LDS (unwritten-slot reads would pick them up)."""
+    import torch
+    rng = np.random.default_rng(5)
+    ctx = _lib.Context(0)
+    dev = torch.device("cuda", 0)
+    dist = synth.esdf_3d(4, n=100, res=0.3, canopy=20)
+    g3 = npa.ESDF3D(torch.from_numpy(dist).to(dev), 0.3, synth.DOMAIN_ORIGIN, store="f32", layout="brick", ctx=ctx)
+    occ = synth.occupancy_2d(4, count=30)
+    m2 = npa.ESDF(ctx=ctx)
+    m2.occupancy_map_cb(synth.OccupancyGridMsg(occ))
+    # poison LDS: a kernel whose staging holds NaN bit patterns at exit (the sampled-terms kernel fed NaN coefficients)
+    nanc = np.full((64, 6 * 21, 3), np.nan)
+    npa.BatchPlanner(ctx=ctx, sample_dtype="f32").sampled_terms(g3, nanc, np.full((64, 21), 2.0))
+    for D, scene, Ms in ((3, g3, (2, 3, 4, 5, 8, 9, 16, 17, 20, 21, 22, 31)), (2, m2, (2, 3, 7, 16, 21, 31, 32, 33))):
+        for M in Ms:
+            B = 96
+            head, tail, wp, ts = synth.replan_requests(100 + M, B, M - 1, D=D, length_range=(6.0, 20.0))
+            on = npa.BatchPlanner(ctx=ctx, sample_dtype="f32x")
+            off = npa.BatchPlanner(ctx=ctx, sample_dtype="f32x")
+            off.flags |= 4096
+            x0 = on.pack_x(wp, ts)
+            e_on, e_off = on.cost_grad(scene, x0, head, tail), off.cost_grad(scene, x0, head, tail)
+            assert np.all(np.isfinite(e_on["grad"])) and np.all(np.isfinite(e_on["cost"])), (D, M)
+            scale = np.abs(e_off["grad"]).max(axis=1)
+            assert np.all(np.abs(e_on["grad"] - e_off["grad"]).max(axis=1) <= 2e-4 * scale + 1e-6), (D, M)
+            r_on, r_off = on.optimize(scene, x0, head, tail), off.optimize(scene, x0, head, tail)
+            assert np.all(np.isfinite(r_on["x"])) and set(np.unique(r_on["status"])) <= {0, 1, 2, 4}, (D, M, np.unique(r_on["status"]))
+            assert abs(int((r_on["status"] <= 1).sum()) - int((r_off["status"] <= 1).sum())) <= 0.1 * B + 3, (D, M)
+            assert abs(r_on["nfev"].mean() - r_off["nfev"].mean()) <= 0.25 * r_off["nfev"].mean() + 3, (D, M)
+            both = (r_on["status"] <= 1) & (r_off["status"] <= 1)
+            if both.sum() >= 20:
+                med = np.median(r_off["final_cost"][both])
+                # (a hundred chaotic runs whose costs span three orders of magnitude: the median is a coarse figure)
+                assert abs(np.median(r_on["final_cost"][both]) - med) <= 0.3 * abs(med) + 1e-6, (D, M)
