@@ -177,6 +177,59 @@ __global__ __launch_bounds__(256) void edt3_x_kernel(const uint8_t *__restrict__
   }
 }
 
+// The same pass with V = 8 or 16 consecutive voxels per lane (rows of up to 64 V voxels, nx a multiple of four): ONE
+// pair of 4-byte loads per lane instead of a byte per lane and chunk, one prefix and one suffix scan per row, the
+// distances of the lane's voxels by two sweeps in registers, 8-byte stores (round 4: 69 -> see DESIGN.md at 300^3).
+template <int V>
+__global__ __launch_bounds__(256) void edt3_xv_kernel(const uint8_t *__restrict__ occ, int nx, size_t rows,
+                                                      uint16_t *__restrict__ gx) {
+  const int lane = lane_id(), wave = threadIdx.x / kWave;
+  const size_t row = (size_t)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const uint32_t *o = reinterpret_cast<const uint32_t *>(occ + row * nx);
+  const int idx0 = lane * V;
+  uint32_t w[V / 4];
+#pragma unroll
+  for (int k = 0; k < V / 4; ++k) w[k] = idx0 + 4 * k < nx ? o[(idx0 >> 2) + k] : 0u;
+  // bit k of m: voxel idx0 + k is occupied
+  uint32_t m = 0;
+#pragma unroll
+  for (int k = 0; k < V / 4; ++k) {
+    const uint32_t nz = (((w[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[k]) & 0x80808080u;  // bit 7 of every non-zero byte
+    m |= (((nz >> 7) & 1u) | ((nz >> 14) & 2u) | ((nz >> 21) & 4u) | ((nz >> 28) & 8u)) << (4 * k);
+  }
+  // nearest occupied voxel before the lane's group (index + 1, 0 = none) and after it (nx - index, 0 = none)
+  const int last_in = m ? idx0 + (31 - __clz((int)m)) + 1 : 0;
+  const int first_in = m ? nx - (idx0 + __ffs((int)m) - 1) : 0;
+  const int pre = wave_scan_max_nonneg(last_in);
+  int before = __shfl_up(pre, 1, kWave);
+  before = lane == 0 ? 0 : before;
+  const int rev = __shfl(first_in, kWave - 1 - lane, kWave);
+  const int suf = wave_scan_max_nonneg(rev);  // (in reversed lane order)
+  int after = __shfl(suf, kWave - 2 - lane >= 0 ? kWave - 2 - lane : 0, kWave);
+  after = lane == kWave - 1 ? 0 : after;
+  int left[V];
+  int last = before;
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    if ((m >> k) & 1u) last = idx0 + k + 1;
+    left[k] = last ? idx0 + k + 1 - last : kXInf;
+  }
+  int nxt = after;
+  uint16_t out[V];
+#pragma unroll
+  for (int k = V - 1; k >= 0; --k) {
+    if ((m >> k) & 1u) nxt = nx - (idx0 + k);
+    const int right = nxt ? (nx - nxt) - (idx0 + k) : kXInf;
+    out[k] = (uint16_t)min(min(left[k], right), kXInf);
+  }
+  uint2 *dst = reinterpret_cast<uint2 *>(gx + row * nx + idx0);
+#pragma unroll
+  for (int k = 0; k < V / 4; ++k)
+    if (idx0 + 4 * k < nx)
+      dst[k] = make_uint2((uint32_t)out[4 * k] | ((uint32_t)out[4 * k + 1] << 16), (uint32_t)out[4 * k + 2] | ((uint32_t)out[4 * k + 3] << 16));
+}
+
 constexpr int kSqInf = 1 << 28;
 
 // SrcT = uint16_t: plane distances from row distances (squared while the tile is loaded); uint32_t: volume distances
@@ -295,6 +348,181 @@ __global__ __launch_bounds__(kEdtThreads) void edt3_line_kernel(const SrcT *__re
   }
 }
 
+// The same monotone-minima line pass on PACKED KEYS (round 4), for volumes whose squared diagonal leaves room in 31 bits
+// (every scene of BASELINE.json: 300^3 needs 28 bits, 600^3 31).  With h(q) = f(q) + q^2 the cost of candidate q at point
+// p is f(q) + (p - q)^2 = h(q) - 2 p q + p^2; the tile holds hk(q) = (h(q) << qb) | q, and
+//     key(p, q) = hk(q) - q * (p << (qb + 1))        [= ((cost - p^2) << qb) | q]
+// orders the candidates of one point by (cost, q): the leftmost minimiser is ONE v_mad_i32_i24 and half a v_min3_i32 per
+// candidate instead of square / add / compare / two selects (the line passes are bound by vector issue: 4.0 k vector
+// instructions a wavefront, 72 % of the SIMDs' cycles, `tools/probe/pmc_edt.sh`).  Unreachable voxels enter as
+// `big` = nx^2 + ny^2 + nz^2 + 1, above every real squared distance, so a line's minimum is a real candidate whenever it
+// has one.  Same levels, same work distribution, bit-equal results (integers).
+template <typename SrcT, int TX, bool FINAL>
+__global__ __launch_bounds__(kEdtThreads) void edt3_line_keys_kernel(const SrcT *__restrict__ src, int nx, int nline,
+                                                                     size_t stride_line, size_t stride_slab, int nslab, double res,
+                                                                     int big, int qb, uint32_t *__restrict__ out_sq,
+                                                                     float *__restrict__ out_dist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+  static_assert((TX & (TX - 1)) == 0, "TX is a power of two");
+  constexpr int LX = TX == 32 ? 5 : (TX == 16 ? 4 : (TX == 8 ? 3 : (TX == 4 ? 2 : 1)));
+  int *hk = reinterpret_cast<int *>(tile_raw);                                                    // [nline][TX] keys
+  uint16_t *am = reinterpret_cast<uint16_t *>(tile_raw + (size_t)nline * TX * sizeof(int));       // [nline][TX] minimisers
+  // 1-D grid, XCD-aware: workgroup b runs on XCD b mod 8; the tiles of one slab share their rows' 128-byte lines (a row
+  // of a 16-column tile is 32 or 64 bytes), so a slab's tiles go to ONE XCD, one after the other, and meet in its L2
+  const int ntx = (nx + TX - 1) / TX;
+  const int bj = blockIdx.x >> 3, slab = (blockIdx.x & 7) + 8 * (bj / ntx);
+  if (slab >= nslab) return;
+  const int x0 = (bj % ntx) * TX;
+  const size_t base = (size_t)slab * stride_slab;
+  const int qmask = (1 << qb) - 1;
+  // the tile: several loads in flight per thread (one load per thread and trip left the pass waiting on memory latency:
+  // 84 of the y pass's 149 us at 300^3 were this loop and the store loop with the levels switched off) -- four
+  // neighbouring columns per load where the rows are aligned for it, eight rows per thread in flight
+  auto put = [&](int q, int xl, int v, bool in) {
+    int c = big;
+    if (in) {
+      if constexpr (sizeof(SrcT) == 2)
+        c = v >= kXInf ? big : v * v;
+      else
+        c = v >= kSqInf ? big : v;
+    }
+    hk[q * TX + xl] = ((c + q * q) << qb) | q;
+  };
+  if (TX >= 4 && ((nx | stride_line | stride_slab) & 3) == 0) {
+    struct alignas(4 * sizeof(SrcT)) Vec4 { SrcT v[4]; };
+    constexpr int CPR = TX / 4 > 0 ? TX / 4 : 1, RPP = kEdtThreads / CPR;  // threads a row, rows a pass of the block
+    const int xl = (threadIdx.x % CPR) * 4, r0 = threadIdx.x / CPR;
+    const bool in = x0 + xl < nx;  // (nx is a multiple of four: the four columns are in or out together)
+    constexpr int U = 8;
+    for (int qa = r0; qa < nline; qa += U * RPP) {
+      Vec4 w[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = qa + u * RPP;
+        if (q < nline && in) w[u] = *reinterpret_cast<const Vec4 *>(src + base + (size_t)q * stride_line + x0 + xl);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = qa + u * RPP;
+        if (q < nline) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) put(q, xl + e, in ? (int)w[u].v[e] : 0, in);
+        }
+      }
+    }
+  } else {
+    constexpr int U = 8;
+    for (int ia = threadIdx.x; ia < nline * TX; ia += U * kEdtThreads) {
+      int v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = ia + u * kEdtThreads, q = i >> LX, xl = i & (TX - 1);
+        v[u] = (i < nline * TX && x0 + xl < nx) ? (int)src[base + (size_t)q * stride_line + x0 + xl] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = ia + u * kEdtThreads, q = i >> LX, xl = i & (TX - 1);
+        if (i < nline * TX) put(q, xl, v[u], x0 + xl < nx);
+      }
+    }
+  }
+  __syncthreads();
+  // smallest key of the candidates a <= q <= b of column xl for the point with negP = -(p << (qb + 1)).  (No unrolling
+  // beyond the four written out: most ranges of the fine levels hold one to three candidates, and the kernel is bound
+  // by the instructions around the loop.)
+  auto scan = [&](int negP, int xl, int a, int b, int &best) {
+    int q = a;
+    const int *h = hk + a * TX + xl;
+    int t = __mul24(q, negP);
+#pragma clang loop unroll(disable)
+    for (; q + 3 <= b; q += 4, h += 4 * TX, t += 4 * negP) {
+      const int k0 = h[0], k1 = h[TX], k2 = h[2 * TX], k3 = h[3 * TX];
+      best = min(min(best, k0 + t), k1 + t + negP);
+      best = min(min(best, k2 + t + 2 * negP), k3 + t + 3 * negP);
+    }
+#pragma clang loop unroll(disable)
+    for (; q <= b; ++q, h += TX, t += negP) best = min(best, h[0] + t);
+  };
+  __shared__ int part_key[kEdtThreads];
+  const int my_xl = threadIdx.x & (TX - 1), my_k = threadIdx.x >> LX;
+  auto level = [&](int npts, int p0, int dp, int S) {
+    int G = 1, lg = 0;
+    while (G < 8 && npts * TX * G * 2 <= kEdtThreads) G *= 2, ++lg;
+    if (G > 1) {
+      const int items = npts * TX * G;
+      const bool mine = (int)threadIdx.x < items;
+      int p = 0, g = 0;
+      const int xl = my_xl;
+      if (mine) {
+        g = my_k & (G - 1);
+        p = min(p0 + (int)(threadIdx.x >> (LX + lg)) * dp, nline - 1);
+        const int lo = S ? am[(p - S) * TX + xl] : 0, hi = S ? am[min(p + S, nline - 1) * TX + xl] : nline - 1;
+        const int chunk = (hi - lo + G) >> lg, a = lo + g * chunk, b = min(hi, a + chunk - 1);
+        int best = 0x7fffffff;
+        scan(-(p << (qb + 1)), xl, a, b, best);
+        part_key[threadIdx.x] = best;
+      }
+      __syncthreads();
+      if (mine && g == 0) {
+        int best = part_key[threadIdx.x];
+        for (int j = 1; j < G; ++j) best = min(best, part_key[threadIdx.x + j * TX]);
+        am[p * TX + xl] = (uint16_t)(best & qmask);
+      }
+    } else {
+      // (every point of these levels has both neighbours: p = S + 2 S k < nline - 1)
+      const int xl = my_xl;
+      for (int k = my_k; k < npts; k += kEdtThreads / TX) {
+        const int p = p0 + k * dp;
+        const int lo = am[(p - S) * TX + xl], hi = am[min(p + S, nline - 1) * TX + xl];
+        int arg = lo;
+        if (lo != hi) {  // (neighbours with the same minimiser: it is this point's too)
+          int best = 0x7fffffff;
+          scan(-(p << (qb + 1)), xl, lo, hi, best);
+          arg = best & qmask;
+        }
+        am[p * TX + xl] = (uint16_t)arg;
+      }
+    }
+    __syncthreads();
+  };
+  level(2, 0, nline - 1, 0);  // the two end points: full scans
+  int top = 1;
+  while (top < nline - 1) top <<= 1;
+  for (int S = top >> 1; S >= 1; S >>= 1) level((nline - 1 - S + 2 * S - 1) / (2 * S), S, 2 * S, S);
+  auto result = [&](int p, int xl) {  // squared distance of voxel p of column xl (>= big: nothing occupied in reach)
+    const int q = am[p * TX + xl];
+    const int key = hk[q * TX + xl] - q * (p << (qb + 1));
+    return (key >> qb) + p * p;  // (arithmetic shift: the key is ((cost - p^2) << qb) | q)
+  };
+  auto emit = [&](int c) {
+    // (the correctly rounded fp64 root is 7 of the z pass's 157 us at 300^3 -- measured with an fp32 root in its place)
+    if constexpr (FINAL) return (float)(c >= big ? 1.0e4 : sqrt((double)c) * res);
+    else return c >= big ? (uint32_t)kSqInf : (uint32_t)c;
+  };
+  using OutT = std::conditional_t<FINAL, float, uint32_t>;
+  OutT *out = nullptr;
+  if constexpr (FINAL) out = out_dist; else out = out_sq;
+  if (TX >= 4 && ((nx | stride_line | stride_slab) & 3) == 0) {
+    struct alignas(16) Out4 { OutT v[4]; };
+    constexpr int CPR = TX / 4 > 0 ? TX / 4 : 1, RPP = kEdtThreads / CPR;
+    const int xl = (threadIdx.x % CPR) * 4;
+    if (x0 + xl < nx) {
+      for (int p = threadIdx.x / CPR; p < nline; p += RPP) {
+        Out4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.v[e] = emit(result(p, xl + e));
+        *reinterpret_cast<Out4 *>(out + base + (size_t)p * stride_line + x0 + xl) = o;
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < nline * TX; i += kEdtThreads) {
+      const int p = i >> LX, xl = i & (TX - 1);
+      if (x0 + xl >= nx) continue;
+      out[base + (size_t)p * stride_line + x0 + xl] = emit(result(p, xl));
+    }
+  }
+}
+
 // numpy.gradient, unit spacing: central differences inside, one-sided at the borders
 __global__ void gradient_pack_kernel(const double *__restrict__ dist, int W, int H, double4 *__restrict__ rec,
                                      double *__restrict__ gx_out, double *__restrict__ gy_out) {
@@ -372,36 +600,56 @@ __global__ void pack3d_cell8_kernel(const SrcT *__restrict__ src, int nx, int ny
 
 // corner-brick layout: one 128-byte line per block of 2 x 2 x 2 cells (fp32: 32 elements a line, 27 used) or 4 x 2 x 2
 // cells (fp16: 64 elements, 45 used); element ((cz * 3 + cy) * CX + cx) of block (bx, by, bz) = src at the block's corner
-// (cx, cy, cz), clamped at the upper faces; the rest of the line is zero.  One thread per stored element.
+// (cx, cy, cz), clamped at the upper faces; the rest of the line is zero.
+// A workgroup packs kBrickXB bricks of one (by, bz) row: their nine source rows (3 y x 3 z) come in with coalesced loads
+// through LDS, then every thread assembles 16-byte (fp32) / 8-byte (fp16) pieces of the lines.  (Round 4, first form: one
+// thread per four stored elements reading its four corners straight from memory -- 153 us at 300^3, bound by the
+// address processing of the scattered 4-byte loads.)
+constexpr int kBrickXB = 64;  // (32: 145 us at 300^3 against 126)
 template <typename SrcT, typename DstT>
-__global__ void pack3d_brick_kernel(const SrcT *__restrict__ src, int nx, int ny, int nz, int nbx, int nby, size_t total,
-                                    DstT *__restrict__ dst) {
+__global__ __launch_bounds__(256) void pack3d_brick_kernel(const SrcT *__restrict__ src, int nx, int ny, int nz, int nbx, int nby,
+                                                           DstT *__restrict__ dst) {
   constexpr int SHX = sizeof(DstT) == 4 ? 1 : 2, CX = (1 << SHX) + 1, PER = 128 / (int)sizeof(DstT);
-  // four stored elements a thread: one 16-byte (fp32) or 8-byte (fp16) store (total is a multiple of PER)
-  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= total) return;
-  const size_t blk = i / PER;
-  const int e0 = (int)(i - blk * PER);
-  const int bx = (int)(blk % nbx), by = (int)((blk / nbx) % nby), bz = (int)(blk / ((size_t)nbx * nby));
-  float v[4];
+  constexpr int NCOL = (kBrickXB << SHX) + 1;  // corners along x the workgroup's bricks touch
+  __shared__ float tile[9 * NCOL];
+  const int bx0 = blockIdx.x * kBrickXB, by = blockIdx.y, bz = blockIdx.z;
+  {
+    constexpr int NL = (9 * NCOL + 255) / 256;  // loads a thread, all in flight before the first is stored
+    SrcT w[NL];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int e = e0 + k;
-    v[k] = 0.0f;
-    if (e < 9 * CX) {
-      const int cz = e / (3 * CX), cy = (e / CX) % 3, cx = e % CX;
-      const int x = min((bx << SHX) + cx, nx - 1), y = min(2 * by + cy, ny - 1), z = min(2 * bz + cz, nz - 1);
-      v[k] = (float)src[((size_t)z * ny + y) * nx + x];
+    for (int u = 0; u < NL; ++u) {
+      const int i = min((int)threadIdx.x + u * 256, 9 * NCOL - 1), r = i / NCOL, cxl = i - r * NCOL;
+      const int x = min((bx0 << SHX) + cxl, nx - 1), y = min(2 * by + r % 3, ny - 1), z = min(2 * bz + r / 3, nz - 1);
+      w[u] = src[((size_t)z * ny + y) * nx + x];
+    }
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int i = threadIdx.x + u * 256;
+      if (i < 9 * NCOL) tile[i] = (float)w[u];
     }
   }
-  if constexpr (sizeof(DstT) == 2) {
-    const __half2 lo = __floats2half2_rn(v[0], v[1]), hi = __floats2half2_rn(v[2], v[3]);
-    uint2 u;
-    u.x = *reinterpret_cast<const unsigned int *>(&lo);
-    u.y = *reinterpret_cast<const unsigned int *>(&hi);
-    *reinterpret_cast<uint2 *>(dst + i) = u;
-  } else {
-    *reinterpret_cast<float4 *>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
+  __syncthreads();
+  constexpr int Q = PER / 4;  // four-element pieces a line
+  DstT *line0 = dst + ((size_t)((size_t)bz * nby + by) * nbx + bx0) * PER;
+  for (int i = threadIdx.x; i < kBrickXB * Q; i += 256) {
+    const int bl = i / Q, e0 = (i - bl * Q) * 4;
+    if (bx0 + bl >= nbx) break;  // (bl grows with i)
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = e0 + k, r = e / CX, cx = e - r * CX;  // r = cz * 3 + cy
+      v[k] = e < 9 * CX ? tile[r * NCOL + (bl << SHX) + cx] : 0.0f;
+    }
+    DstT *o = line0 + (size_t)bl * PER + e0;
+    if constexpr (sizeof(DstT) == 2) {
+      const __half2 lo = __floats2half2_rn(v[0], v[1]), hi = __floats2half2_rn(v[2], v[3]);
+      uint2 u;
+      u.x = *reinterpret_cast<const unsigned int *>(&lo);
+      u.y = *reinterpret_cast<const unsigned int *>(&hi);
+      *reinterpret_cast<uint2 *>(o) = u;
+    } else {
+      *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    }
   }
 }
 
@@ -907,6 +1155,8 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
   const size_t nstore = layout == NEO_LAYOUT_YZ4 ? nvox * 4 : (layout == NEO_LAYOUT_CELL8 ? nvox * 8 :
                         (layout == NEO_LAYOUT_BRICK ? (size_t)nbx * nby * nbz * (128 / dsz) : nvox));
   if ((nstore + 64) * dsz >= (size_t)4 << 30) return fail(c, NEO_ERR_INVALID, "field too large for 32-bit buffer offsets in this layout");
+  if (layout == NEO_LAYOUT_BRICK && (nby > 65535 || nbz > 65535))
+    return fail(c, NEO_ERR_INVALID, "field too large for the brick layout: at most 131070 voxels along y and z");
   const void *src = dist;
   DevBuf staged, field;
   if (!src_is_device) {
@@ -934,15 +1184,15 @@ int neo_esdf_upload_3d(neo_ctx *c, int scene_id, const void *dist, int src_dtype
       hipLaunchKernelGGL((KERNEL<float, __half>), grid, blk, 0, c->stream, (const float *)src, nx, ny, nz, (__half *)field.p);   \
   } while (0)
   if (layout == NEO_LAYOUT_BRICK) {
-    const dim3 gb((unsigned)((nstore / 4 + 255) / 256));
+    const dim3 gb((unsigned)((nbx + kBrickXB - 1) / kBrickXB), (unsigned)nby, (unsigned)nbz);
     if (src_dtype == NEO_F64 && store_dtype == NEO_F32)
-      hipLaunchKernelGGL((pack3d_brick_kernel<double, float>), gb, blk, 0, c->stream, (const double *)src, nx, ny, nz, nbx, nby, nstore, (float *)field.p);
+      hipLaunchKernelGGL((pack3d_brick_kernel<double, float>), gb, blk, 0, c->stream, (const double *)src, nx, ny, nz, nbx, nby, (float *)field.p);
     else if (src_dtype == NEO_F64)
-      hipLaunchKernelGGL((pack3d_brick_kernel<double, __half>), gb, blk, 0, c->stream, (const double *)src, nx, ny, nz, nbx, nby, nstore, (__half *)field.p);
+      hipLaunchKernelGGL((pack3d_brick_kernel<double, __half>), gb, blk, 0, c->stream, (const double *)src, nx, ny, nz, nbx, nby, (__half *)field.p);
     else if (store_dtype == NEO_F32)
-      hipLaunchKernelGGL((pack3d_brick_kernel<float, float>), gb, blk, 0, c->stream, (const float *)src, nx, ny, nz, nbx, nby, nstore, (float *)field.p);
+      hipLaunchKernelGGL((pack3d_brick_kernel<float, float>), gb, blk, 0, c->stream, (const float *)src, nx, ny, nz, nbx, nby, (float *)field.p);
     else
-      hipLaunchKernelGGL((pack3d_brick_kernel<float, __half>), gb, blk, 0, c->stream, (const float *)src, nx, ny, nz, nbx, nby, nstore, (__half *)field.p);
+      hipLaunchKernelGGL((pack3d_brick_kernel<float, __half>), gb, blk, 0, c->stream, (const float *)src, nx, ny, nz, nbx, nby, (__half *)field.p);
   } else if (layout == NEO_LAYOUT_CELL8)
     NEO_PACK(pack3d_cell8_kernel);
   else if (layout == NEO_LAYOUT_YZ4)
@@ -990,8 +1240,15 @@ int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_d
     {
       ProfScope ps(c, NEO_KERNEL_ESDF_BUILD);
       const size_t rows = (size_t)ny * nz;
-      hipLaunchKernelGGL(edt3_x_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 4 * (size_t)nx * sizeof(uint16_t),
-                         c->stream, src, nx, rows, d_gx);
+      // (the occupancy's rows must be 4-byte aligned for the wide form: nx a multiple of four and an aligned base)
+      const bool wide = nx % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+      if (wide && nx <= 8 * kWave)
+        hipLaunchKernelGGL(edt3_xv_kernel<8>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, src, nx, rows, d_gx);
+      else if (wide && nx <= 16 * kWave)
+        hipLaunchKernelGGL(edt3_xv_kernel<16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, src, nx, rows, d_gx);
+      else
+        hipLaunchKernelGGL(edt3_x_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 4 * (size_t)nx * sizeof(uint16_t),
+                           c->stream, src, nx, rows, d_gx);
       // tiles of at most 64 KB of LDS INCLUDING the kernel's 2 KB of static part_best / part_arg (4 bytes a voxel in the y
       // pass, 6 in the z pass): TX x-columns by the whole line
       constexpr size_t kEdtTile = 65536 - 2 * kEdtThreads * sizeof(int);
@@ -1009,9 +1266,42 @@ int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_d
   else if ((size_t)(nline) * 16 * 6 <= kEdtTile) NEO_EDT_LINE(SRC, 16, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd); \
   else if ((size_t)(nline) * 8 * 6 <= kEdtTile) NEO_EDT_LINE(SRC, 8, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd);   \
   else NEO_EDT_LINE(SRC, 2, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd)
+      // packed-key form of the same passes where (squared diagonal + 2 nline^2) << bits(nline) fits 31 bits
+#define NEO_EDT_KEYS(SRC, TXV, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb)                                  \
+  hipLaunchKernelGGL((edt3_line_keys_kernel<SRC, TXV, FINAL>),                                                          \
+                     dim3((unsigned)(((nx + TXV - 1) / TXV) * (((nslab) + 7) / 8) * 8)), dim3(kEdtThreads),                \
+                     (size_t)(nline) * TXV * 6, c->stream, srcp, nx, nline, sline, sslab, (int)(nslab), res, big, qb, outsq, outd)
+#define NEO_EDT_KEYS_PASS(SRC, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb)                                    \
+  if ((size_t)(nline) * 16 * 6 <= 40960) NEO_EDT_KEYS(SRC, 16, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb);     \
+  else if ((size_t)(nline) * 32 * 6 <= kEdtTile) NEO_EDT_KEYS(SRC, 32, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb); \
+  else if ((size_t)(nline) * 16 * 6 <= kEdtTile) NEO_EDT_KEYS(SRC, 16, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb); \
+  else if ((size_t)(nline) * 8 * 6 <= kEdtTile) NEO_EDT_KEYS(SRC, 8, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb);   \
+  else NEO_EDT_KEYS(SRC, 2, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb)
+      const long long diag2 = (long long)nx * nx + (long long)ny * ny + (long long)nz * nz + 1;
+      const int big = (int)std::min<long long>(diag2, 1 << 30);
+      auto key_bits = [&](int nline) {  // bits of the minimiser field, or 0 when the keys do not fit
+        int qb = 1;
+        while ((1 << qb) < nline) ++qb;
+        const long long span = (diag2 + 2LL * nline * nline) << qb;
+        return (span < (1LL << 31) && ((long long)nline << (qb + 1)) < (1LL << 23)) ? qb : 0;
+      };
+      // (NEO_EDT_GENERIC=1 in the environment: the general form for every volume -- the tests run both)
+      const char *force_generic = getenv("NEO_EDT_GENERIC");
+      const bool generic = force_generic && force_generic[0] == '1';
+      const int qby = generic ? 0 : key_bits(ny), qbz = generic ? 0 : key_bits(nz);
       // pass Y: lines along y (stride nx) in every z slab; pass Z: lines along z (stride nx * ny) for every y row
-      NEO_EDT_PASS(uint16_t, false, d_gx, ny, (size_t)nx, plane, nz, d_sq, (float *)nullptr);
-      NEO_EDT_PASS(uint32_t, true, d_sq, nz, plane, (size_t)nx, ny, (uint32_t *)nullptr, d_dist_p);
+      if (qby) {
+        NEO_EDT_KEYS_PASS(uint16_t, false, d_gx, ny, (size_t)nx, plane, nz, d_sq, (float *)nullptr, qby);
+      } else {
+        NEO_EDT_PASS(uint16_t, false, d_gx, ny, (size_t)nx, plane, nz, d_sq, (float *)nullptr);
+      }
+      if (qbz) {
+        NEO_EDT_KEYS_PASS(uint32_t, true, d_sq, nz, plane, (size_t)nx, ny, (uint32_t *)nullptr, d_dist_p, qbz);
+      } else {
+        NEO_EDT_PASS(uint32_t, true, d_sq, nz, plane, (size_t)nx, ny, (uint32_t *)nullptr, d_dist_p);
+      }
+#undef NEO_EDT_KEYS_PASS
+#undef NEO_EDT_KEYS
 #undef NEO_EDT_PASS
 #undef NEO_EDT_LINE
     }

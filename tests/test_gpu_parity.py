@@ -94,6 +94,25 @@ def test_esdf_build_3d_is_the_exact_edt(shape, seed):
         assert np.max(np.abs(dis - np.array([o3.lookup(p)[0] for p in pts]))) < 1e-12
 
 
+def test_esdf_build_3d_packed_key_and_general_line_passes_agree(monkeypatch):
+    """round 4: the y / z passes run on packed (cost, minimiser) keys where the volume's squared diagonal leaves room in 31
+    bits, and in the general form elsewhere (NEO_EDT_GENERIC=1 forces it); the x pass has a form with 8 / 16 voxels per
+    lane for rows of 4-byte aligned length.  Every form against SciPy, on the shapes that take the fast forms by default."""
+    from scipy import ndimage
+    rng = np.random.default_rng(21)
+    for shape, dens in (((48, 48, 48), 0.01), ((33, 300, 64), 0.002), ((300, 20, 40), 0.002), ((9, 40, 600), 0.001),
+                        ((12, 40, 1028), 0.001), ((21, 33, 47), 0.02)):
+        occ = (rng.random(shape) < dens).astype(np.uint8)
+        occ[0] = 1
+        occ[:, shape[1] // 2:, :] &= (rng.random((shape[0], shape[1] - shape[1] // 2, shape[2])) < 0.5)  # rows with nothing occupied
+        want = (ndimage.distance_transform_edt(1 - occ) * 0.1).astype(np.float32)
+        for generic in ("0", "1"):
+            monkeypatch.setenv("NEO_EDT_GENERIC", generic)
+            g3 = npa.ESDF3D.from_occupancy(occ, 0.1, (0.0, 0.0, 0.0), layout="linear", want_dist=True)
+            assert np.array_equal(g3.dist, want), (shape, generic)
+    monkeypatch.delenv("NEO_EDT_GENERIC")
+
+
 def test_esdf_build_3d_line_lengths_around_powers_of_two():
     """the y / z passes solve a line by monotone minima over spacings 2^k: line lengths 2 .. 34 on both axes, with and
     without occupied voxels in a line, dense and sparse"""

@@ -17,7 +17,7 @@ for n in (int(a) for a in (sys.argv[1:] or ["300"])):
     ts = []
     for _ in range(4):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        g3 = npa.ESDF3D.from_occupancy(d_occ, res, synth.DOMAIN_ORIGIN, layout="yz4", ctx=ctx)
+        g3 = npa.ESDF3D.from_occupancy(d_occ, res, synth.DOMAIN_ORIGIN, layout=os.environ.get("NEO_LAYOUT", "brick"), ctx=ctx)
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     print(f"{n}^3: from_occupancy (EDT + pack, device to device) {1e3 * min(ts):.2f} ms wall (first call {1e3 * ts[0]:.1f})")
     if n <= 160:
