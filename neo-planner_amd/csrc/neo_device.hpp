@@ -154,6 +154,17 @@ __device__ __forceinline__ int opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+// the same for a wave-uniform value (it stays in a scalar register)
+__device__ __forceinline__ int opaque_uniform(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+// lane predicates compared WHERE THEY ARE USED: the bound goes through an opaque scalar copy, so the compare cannot be
+// hoisted out of the optimiser loop -- where it would be a scalar register pair that lives across the whole loop, is
+// spilled to a lane of a vector register and costs two v_readlane at every use instead of one v_cmp (DevBackend::eval)
+__device__ __forceinline__ bool lane_lt(int bound) { return (int)__lane_id() < opaque_uniform(bound); }
+__device__ __forceinline__ bool lane_ge(int bound) { return (int)__lane_id() >= opaque_uniform(bound); }
+__device__ __forceinline__ bool lane_eq(int which) { return (int)__lane_id() == opaque_uniform(which); }
 __device__ __forceinline__ float uniform(float v) {
   return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
 }
@@ -304,19 +315,19 @@ __device__ __forceinline__ int wave_max_nonneg(int v) {
 // value of lane (l-1) / (l+1); lanes without such a neighbour get `fill`
 __device__ __forceinline__ double from_prev(double v, double fill) {
   const double o = dpp_d<0x138>(v);  // wave_shr:1
-  return lane_id() == 0 ? fill : o;
+  return lane_eq(0) ? fill : o;
 }
 __device__ __forceinline__ double from_next(double v, double fill) {
   const double o = dpp_d<0x130>(v);  // wave_shl:1
-  return lane_id() == kWave - 1 ? fill : o;
+  return lane_eq(kWave - 1) ? fill : o;
 }
 __device__ __forceinline__ float from_prev(float v, float fill) {
   const float o = dpp_f<0x138>(v);
-  return lane_id() == 0 ? fill : o;
+  return lane_eq(0) ? fill : o;
 }
 __device__ __forceinline__ float from_next(float v, float fill) {
   const float o = dpp_f<0x130>(v);
-  return lane_id() == kWave - 1 ? fill : o;
+  return lane_eq(kWave - 1) ? fill : o;
 }
 
 // ------------------------------------------------------------------ map lookups
@@ -778,6 +789,8 @@ struct WaveLanesPD {
   static __device__ __forceinline__ int lane() { return lane_id(); }
   static __device__ __forceinline__ int base() { return 0; }
   static __device__ __forceinline__ int piece() { return (lane_id() * ((65536 + S - 1) / S)) >> 16; }  // lane / S
+  // (round 4: an opaque piece number -- every mask compared at its use -- removes 19 more of the 45 remaining scalar
+  //  reloads an evaluation and adds 65 vector instructions: 1.457 against 1.455 M traj/s, not kept)
   static __device__ __forceinline__ int dim0() { return lane_id() - S * piece(); }
   // value held by piece q (any of its lanes: used for quantities that depend on the durations only)
   static __device__ __forceinline__ double read(double v, int q /*wave-uniform*/) { return rdlane(v, S * q); }
@@ -785,12 +798,12 @@ struct WaveLanesPD {
   static __device__ __forceinline__ double prev(double v, double fill) {
 #pragma unroll
     for (int k = 0; k < S; ++k) v = dpp_d<0x138>(v);  // wave_shr:1
-    return lane_id() < S ? fill : v;
+    return lane_lt(S) ? fill : v;
   }
   static __device__ __forceinline__ double next(double v, double fill) {
 #pragma unroll
     for (int k = 0; k < S; ++k) v = dpp_d<0x130>(v);  // wave_shl:1
-    return lane_id() >= kWave - S ? fill : v;
+    return lane_ge(kWave - S) ? fill : v;
   }
   static __device__ __forceinline__ double sum(double v) { return wave_sum(v); }
   static __device__ __forceinline__ int sum(int v) { return wave_sum(v); }
@@ -801,12 +814,12 @@ struct WaveLanesPD {
   static __device__ __forceinline__ float prev(float v, float fill) {
 #pragma unroll
     for (int k = 0; k < S; ++k) v = dpp_f<0x138>(v);
-    return lane_id() < S ? fill : v;
+    return lane_lt(S) ? fill : v;
   }
   static __device__ __forceinline__ float next(float v, float fill) {
 #pragma unroll
     for (int k = 0; k < S; ++k) v = dpp_f<0x130>(v);
-    return lane_id() >= kWave - S ? fill : v;
+    return lane_ge(kWave - S) ? fill : v;
   }
   static __device__ __forceinline__ float sum(float v) { return wave_sum(v); }
   static __device__ __forceinline__ float sum_dims(float v) {
@@ -1061,7 +1074,7 @@ __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2]
   // sixth level (M > 33: cfg5) would eliminate is five orders below the rounding of the fp32 solve.
   const int s_end = sizeof(Num) == 4 ? min(M - 1, 32) : M - 1;
   typedef Num Quad __attribute__((ext_vector_type(4)));
-  const bool writer = mult != nullptr && in && LG::dim0() == 0;  // one lane per joint writes
+  const bool writer = mult != nullptr && in && LG::dim0() == opaque_uniform(0);  // one lane per joint writes
   int level = 0;
   if constexpr (sizeof(Num) == 4) {
     // fp32: the 2 x 2 blocks as ROWS in register pairs, their products as packed operations (v_pk_mul_f32 / v_pk_fma_f32
@@ -1458,7 +1471,7 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
          Num(720.0) * T4 * c4 * c5 + Num(720.0) * T5 * c5 * c5;
   }
   energy = LG::sum(act ? e : Num(0.0));
-  time_sum = LG::sum((act && LG::dim0() == 0) ? t.T : Num(0.0));  // add_time_cost (:386-387): once per piece
+  time_sum = LG::sum((act && LG::dim0() == opaque_uniform(0)) ? t.T : Num(0.0));  // add_time_cost (:386-387): once per piece
   return 0;
 }
 
@@ -2014,7 +2027,7 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
   }
   gT = fv[6 * D];
   const Real pf = fv[6 * D + 1], pk = fv[6 * D + 2];
-  const bool mine = SAMPLE_IO ? (act && r == 0) : (LG::piece() < M && LG::dim0() == 0);  // every piece once
+  const bool mine = SAMPLE_IO ? (act && r == 0) : (LG::piece() < M && LG::dim0() == opaque_uniform(0));  // every piece once
   cost_feas = LG::sum(mine ? (double)pf : 0.0);
   cost_coll = LG::sum(mine ? (double)pk : 0.0);
 }
@@ -2038,7 +2051,7 @@ __device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D), Num> &t, 
   Num jerk_end[DL], snap_end[DL], crackle[DL];
   // add_energy_grad_CT (:361-384), add_time_grad_CT (:389-390)
   // (gT: the sampled partial and the time weight enter once per piece -- in the lane of its first dimension)
-  gT = (LG::dim0() == 0) ? gT + par_w1<Num>(prm) : Num(0.0);
+  gT = (LG::dim0() == opaque_uniform(0)) ? gT + par_w1<Num>(prm) : Num(0.0);
 #pragma unroll
   for (int d = 0; d < DL; ++d) {
     const Num c3 = t.c[3][d], c4 = t.c[4][d], c5 = t.c[5][d];

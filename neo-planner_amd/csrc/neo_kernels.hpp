@@ -208,14 +208,17 @@ struct DevBackend {
   // iteration) and, when asked for, the evaluated point and its gradient (replay tests: every evaluation of a run is laid
   // beside the CPU oracle's at the same point)
   __device__ __forceinline__ void note_eval(int nfev, int iter, double stp, double f, const Vec &x, const Vec &g) {
-    if (trace != nullptr && nfev <= trace_cap && lane_id() == 0) {
+    // (trace_cap is 0 when neither buffer was given: ONE scalar test in the product path -- the two pointers tested
+    //  here were four spilled scalar registers re-read at every evaluation)
+    if (nfev > trace_cap) return;
+    if (trace != nullptr && lane_id() == 0) {
       double *r = trace + (size_t)(nfev - 1) * 4;
       r[0] = f;
       r[1] = stp;
       r[2] = (double)last_ns;
       r[3] = (double)iter;
     }
-    if (trace_xg != nullptr && nfev <= trace_cap) {
+    if (trace_xg != nullptr) {
       const int lane = lane_id();
       double *r = trace_xg + (size_t)(nfev - 1) * 2 * t.n;
 #pragma unroll
@@ -258,6 +261,12 @@ struct DevBackend {
     const long long s0 = wall_clock64();
 #endif
     NEO_MARK("eval_begin");
+    // Lane masks such as `piece < M` are loop invariant: hoisted out of the optimiser loop they are scalar register PAIRS
+    // that live across everything, the allocator spills them to lanes of a vector register, and every use inside the
+    // loop pays two v_readlane on the vector pipe (round 4: ~120 of them an evaluation).  The piece count is re-read
+    // through an opaque copy at the head of every phase, so the masks are compared where they are used (one v_cmp).
+    const int M_all = t.M;
+    t.M = opaque_uniform(M_all);
     scatter_x(x);
     NEO_MARK("scatter_done");
     Num *xn = reinterpret_cast<Num *>(xs);
@@ -303,6 +312,7 @@ struct DevBackend {
       int ns_by_piece = t.ns;
       if constexpr (LG::S > 1) ns_by_piece = __shfl(t.ns, min(LG::S * lane, kWave - 1), kWave);
       NEO_MARK("assign_begin");
+      t.M = opaque_uniform(M_all);
       const SampleLanes sl = balanced_sample_lanes(t.M, ns_by_piece, reinterpret_cast<int *>(xs));
       last_ns = sl.total;  // (the lane assignment has summed the sample counts already)
       samples += (long long)last_ns;
@@ -325,6 +335,7 @@ struct DevBackend {
     f = uniform(costs[0] * prm.w[0] + costs[1] * prm.w[1] + costs[2] * prm.w[2] + costs[3] * prm.w[3]);
     Num gq[DL], gtau;
     NEO_MARK("sample_done");
+    t.M = opaque_uniform(M_all);
     const int bst = minco_backward<D, LG, Num, kPcr>(t, prm, gC, gT, gq, gtau);
     NEO_MARK("backward_done");
     if (bst != 0) return bst;
@@ -335,7 +346,7 @@ struct DevBackend {
 #pragma unroll
       for (int d = 0; d < DL; ++d) xn[(LG::dim0() + d) * (t.M - 1) + pg - 1] = gq[d];
     }
-    if (pg < t.M && LG::dim0() == 0) xn[t.nq + pg] = gtau;
+    if (pg < t.M && LG::dim0() == opaque_uniform(0)) xn[t.nq + pg] = gtau;
     lds_wave_sync();
 #pragma unroll
     for (int k = 0; k < NS; ++k) g.v[k] = in_range(k, lg) ? xn[k * kWave + lg] : Num(0);
@@ -485,7 +496,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   be.m = NEO_LBFGS_M;
   be.coeff_out = nullptr;
   be.trace = trace ? trace + (size_t)b * trace_cap * 4 : nullptr;
-  be.trace_cap = trace_cap;
+  be.trace_cap = (trace != nullptr || trace_xg != nullptr) ? trace_cap : 0;
   be.trace_xg = trace_xg ? trace_xg + (size_t)b * trace_cap * 2 * (D * (M - 1) + M) : nullptr;
   load_boundary<LG>(be.t, head + (size_t)b * 3 * D, tail + (size_t)b * 3 * D, M, bnd);
   const int n = be.t.n;

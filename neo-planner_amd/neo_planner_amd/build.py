@@ -54,8 +54,10 @@ def _newest_header():
 # such instructions back into the loop leaves 7 and is worth 13 % (549 k -> 620 k traj/s; the all-fp32 kernels do not
 # care: 1.26 M either way).
 _SINK = ["-mllvm", "-sink-insts-to-avoid-spills"]
-UNIT_FLAGS = {"neo_disp_opt3d_x.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
-              "neo_disp_opt2d_x.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
+_ASWRITTEN = ["-ffp-contract=" + os.environ.get("NEO_FP_CONTRACT", "on")]
+UNIT_FLAGS = {"neo_disp_opt3d_x.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"] + _ASWRITTEN,
+              "neo_disp_opt2d_x.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"] + _ASWRITTEN,
+              "neo_disp_eval.hip": _ASWRITTEN,
               # (the fp64 unit also without machine LICM: no spills at all in its two-waves kernels, 618 k -> 640 k; the
               #  same pair costs the mixed mode 6 % and the all-fp32 mode 2 %, so only there)
               "neo_disp_opt3d_f64.hip": _SINK + ["-mllvm", "-disable-machine-licm"],

@@ -53,7 +53,10 @@ def _compare(gpu, cpu, idx, nq, ctrl, same_path_is_same_point=True):
     if same.any() and same_path_is_same_point:
         # same evaluation count = same path, up to the drift the control shows for such runs (fp64 evaluations only:
         # with fp32-level differences two runs can share a count and still end in different minima)
-        assert (dx[same] <= 1e-4).mean() >= 0.85 and dx[same].max() < 1e-2, dx[same].max()
+        # (the share only where there are enough such runs to speak of one: at M = 41 a batch of 64 may hold a single one)
+        assert dx[same].max() < 1e-2, dx[same].max()
+        if same.sum() >= 8:
+            assert (dx[same] <= 1e-4).mean() >= 0.85, (dx[same] <= 1e-4).mean()
     # the runs that part end in other local minima of the same landscape: medians agree as well as the control's do
     cm = (ctrl["costs_last"] * W4).sum(axis=1)
     assert abs(np.median(gc) - np.median(cc)) <= max(0.15 * abs(np.median(cc)), 2.0 * abs(np.median(cm) - np.median(cc)))
