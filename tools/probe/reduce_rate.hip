@@ -7,6 +7,7 @@
 //      (row_ror 8,4,2,1): total in every lane, no v_readlane
 //   2  four DPP adds (row_ror) + v_permlane16_swap + add + v_permlane32_swap + add: total in every lane
 //   3  four DPP adds (row_ror) + the MFMA last (rows summed by the matrix pipe)
+//   4  variant 0 written in assembly: the row broadcasts as one v_add_f32_dpp under a row mask each (7 instructions, not 9)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -58,7 +59,7 @@ __device__ __forceinline__ float reduce(float v) {
       s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
     return s;
-  } else {
+  } else if constexpr (KIND == 3) {
     float s = v;
     s += dppf_ror<0x128>(s);
     s += dppf_ror<0x124>(s);
@@ -67,6 +68,17 @@ __device__ __forceinline__ float reduce(float v) {
     const f4 z = {0.f, 0.f, 0.f, 0.f};
     const f4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, s, z, 0, 0, 0);
     return d[0];
+  } else {
+    // variant 0 with the two row broadcasts as ONE v_add_f32_dpp each (rows the mask leaves out keep their value): the
+    // builtin cannot express "add under a row mask", the compiler emits v_mov_b32_dpp + v_add_f32
+    asm("v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
   }
 }
 
@@ -101,6 +113,7 @@ __global__ void check(float *out) {
   out[64 + threadIdx.x] = reduce<1>(v);
   out[128 + threadIdx.x] = reduce<2>(v);
   out[192 + threadIdx.x] = reduce<3>(v);
+  out[256 + threadIdx.x] = reduce<4>(v);
 }
 
 template <int KIND, bool CHAIN, int FILL>
@@ -136,10 +149,10 @@ void all(const char *name) {
 int main() {
   // correctness of the variants first: sum of the lane numbers = 2016 in the lanes that hold the result
   {
-    float *out; hipMalloc(&out, 4 * 64 * sizeof(float));
+    float *out; hipMalloc(&out, 5 * 64 * sizeof(float));
     check<<<1, 64>>>(out);
-    float h[4 * 64]; hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
-    for (int kd = 0; kd < 4; ++kd) printf("variant %d: lane 0 %.1f  lane 17 %.1f  lane 63 %.1f (2016)\n", kd, h[kd * 64], h[kd * 64 + 17], h[kd * 64 + 63]);
+    float h[5 * 64]; hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+    for (int kd = 0; kd < 5; ++kd) printf("variant %d: lane 0 %.1f  lane 17 %.1f  lane 63 %.1f (2016)\n", kd, h[kd * 64], h[kd * 64 + 17], h[kd * 64 + 63]);
     hipFree(out);
   }
   run<0, false, 16>("fill only reference: see fill 0 rows");
@@ -147,5 +160,6 @@ int main() {
   all<1>("mfma+dpp4");
   all<2>("dpp4+swap16+swap32");
   all<3>("dpp4+mfma");
+  all<4>("dpp6 (asm, fused bcast)+readlane");
   return 0;
 }
