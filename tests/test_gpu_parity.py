@@ -101,7 +101,9 @@ def test_esdf_build_3d_packed_key_and_general_line_passes_agree(monkeypatch):
     from scipy import ndimage
     rng = np.random.default_rng(21)
     for shape, dens in (((48, 48, 48), 0.01), ((33, 300, 64), 0.002), ((300, 20, 40), 0.002), ((9, 40, 600), 0.001),
-                        ((12, 40, 1028), 0.001), ((21, 33, 47), 0.02)):
+                        ((12, 40, 1028), 0.001), ((21, 33, 47), 0.02),
+                        # x rows at the edges of the 8 / 16 voxels-a-lane forms: one load a lane, all 64 lanes, one past
+                        ((5, 6, 4), 0.05), ((6, 9, 512), 0.002), ((6, 9, 516), 0.002), ((5, 7, 1024), 0.001)):
         occ = (rng.random(shape) < dens).astype(np.uint8)
         occ[0] = 1
         occ[:, shape[1] // 2:, :] &= (rng.random((shape[0], shape[1] - shape[1] // 2, shape[2])) < 0.5)  # rows with nothing occupied
