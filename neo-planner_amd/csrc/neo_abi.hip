@@ -350,8 +350,9 @@ __global__ __launch_bounds__(kEdtThreads) void edt3_line_kernel(const SrcT *__re
 
 // The same monotone-minima line pass on PACKED KEYS (round 4), for volumes whose squared diagonal leaves room in 31 bits
 // (every scene of BASELINE.json: 300^3 needs 28 bits, 600^3 31).  With h(q) = f(q) + q^2 the cost of candidate q at point
-// p is f(q) + (p - q)^2 = h(q) - 2 p q + p^2; the tile holds hk(q) = (h(q) << qb) | q, and
-//     key(p, q) = hk(q) - q * (p << (qb + 1))        [= ((cost - p^2) << qb) | q]
+// p is f(q) + (p - q)^2 = h(q) - 2 p q + p^2; the tile holds h(q) << qb (the low qb bits are the slot of the minimiser
+// found for POINT q, masked off when q is read as a candidate), and
+//     key(p, q) = (h(q) << qb) + q * (1 - (p << (qb + 1)))        [= ((cost - p^2) << qb) | q]
 // orders the candidates of one point by (cost, q): the leftmost minimiser is ONE v_mad_i32_i24 and half a v_min3_i32 per
 // candidate instead of square / add / compare / two selects (the line passes are bound by vector issue: 4.0 k vector
 // instructions a wavefront, 72 % of the SIMDs' cycles, `tools/probe/pmc_edt.sh`).  Unreachable voxels enter as
@@ -365,8 +366,15 @@ __global__ __launch_bounds__(kEdtThreads) void edt3_line_keys_kernel(const SrcT 
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
   static_assert((TX & (TX - 1)) == 0, "TX is a power of two");
   constexpr int LX = TX == 32 ? 5 : (TX == 16 ? 4 : (TX == 8 ? 3 : (TX == 4 ? 2 : 1)));
-  int *hk = reinterpret_cast<int *>(tile_raw);                                                    // [nline][TX] keys
-  uint16_t *am = reinterpret_cast<uint16_t *>(tile_raw + (size_t)nline * TX * sizeof(int));       // [nline][TX] minimisers
+  int *hk = reinterpret_cast<int *>(tile_raw);  // [nline][TX] keys (and, in their low bits, the minimisers found)
+  // the minimiser found for point p lives in the low qb bits of hk[p] (they hold p itself until then, and a candidate's
+  // position is added back from its index): 4 bytes a voxel -- 8 workgroups a CU at 300 voxels a line, 4 at 600 (with a
+  // separate 2-byte array: 5 and 2; 600^3 5.1 -> 4.0 ms the build).  A candidate's key is masked when it is read.
+  const int himask = ~((1 << qb) - 1);
+  auto am_get = [&](int i) { return hk[i] & ~himask; };
+  auto am_put = [&](int i, int arg) { hk[i] = (hk[i] & himask) | arg; };
+#define NEO_EDT_K(x) ((x) & himask)
+#define NEO_EDT_NEGP(p) (1 - ((p) << (qb + 1)))  // per unit of q: -(p << (qb + 1)) for the cost, + 1 for q in the low bits
   // 1-D grid, XCD-aware: workgroup b runs on XCD b mod 8; the tiles of one slab share their rows' 128-byte lines (a row
   // of a 16-column tile is 32 or 64 bytes), so a slab's tiles go to ONE XCD, one after the other, and meet in its L2
   const int ntx = (nx + TX - 1) / TX;
@@ -436,12 +444,12 @@ __global__ __launch_bounds__(kEdtThreads) void edt3_line_keys_kernel(const SrcT 
     int t = __mul24(q, negP);
 #pragma clang loop unroll(disable)
     for (; q + 3 <= b; q += 4, h += 4 * TX, t += 4 * negP) {
-      const int k0 = h[0], k1 = h[TX], k2 = h[2 * TX], k3 = h[3 * TX];
+      const int k0 = NEO_EDT_K(h[0]), k1 = NEO_EDT_K(h[TX]), k2 = NEO_EDT_K(h[2 * TX]), k3 = NEO_EDT_K(h[3 * TX]);
       best = min(min(best, k0 + t), k1 + t + negP);
       best = min(min(best, k2 + t + 2 * negP), k3 + t + 3 * negP);
     }
 #pragma clang loop unroll(disable)
-    for (; q <= b; ++q, h += TX, t += negP) best = min(best, h[0] + t);
+    for (; q <= b; ++q, h += TX, t += negP) best = min(best, NEO_EDT_K(h[0]) + t);
   };
   __shared__ int part_key[kEdtThreads];
   const int my_xl = threadIdx.x & (TX - 1), my_k = threadIdx.x >> LX;
@@ -456,31 +464,31 @@ __global__ __launch_bounds__(kEdtThreads) void edt3_line_keys_kernel(const SrcT 
       if (mine) {
         g = my_k & (G - 1);
         p = min(p0 + (int)(threadIdx.x >> (LX + lg)) * dp, nline - 1);
-        const int lo = S ? am[(p - S) * TX + xl] : 0, hi = S ? am[min(p + S, nline - 1) * TX + xl] : nline - 1;
+        const int lo = S ? am_get((p - S) * TX + xl) : 0, hi = S ? am_get(min(p + S, nline - 1) * TX + xl) : nline - 1;
         const int chunk = (hi - lo + G) >> lg, a = lo + g * chunk, b = min(hi, a + chunk - 1);
         int best = 0x7fffffff;
-        scan(-(p << (qb + 1)), xl, a, b, best);
+        scan(NEO_EDT_NEGP(p), xl, a, b, best);
         part_key[threadIdx.x] = best;
       }
       __syncthreads();
       if (mine && g == 0) {
         int best = part_key[threadIdx.x];
         for (int j = 1; j < G; ++j) best = min(best, part_key[threadIdx.x + j * TX]);
-        am[p * TX + xl] = (uint16_t)(best & qmask);
+        am_put(p * TX + xl, best & qmask);
       }
     } else {
       // (every point of these levels has both neighbours: p = S + 2 S k < nline - 1)
       const int xl = my_xl;
       for (int k = my_k; k < npts; k += kEdtThreads / TX) {
         const int p = p0 + k * dp;
-        const int lo = am[(p - S) * TX + xl], hi = am[min(p + S, nline - 1) * TX + xl];
+        const int lo = am_get((p - S) * TX + xl), hi = am_get(min(p + S, nline - 1) * TX + xl);
         int arg = lo;
         if (lo != hi) {  // (neighbours with the same minimiser: it is this point's too)
           int best = 0x7fffffff;
-          scan(-(p << (qb + 1)), xl, lo, hi, best);
+          scan(NEO_EDT_NEGP(p), xl, lo, hi, best);
           arg = best & qmask;
         }
-        am[p * TX + xl] = (uint16_t)arg;
+        am_put(p * TX + xl, arg);
       }
     }
     __syncthreads();
@@ -490,8 +498,8 @@ __global__ __launch_bounds__(kEdtThreads) void edt3_line_keys_kernel(const SrcT 
   while (top < nline - 1) top <<= 1;
   for (int S = top >> 1; S >= 1; S >>= 1) level((nline - 1 - S + 2 * S - 1) / (2 * S), S, 2 * S, S);
   auto result = [&](int p, int xl) {  // squared distance of voxel p of column xl (>= big: nothing occupied in reach)
-    const int q = am[p * TX + xl];
-    const int key = hk[q * TX + xl] - q * (p << (qb + 1));
+    const int q = am_get(p * TX + xl);
+    const int key = NEO_EDT_K(hk[q * TX + xl]) + q * NEO_EDT_NEGP(p);
     return (key >> qb) + p * p;  // (arithmetic shift: the key is ((cost - p^2) << qb) | q)
   };
   auto emit = [&](int c) {
@@ -522,6 +530,9 @@ __global__ __launch_bounds__(kEdtThreads) void edt3_line_keys_kernel(const SrcT 
     }
   }
 }
+
+#undef NEO_EDT_K
+#undef NEO_EDT_NEGP
 
 // numpy.gradient, unit spacing: central differences inside, one-sided at the borders
 __global__ void gradient_pack_kernel(const double *__restrict__ dist, int W, int H, double4 *__restrict__ rec,
@@ -1270,12 +1281,13 @@ int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_d
 #define NEO_EDT_KEYS(SRC, TXV, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb)                                  \
   hipLaunchKernelGGL((edt3_line_keys_kernel<SRC, TXV, FINAL>),                                                          \
                      dim3((unsigned)(((nx + TXV - 1) / TXV) * (((nslab) + 7) / 8) * 8)), dim3(kEdtThreads),                \
-                     (size_t)(nline) * TXV * 6, c->stream, srcp, nx, nline, sline, sslab, (int)(nslab), res, big, qb, outsq, outd)
+                     (size_t)(nline) * TXV * NEO_EDT_KEY_BYTES, c->stream, srcp, nx, nline, sline, sslab, (int)(nslab), res, big, qb, outsq, outd)
+#define NEO_EDT_KEY_BYTES 4
 #define NEO_EDT_KEYS_PASS(SRC, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb)                                    \
-  if ((size_t)(nline) * 16 * 6 <= 40960) NEO_EDT_KEYS(SRC, 16, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb);     \
-  else if ((size_t)(nline) * 32 * 6 <= kEdtTile) NEO_EDT_KEYS(SRC, 32, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb); \
-  else if ((size_t)(nline) * 16 * 6 <= kEdtTile) NEO_EDT_KEYS(SRC, 16, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb); \
-  else if ((size_t)(nline) * 8 * 6 <= kEdtTile) NEO_EDT_KEYS(SRC, 8, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb);   \
+  if ((size_t)(nline) * 16 * NEO_EDT_KEY_BYTES <= 40960) NEO_EDT_KEYS(SRC, 16, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb);     \
+  else if ((size_t)(nline) * 32 * NEO_EDT_KEY_BYTES <= kEdtTile) NEO_EDT_KEYS(SRC, 32, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb); \
+  else if ((size_t)(nline) * 16 * NEO_EDT_KEY_BYTES <= kEdtTile) NEO_EDT_KEYS(SRC, 16, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb); \
+  else if ((size_t)(nline) * 8 * NEO_EDT_KEY_BYTES <= kEdtTile) NEO_EDT_KEYS(SRC, 8, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb);   \
   else NEO_EDT_KEYS(SRC, 2, FINAL, srcp, nline, sline, sslab, nslab, outsq, outd, qb)
       const long long diag2 = (long long)nx * nx + (long long)ny * ny + (long long)nz * nz + 1;
       const int big = (int)std::min<long long>(diag2, 1 << 30);
