@@ -8,39 +8,32 @@ bench.py -- trajectories/sec of the batched replan inner loop on MI355X (BASELIN
 `--gpus N` without a torch.distributed environment launches the N ranks itself (one child process per GPU,
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set for each, rendezvous on 127.0.0.1) before anything touches a GPU.
 
+This file holds the driver contract only: the workload, the timed region, the roofline figure of the dominant kernel
+from HIP events, the CPU baseline, and ONE COMPACT JSON line (< 4 KB; `compact_line`, size-tested on the CPU).
+Everything else a one-GPU run reports -- the other arithmetic modes' parity tables, the retry chain, the stand-alone
+ESDF-lookup kernel's layouts / orders, cfg1, the reference-fixture replays, the CPU-vs-CPU controls -- is produced by
+tools/bench_report.py and written to the side file the line names (`"details"`), never to stdout.
+
 Workload (config.workload): BASELINE.json configs[1] -- per GPU one 300^3-voxel fp32 ESDF of a synthetic
 random-forest scene (pillars + floating canopy boxes) resident in HBM in the corner-brick layout
-(NEO_LAYOUT_BRICK: one 128-byte line per block of 2 x 2 x 2 trilinear cells holding its 27 corners, 432 MB), and request batches of
-B = 4096 replans with 20 intermediate waypoints (M = 21 pieces, D = 3, n = 81 variables) whose starts, goals and
-waypoints fill the volume (synth.VOLUME: heights 1..25 m, climbing and descending paths).  One launch optimises one
-batch of 4096 from its initial guess to L-BFGS-B termination (neo_optimize_batch_dev), inputs already in HBM.
-One STEP = one pass of the hot path over `--batches-per-step` (default 40) different request batches of the scene,
-i.e. 40 launches of 4096 trajectories: the timed region then lasts > 3 s at the driver's `--steps 20`.  Launches are issued round-robin on `--streams` (default 4) HIP streams with separate state and result
-buffers: the end of a launch is a handful of long runs on an otherwise idle chip, and the next batches fill it
-(`--streams 1 --batches-per-step 1` gives the one-batch-at-a-time latency figure).
-With N > 1 every rank owns its own scene and batches (weak scaling, no data-path collective); the per-rank results
-of every batch are gathered with one RCCL all_gather inside the timed region.
+(NEO_LAYOUT_BRICK: one 128-byte line per block of 2 x 2 x 2 trilinear cells holding its 27 corners, 432 MB), and request
+batches of B = 4096 replans with 20 intermediate waypoints (M = 21 pieces, D = 3, n = 81 variables) whose starts, goals
+and waypoints fill the volume (synth.VOLUME).  One launch optimises one batch of 4096 from its initial guess to L-BFGS-B
+termination (neo_optimize_batch_dev), inputs already in HBM.  One STEP = one pass of the hot path over
+`--batches-per-step` (default 40) different request batches of the scene; launches are issued round-robin on `--streams`
+(default 4) HIP streams with separate state and result buffers (`single_batch_*` is one launch alone on the chip).
+With N > 1 every rank owns its own scene and batches (weak scaling, no data-path collective); the per-rank results of
+every batch are gathered with one RCCL all_gather inside the timed region.
 
 Arithmetic modes: `--dtype f32x` (default, the headline: BASELINE.json's cfg2 is an fp32
 configuration) computes everything in fp32; `f32` keeps the coefficient solve, adjoint and optimiser in fp64; `f64` is
-the parity mode.  With one GPU all three are timed in the same run under the same protocol (`modes`), each with its
-parity figures against the CPU optimiser; `value` is the `--dtype` mode's.
+the parity mode (`value_parity_mode`).  With one GPU all three are timed in the same run under the same protocol.
 
-Printed JSON (one line, rank 0): the driver contract plus
-  modes          f64 / f32 / f32x: traj/s, accepted traj/s, roofline fraction, parity against the CPU optimiser
-  accepted_traj_per_s   trajectories per second whose result the reference would accept (L-BFGS-B converged or stopped
-                 on its own, no `collision cost too large`, expert_planner.py:235-237): `value` counts plan_once runs
-  cfg1           BASELINE.json configs[0]: one plan() of the reference's own shape (M = 3, 2-D map, fp64) in ms -- GPU
-                 path, NumPy port, cpu_native
-  roofline       dominant kernel = optimize_kernel; achieved = algorithmic bytes per launch (samples visited *
-                 8 corners * 4 B + evaluations * (2 n 4 + 20) B) / mean launch duration from HIP
-                 events on the kernel's stream
-  esdf_kernel    the ESDF-lookup kernel alone (sample_kernel), both byte conventions, footprint of the field it touches
-  cpu_baseline   the loop-faithful NumPy/SciPy port (oracle/minco_np.py) on the usable host cores, bounded sample
-  cpu_native     the C++ fp64 restatement in the reference's formulation (oracle/cpu_native), same sample
-  parity         final control points / cost of the GPU runs against the CPU optimiser on the same trajectories,
-                 next to the CONTROL: the CPU optimiser against itself with fp32-rounded sampling and with the
-                 coefficients perturbed by one ulp
+The compact line: the driver contract keys, `config`, `roofline` (dominant kernel = optimize_kernel; achieved =
+algorithmic bytes per launch -- samples visited x 8 corners x e B + evaluations x (2 n 4 + 20) B, SURVEY.md 8.d2 -- over
+the mean launch duration from HIP events on the kernel's stream), `esdf_kernel` (the ESDF-lookup kernel alone),
+`cpu_baseline` (the loop-faithful NumPy / SciPy port on the usable host cores, bounded sample), `cpu_native`, `modes`,
+`single_batch_traj_per_s`, `details`.
 """
 import argparse
 import ctypes
@@ -60,67 +53,15 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 REPO = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, REPO)
-sys.path.insert(0, os.path.join(REPO, "neo-planner_amd"))
+for p_ in (REPO, os.path.join(REPO, "neo-planner_amd"), os.path.join(REPO, "tools")):
+    if p_ not in sys.path:
+        sys.path.insert(0, p_)
 
 import numpy as np
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak
 CANOPY = 80                 # floating boxes per 3-D scene (synth.canopy_boxes)
-
-
-def pmc_profile(kernel, default_workload):
-    """PMC counters per launch of `kernel` from the newest committed rocprofv3 passes of this same command
-    (profiles/*_pmc.json; FETCH_SIZE / WRITE_SIZE in KB per dispatch, raw, separate passes).  PMC counters cannot
-    be collected from inside the process, so these are the profile's figures, or {} when the workload differs."""
-    import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc.json")))
-    if not files or not default_workload:
-        return {}, None
-    try:
-        prof = json.load(open(files[-1]))
-        if "--config" in prof.get("command", "") and "--config cfg2" not in prof.get("command", ""):
-            return {}, None          # (counters of another configuration: profiles/*_counters.json is where they belong)
-        ks = prof["kernels"]
-        k = ks[kernel] if kernel in ks else ks[kernel.split("@")[0]]    # (profiles before round 3 are not keyed by grid)
-        return {c: v["mean_per_dispatch"] for c, v in k.items() if "mean_per_dispatch" in v}, os.path.relpath(files[-1], REPO)
-    except Exception:
-        return {}, None
-
-
-# measured on the MI355X for the ESDF kernel's access shape (tools/gpu_gather_calib.py, profiles/r03_gather_calib.json):
-# 32-byte lookups at random offsets of a 432 MB buffer reach 54.6 lookups/ns = 1.75 TB/s of useful bytes, every one a
-# 128-byte L2 -> fabric request: 7.0 TB/s of lines.  The same run calibrates FETCH_SIZE for this shape: exactly half of
-# the bytes the L2 requests (TCC_EA0_RDREQ_128B x 128), as MI355X_MICROARCH.md states for streaming reads.
-GATHER_LINE_ROOFLINE_GBPS = 7020.0
-
-
-def hbm_traffic(pm):
-    """bytes the L2 moved to and from the fabric (HBM / Infinity Cache) per launch.  From the L2's own read requests by
-    size when the profile has them (32 n32 + 64 n64 + 128 n128: exact for every launch shape); otherwise 2 x FETCH_SIZE
-    -- the gfx950 correction of MI355X_MICROARCH.md, calibrated for large streaming / gather launches
-    (profiles/r03_gather_calib.json; small grids read ~0.9 x there, so the rule is recorded in `traffic_rule`)."""
-    if "WRITE_SIZE" not in pm:
-        return None
-    if "TCC_EA0_RDREQ_128B_sum" in pm and "TCC_EA0_RDREQ_sum" in pm:
-        n128, n64, n32 = pm["TCC_EA0_RDREQ_128B_sum"], pm.get("TCC_EA0_RDREQ_64B_sum", 0.0), pm.get("TCC_EA0_RDREQ_32B_sum", 0.0)
-        return 128.0 * n128 + 64.0 * n64 + 32.0 * n32 + pm["WRITE_SIZE"] * 1024.0
-    if "FETCH_SIZE" not in pm:
-        return None
-    return (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
-
-
-def traffic_rule(pm):
-    if "WRITE_SIZE" not in pm:
-        return None
-    return ("32/64/128-byte L2 read requests (TCC_EA0_RDREQ_*) + WRITE_SIZE" if "TCC_EA0_RDREQ_128B_sum" in pm
-            else "2 x FETCH_SIZE + WRITE_SIZE (large-launch calibration)")
-
-
-def l2_hit(pm):
-    if "TCC_HIT_sum" not in pm:
-        return None
-    return pm["TCC_HIT_sum"] / max(pm["TCC_HIT_sum"] + pm.get("TCC_MISS_sum", 0.0), 1.0)
+LINE_LIMIT = 4096           # bytes of the final stdout line (the driver's parser gave up at 20 KB in round 4)
 
 
 def parse(argv=None):
@@ -143,6 +84,10 @@ def parse(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-retries", action="store_true", help="skip the warm_start_plan retry-chain measurement")
     ap.add_argument("--no-modes", action="store_true", help="time only the --dtype mode (cfg2 on one GPU times all three)")
+    ap.add_argument("--no-report", action="store_true",
+                    help="the timed region and the compact line only: nothing of tools/bench_report.py runs")
+    ap.add_argument("--details", default=None,
+                    help="where the full report goes (default gpurun_out/bench_details.json, /tmp when that is not writable)")
     ap.add_argument("--esdf-order", default="spatial", choices=["spatial", "index"],
                     help="dispatch order of the stand-alone ESDF-lookup kernel: XCD-aware spatial order "
                          "(BatchPlanner.spatial_order) or index order; the other one is timed beside it")
@@ -169,7 +114,7 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
-# ================================================================== CPU legs (a child process that never touches HIP)
+# ================================================================== CPU leg (a child process that never touches HIP)
 def usable_cpus():
     """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -215,8 +160,9 @@ def _np_worker(args):
 
 
 def cpu_leg(workdir):
-    """runs in its own process: (1) single-process calibration and pooled run of the NumPy/SciPy port, (2) cpu_native
-    on the same cores, (3) the parity control.  Reads workdir/in.npz + field.npy, writes workdir/out.npz + out.json."""
+    """runs in its own process: (1) single-process calibration and pooled run of the NumPy/SciPy port = `cpu_baseline`,
+    (2) cpu_native on the same cores, (3) with `report` set the parity controls and cfg1's CPU side
+    (tools/bench_report.py).  Reads workdir/in.npz + field.npy, writes workdir/out.npz + out.json."""
     import multiprocessing as mp
     cfg = json.load(open(os.path.join(workdir, "in.json")))
     d = np.load(os.path.join(workdir, "in.npz"))
@@ -258,7 +204,7 @@ def cpu_leg(workdir):
     arrays["np_nfev"] = np.array([r[2] for r in np_all])
     arrays["np_wp"] = np.stack([r[3] for r in np_all])
 
-    # ---- (2) cpu_native, (3) control
+    # ---- (2) cpu_native
     from oracle import cpu_native as cn
     from oracle import minco_np as onp
     nm = cn.NativeMap.from_field3d(np.asarray(dist, dtype=np.float32), res, origin)
@@ -267,7 +213,7 @@ def cpu_leg(workdir):
     x0 = np.concatenate([wp.reshape(B, -1), tau], axis=1)
     sec = cfg["native_seconds"]
     t0 = time.time()
-    one = cn.optimize_batch(nm, x0[:8], head[:8], tail[:8], M, D, threads=1)
+    cn.optimize_batch(nm, x0[:8], head[:8], tail[:8], M, D, threads=1)
     nat_single = 8 / (time.time() - t0)
     t0 = time.time()
     base = cn.optimize_batch(nm, x0, head, tail, M, D, threads=cores, limit_s=sec)
@@ -286,64 +232,9 @@ def cpu_leg(workdir):
     arrays["nat_cost"] = (base["costs_last"][sel] * w).sum(axis=1)
     arrays["nat_nfev"] = base["nfev"][sel]
     arrays["nat_wp"] = base["x"][sel, :nq]
-    # agreement of the two CPU implementations with each other (different solvers of the same system)
-    common = np.intersect1d(arrays["np_idx"], sel)
-    if len(common):
-        a = {int(i): k for k, i in enumerate(arrays["np_idx"])}
-        b = {int(i): k for k, i in enumerate(sel)}
-        ia = np.array([a[int(i)] for i in common]); ib = np.array([b[int(i)] for i in common])
-        dx = np.abs(arrays["np_wp"][ia] - arrays["nat_wp"][ib]).max(axis=1) / np.abs(arrays["np_wp"][ia]).max(axis=1)
-        out["cpu_native"]["vs_numpy_port"] = dict(
-            n=int(len(common)), frac_same_nfev=float((arrays["np_nfev"][ia] == arrays["nat_nfev"][ib]).mean()),
-            control_points_frac_within_1e_4=float((dx <= 1e-4).mean()), control_points_rel_median=float(np.median(dx)))
-
-    def control(name, **kw):
-        o = cn.optimize_batch(nm, x0[sel], head[sel], tail[sel], M, D, params=cn.make_params(**kw), threads=cores)
-        c0 = arrays["nat_cost"]
-        c1 = (o["costs_last"] * w).sum(axis=1)
-        relc = np.abs(c1 - c0) / np.maximum(np.abs(c0), 1e-12)
-        dx = np.abs(o["x"][:, :nq] - arrays["nat_wp"]).max(axis=1) / np.maximum(np.abs(arrays["nat_wp"]).max(axis=1), 1e-12)
-        return dict(n=int(len(sel)), what=name, status_hist=np.bincount(o["status"] & 0xff, minlength=7).tolist(),
-                    collision_flag_frac=float(((o["status"] & 0x100) != 0).mean()),
-                    frac_same_nfev=float((o["nfev"] == arrays["nat_nfev"]).mean()),
-                    control_points_frac_within_1e_4=float((dx <= 1e-4).mean()), control_points_rel_median=float(np.median(dx)),
-                    final_cost_frac_within_1e_4=float((relc <= 1e-4).mean()), final_cost_rel_median=float(np.median(relc)))
-    out["parity_control"] = dict(
-        cpu_vs_cpu_fp32_sampling=control("cpu_native against itself with the sampled terms in fp32 arithmetic "
-                                         "(what the GPU's timed mode does)", sample_f32=True),
-        cpu_vs_cpu_coeffs_1ulp=control("cpu_native against itself with every polynomial coefficient perturbed by a "
-                                       "relative 2.2e-16 (what any other solver of the same system does)",
-                                       coeff_eps=2.2e-16),
-        cpu_vs_cpu_all_fp32_like=control("cpu_native against itself with the sampled terms in fp32 arithmetic, the "
-                                         "coefficients perturbed by a relative 1e-7 and the gradient entries by 3e-6 (the "
-                                         "per-evaluation deviations of the GPU's all-fp32 mode from the fp64 solve)",
-                                         sample_f32=True, coeff_eps=1e-7, grad_eps=3e-6))
-    if cfg.get("cfg1"):
-        # BASELINE.json configs[0]: one plan() of the reference's own shape on one host core
-        import contextlib
-        import io
-        from neo_planner_amd import synth
-        occ2 = synth.occupancy_2d(3)
-        o2 = onp.GridESDF(occ2, synth.RES, 300, 300, (0.0, -15.0))
-        h2 = np.array([[0.0, 0.0], [0.0, 0.0]]); t2 = np.array([[5.0, 0.3], [0.8, 0.0]])
-        ref = onp.OraclePlanner(onp.PlannerParams())
-        with contextlib.redirect_stdout(io.StringIO()):
-            ref.plan(o2, h2, t2)
-            t0 = time.time()
-            for _ in range(5):
-                ref.plan(o2, h2, t2)
-            port_ms = 1e3 * (time.time() - t0) / 5
-            nm2 = cn.NativeMap.from_grid2d(o2)
-            npl = cn.NativePlanner()
-            iw, its = ref.generate_init_variables(h2, t2)
-            t0 = time.time()
-            for _ in range(50):
-                npl.read_planning_conditions(nm2, h2, t2, iw, its)
-                npl.plan_once()
-            nat_ms = 1e3 * (time.time() - t0) / 50
-        out["cfg1"] = dict(plan_ms_cpu_port=port_ms, plan_ms_cpu_native=nat_ms, plan_final_cost_cpu_port=float(ref.final_cost),
-                           cpu_note="one host core; port = oracle/minco_np.py (the reference's per-sample Python loops + "
-                                    "SciPy L-BFGS-B), native = oracle/cpu_native cost/gradient in C++ under SciPy L-BFGS-B")
+    if cfg.get("report"):
+        import bench_report
+        bench_report.cpu_leg_extras(out, arrays, cn, onp, nm, x0, head, tail, M, D, sel, cores, cfg)
     np.savez(os.path.join(workdir, "out.npz"), **arrays)
     json.dump(out, open(os.path.join(workdir, "out.json"), "w"))
 
@@ -353,7 +244,7 @@ def run_cpu_leg(a, dist_host, res, origin, head, tail, wp, ts):
     np.save(os.path.join(wd, "field.npy"), dist_host)
     np.savez(os.path.join(wd, "in.npz"), head=head, tail=tail, wp=wp, ts=ts)
     json.dump(dict(res=res, origin=list(origin), cpu_seconds=a.cpu_seconds, native_seconds=a.native_seconds,
-                   cfg1=(a.config == "cfg2")),
+                   report=not a.no_report, cfg1=(a.config == "cfg2" and not a.no_report)),
               open(os.path.join(wd, "in.json"), "w"))
     env = dict(os.environ)
     env["NEO_NO_TORCH_PRELOAD"] = "1"
@@ -402,6 +293,118 @@ def self_launch(a, argv):
 EADDRINUSE_RC = 98    # a rank exits with this when the rendezvous port was taken between the probe and rank 0's bind
 
 
+# ================================================================== the compact line
+def _r(v, digits=6):
+    """numbers to `digits` significant digits (the line is for a parser and a reader, not for bit-exact storage)"""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}") if v == v and abs(v) != float("inf") else None
+    if isinstance(v, dict):
+        return {k: _r(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, digits) for x in v]
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out, details_path=None):
+    """the ONE stdout line: the driver contract + roofline + cpu_baseline + the few figures VERDICT r4 item 1 lists, from the
+    full report `out`; everything else stays in the side file.  Pure function of `out` (tests/test_bench_line.py builds it
+    from a canned report and holds it under LINE_LIMIT bytes)."""
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    cfg = out.get("config") or {}
+    line["config"] = _pick(cfg, ("workload", "batch_per_launch", "batches_per_step", "pieces", "dims", "esdf_voxels", "layout",
+                                 "parallelism", "launches_in_flight_per_gpu"))
+    modes = out.get("modes") or {}
+    if "f64" in modes:
+        # the mode that computes in the reference's own arithmetic and meets its 1e-4 as often as the reference meets itself
+        line["value_parity_mode"] = modes["f64"].get("value")
+    line.update(_pick(out, ("accepted_traj_per_s", "accepted_frac", "single_batch_ms", "single_batch_traj_per_s")))
+    retries = out.get("accepted_after_retries")
+    if retries:
+        line["accepted_after_retries_traj_per_s"] = retries.get("accepted_after_retries_traj_per_s")
+    rf = out.get("roofline") or {}
+    line["roofline"] = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_aggregate", "frac_one_launch_alone",
+                                  "kernel_ms", "launches", "concurrent_launches", "algorithmic_bytes_per_launch"))
+    line["roofline"]["traffic"] = rf.get("traffic")
+    line["roofline"]["traffic_source"] = rf.get("traffic_source")
+    es = out.get("esdf_kernel")
+    if es:
+        e = _pick(es, ("kernel", "bound", "achieved", "peak", "unit", "frac", "kernel_us", "trajectories", "traffic",
+                       "traffic_over_algorithmic", "traffic_source", "lookups_per_fetched_line", "l2_hit_rate",
+                       "orders_give_the_same_bits"))
+        ws = es.get("whole_step_launch")
+        if ws:
+            e["whole_step_launch"] = _pick(ws, ("trajectories", "kernel_us", "frac_8d2", "traffic_over_algorithmic"))
+        line["esdf_kernel"] = e
+    eb = out.get("esdf_build")
+    if eb:
+        line["esdf_build"] = _pick(eb, ("voxels", "ms", "GBps"))
+    cb = out.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, ("value", "unit", "cores", "kind", "per_core"))
+        c["sample"] = str(cb.get("sample", ""))[:160]
+        line["cpu_baseline"] = c
+    cn = out.get("cpu_native")
+    if cn:
+        line["cpu_native"] = _pick(cn, ("value", "unit", "cores", "kind"))
+    ml = {}
+    for m_, v_ in modes.items():
+        e = _pick(v_, ("value", "single_batch_traj_per_s", "accepted_frac", "roofline_frac"))
+        par = (v_.get("parity") or {}).get("vs_cpu_native") or {}
+        if "control_points_frac_within_1e_4" in par:
+            e["finals_within_1e_4"] = par["control_points_frac_within_1e_4"]
+        g6 = ((((out.get("parity") or {}).get("vs_reference_fixtures") or {})
+               .get("g6_finals_within_1e_4_of_the_reference")) or {})
+        if m_ in g6:
+            e["g6_finals_within_1e_4_of_reference"] = g6[m_]
+        ml[m_] = e
+    if ml:
+        line["modes"] = ml
+    ctl = (((out.get("parity") or {}).get("control") or {}).get("cpu_vs_cpu_coeffs_1ulp") or {})
+    if "control_points_frac_within_1e_4" in ctl:
+        line["cpu_vs_cpu_1ulp_finals_within_1e_4"] = ctl["control_points_frac_within_1e_4"]
+    c1 = out.get("cfg1")
+    if c1:
+        line["cfg1"] = _pick(c1, ("plan_ms_gpu", "plan_ms_cpu_port", "plan_ms_cpu_native"))
+    line.update(_pick(out, ("rccl_ranks", "gather_ok", "dist_backend", "per_rank_traj_per_s", "timed_region_s")))
+    line["details"] = details_path
+    line = _r(line)
+    s = json.dumps(line, separators=(",", ":"))
+    # belt and braces: drop optional blocks, last first, until the line fits
+    for k in ("cfg1", "esdf_build", "cpu_native", "per_rank_traj_per_s", "accepted_after_retries_traj_per_s"):
+        if len(s) <= LINE_LIMIT:
+            break
+        line.pop(k, None)
+        s = json.dumps(line, separators=(",", ":"))
+    if len(s) > LINE_LIMIT:
+        line["config"]["workload"] = line["config"].get("workload", "")[:120]
+        line.get("cpu_baseline", {}).pop("sample", None)
+        s = json.dumps(line, separators=(",", ":"))
+    return s
+
+
+def write_details(a, out):
+    """the full report -> a side file; returns its path relative to the repository (or absolute under /tmp)"""
+    cands = [a.details] if a.details else [os.path.join(REPO, "gpurun_out", "bench_details.json"),
+                                            os.path.join(tempfile.gettempdir(), "neo_bench_details.json")]
+    for path in cands:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            with open(path, "w") as f:
+                json.dump(out, f, indent=1)
+            ap_ = os.path.abspath(path)
+            return os.path.relpath(ap_, REPO) if ap_.startswith(REPO + os.sep) else ap_
+        except OSError:
+            continue
+    return None
+
+
 # ================================================================== one rank
 def workload_sets(a, rank, M, D, n_sets, n_scenes):
     """request batches of this rank: list of (head, tail, wp, ts)"""
@@ -418,9 +421,266 @@ def workload_sets(a, rank, M, D, n_sets, n_scenes):
     return sets
 
 
+class Rank:
+    """everything one rank keeps in HBM for the bench, the launch of one request batch, the fence and the timed region.
+    tools/bench_report.py's sections take this object (attributes: a, ctx, dev, bp, g3, batches, streams, sets, ...)."""
+
+    def __init__(self, a, rank, local_rank, world, use_dist):
+        import torch
+        import neo_planner_amd as npa
+        from neo_planner_amd import _lib, synth, sharding
+        self.a, self.rank, self.world, self.use_dist = a, rank, world, use_dist
+        self.torch, self.npa, self._lib, self.synth, self.sharding = torch, npa, _lib, synth, sharding
+        self.store = "f16" if a.config == "cfg5" else "f32"
+        self.n_scenes = a.scenes if a.config == "cfg4" else 1
+        self.n_sets = a.batches_per_step
+        self.M, self.D, self.B = a.waypoints + 1, 3, a.batch
+        self.n = self.D * (self.M - 1) + self.M
+        self.res = 30.0 / a.grid
+        self.canopy = 0 if a.planar else CANOPY
+        self.esz = 4 if self.store == "f32" else 2
+        M, D, B, n = self.M, self.D, self.B, self.n
+        self.t_setup = time.time()
+        self.occ = synth.occupancy_3d(rank, n=a.grid, res=self.res, canopy=self.canopy)      # scene = rank (weak scaling)
+        self.sets = workload_sets(a, rank, M, D, self.n_sets, self.n_scenes)
+        if a.share_gpu:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        self.dev = dev = torch.device("cuda", local_rank)
+        self.dist = None
+        if use_dist:
+            import torch.distributed as dist_
+            self.dist = dist_
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            try:
+                if a.dist_backend == "nccl":
+                    dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                else:
+                    dist_.init_process_group(a.dist_backend, rank=rank, world_size=world)
+            except Exception as ex:
+                if "EADDRINUSE" in str(ex) or "address already in use" in str(ex).lower():
+                    sys.exit(EADDRINUSE_RC)      # self_launch picks another port
+                raise
+        # one explicit (non-default) stream for everything: torch copies, our kernels, RCCL.  The default
+        # stream has handle 0, which the C ABI reads as "create your own stream".
+        self.tstream = tstream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(tstream)
+        assert tstream.cuda_stream != 0
+        self.ctx = ctx = npa.Context(local_rank, stream=tstream.cuda_stream)
+        self.bp = self.planner_for(a.dtype)
+        self.bp._sync()
+        self.want_cpu = world == 1 and rank == 0 and not a.no_cpu
+        self.g3 = npa.ESDF3D.from_occupancy(torch.from_numpy(self.occ).to(dev), self.res, synth.DOMAIN_ORIGIN, store=self.store,
+                                            layout=a.layout, ctx=ctx, want_dist=self.want_cpu)
+        self.slots = None
+        self.scenes = [self.g3]
+        if self.n_scenes > 1:
+            # cfg4: every scene's field resident in this GPU's HBM, trajectories carry their scene's table slot
+            for s_ in range(1, self.n_scenes):
+                o_ = synth.occupancy_3d(rank * self.n_scenes + s_, n=a.grid, res=self.res, canopy=self.canopy)
+                self.scenes.append(npa.ESDF3D.from_occupancy(torch.from_numpy(o_).to(dev), self.res, synth.DOMAIN_ORIGIN,
+                                                             store=self.store, layout=a.layout, ctx=ctx))
+            sl = [ctx.lib.neo_scene_slot(ctx.h, sc.scene_id) for sc in self.scenes]
+            self.slots = torch.tensor(np.repeat(sl, 4096), dtype=torch.int32, device=dev)
+        self.init = None
+        self.init_report = None
+        if a.config == "cfg3":
+            self._setup_initializer()
+        self.w = torch.tensor(self.bp.cfg.weights, dtype=torch.float64, device=dev)
+        # `--streams` launches in flight; every request batch has its own inputs, state and result buffers and always runs
+        # on the same stream (batch r -> stream r mod streams), so reuse of its buffers is ordered by that stream
+        self.n_lanes = max(1, a.streams)
+        self.streams = [tstream] + [torch.cuda.Stream(device=dev) for _ in range(self.n_lanes - 1)]
+        self.batches = []
+        for r, (h_, t_, wp_, ts_) in enumerate(self.sets):
+            st_ = self.streams[r % self.n_lanes]
+            with torch.cuda.stream(st_):
+                x0 = torch.from_numpy(self.bp.pack_x(wp_, ts_)).to(dev)
+                order = None if a.no_order else torch.from_numpy(self.bp.expected_effort_order(h_, t_, ts_)).to(dev)
+                self.batches.append(dict(
+                    st=st_, x0=x0, x=torch.empty_like(x0), head=torch.from_numpy(h_).to(dev), tail=torch.from_numpy(t_).to(dev),
+                    order=order, nsamp=torch.zeros(B, dtype=torch.int64, device=dev),
+                    costs=torch.zeros(B, 4, dtype=torch.float64, device=dev), last=torch.zeros(B, 4, dtype=torch.float64, device=dev),
+                    nit=torch.zeros(B, dtype=torch.int32, device=dev), nfev=torch.zeros(B, dtype=torch.int32, device=dev),
+                    status=torch.zeros(B, dtype=torch.int32, device=dev),
+                    gathered=torch.empty(world * B, n + 5, dtype=torch.float32, device=dev) if use_dist else None))
+
+    def planner_for(self, mode):
+        # several launches in flight -> the throughput variant of the optimiser kernel (two wavefronts per SIMD)
+        p_ = self.npa.BatchPlanner(ctx=self.ctx, sample_dtype=mode, waves_per_simd=2 if self.a.streams > 1 else None,
+                                   lane_groups=self.a.lane_groups)
+        p_.flags |= int(os.environ.get("NEO_BENCH_FLAGS_OR", "0"))     # kernel experiments
+        return p_
+
+    def _setup_initializer(self):
+        """cfg3: initializer warm start (random weights: the reference's trained ones are not in its tree).  One synthetic
+        depth image per scene through the backbone once; the dense head runs per trajectory inside the timed region."""
+        torch, synth, a, dev, B = self.torch, self.synth, self.a, self.dev, self.B
+        from neo_planner_amd import initializer as ini
+        head, tail = self.sets[0][0], self.sets[0][1]
+        torch.manual_seed(1234 + self.rank)
+        self.init = init = ini.BatchInitializer(device=dev)
+        # pinhole depth image of the scene's boxes from the mean start pose, looking along +x (SURVEY.md 8.d1)
+        depth = ini.raycast_depth(synth.forest_boxes(self.rank), synth.canopy_boxes(self.rank, self.canopy) if self.canopy else [],
+                                  eye=head[:, 0].mean(axis=0))
+        t_bb = time.perf_counter()
+        self.feat = init.scene_feature(depth)
+        torch.cuda.synchronize()
+        first = 1e3 * (time.perf_counter() - t_bb)
+        t_bb = time.perf_counter()
+        for _ in range(5):
+            self.feat = init.scene_feature(depth)
+        torch.cuda.synchronize()
+        self.init_report = {"backbone_ms_per_scene": 1e3 * (time.perf_counter() - t_bb) / 5, "backbone_ms_first_call": first,
+                            "weights": "random (the reference's trained weights are not in its tree): parity unpinned"}
+        goal_dir = tail[:, 0] - head[:, 0]
+        motion = np.concatenate([head[:, 1], np.tile(np.eye(3).reshape(-1), (B, 1)), np.zeros((B, 3)), head[:, 1],
+                                 goal_dir, tail[:, 1]], axis=1)
+        self.d_motion = torch.from_numpy(motion.astype(np.float32)).to(dev)
+        self.d_R = torch.eye(3, dtype=torch.float64, device=dev).expand(B, 3, 3).contiguous()
+        self.d_p0 = torch.from_numpy(head[:, 0]).to(dev)
+        self.line = torch.from_numpy(np.stack([head[:, 0] + goal_dir * f for f in (1 / 3, 2 / 3)], axis=2)).to(dev)   # [B,3,2]
+
+    def warm_start(self, x0_):
+        """network output -> x0: body-frame waypoints (a small correction on the straight line, the net being untrained)
+        and durations clamped into (T_min, T_max), then tau = map_T2tau(ts)"""
+        torch, B, M, D = self.torch, self.B, self.M, self.D
+        T_lo, T_hi = self.bp.cfg.T_min, self.bp.cfg.T_max
+        out = self.init.net.head(self.feat, self.d_motion).double()
+        local = out[:, :6].reshape(B, 2, 3)
+        world_ = torch.einsum("bij,bwj->bwi", self.d_R, local) + self.d_p0[:, None, :]
+        wp_ = self.line + 0.05 * (world_.transpose(1, 2) - self.d_p0[:, :, None])
+        eps = 1e-3 * (T_hi - T_lo)
+        ts_ = (2.5 + out[:, 6:]).clamp(T_lo + eps, T_hi - eps)
+        tau_ = -torch.log((T_hi - T_lo) / (ts_ - T_lo) - 1.0)
+        x0_[:, :D * (M - 1)] = wp_.reshape(B, -1)
+        x0_[:, D * (M - 1):] = tau_
+
+    def launch(self, bt, bpm):
+        torch, ctx, B = self.torch, self.ctx, self.B
+        ctx.set_stream(bt["st"].cuda_stream)
+        ctx.check(ctx.lib.neo_optimize_sample_counter(ctx.h, ctypes.c_void_p(bt["nsamp"].data_ptr())))
+        ctx.check(ctx.lib.neo_optimize_dispatch_order(
+            ctx.h, ctypes.c_void_p(bt["order"].data_ptr()) if bt["order"] is not None else None, B))
+        with torch.cuda.stream(bt["st"]):
+            if self.init is not None:
+                with torch.no_grad():
+                    self.warm_start(bt["x0"])
+            # start points are read from x0, results written to x: no copy per launch (neo_optimize_batch_from_dev)
+            bpm.optimize_dev(self.g3, bt["x"], bt["head"], bt["tail"], bt["costs"], bt["last"], bt["nit"], bt["nfev"],
+                             bt["status"], slots=self.slots, x0=bt["x0"])
+            if self.use_dist:
+                # results to every rank: final x, total cost, 4 cost terms (SURVEY.md 8.e1).  The gather runs
+                # behind the batch on the process group's own stream; this batch's stream does not wait for it
+                # (the fence at the end of the timed region does), only the batch's next use of its buffers does.
+                if bt.get("work") is not None:
+                    bt["work"].wait()
+                bt["packed"] = self.sharding.pack_results(bt["x"], bt["costs"], self.w)
+                _, bt["work"] = self.sharding.gather_results(bt["packed"], self.world, out=bt["gathered"], force=True,
+                                                             async_op=True)
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.use_dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def kernel_time(self, which):
+        """(launches, total ms) of a kernel family since neo_profile_reset: HIP events on the stream each launch ran on"""
+        launches, kms = ctypes.c_int64(), ctypes.c_double()
+        self.ctx.check(self.ctx.lib.neo_profile_read(self.ctx.h, which, ctypes.byref(launches), ctypes.byref(kms)))
+        return int(launches.value), float(kms.value)
+
+    def time_mode(self, mode):
+        """W warm-up steps, then exactly K timed steps of the hot path in arithmetic mode `mode`, fenced by a barrier
+        and a device synchronisation on both sides; returns the timing and what the launches of the last step left"""
+        torch, ctx, a = self.torch, self.ctx, self.a
+        bpm = self.bp if mode == a.dtype else self.planner_for(mode)
+        bpm._sync()
+        self.fence()
+        for k in range(a.warmup):
+            for bt in self.batches:
+                self.launch(bt, bpm)
+        self.fence()
+        ctx.check(ctx.lib.neo_profile_reset(ctx.h))
+        ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            for bt in self.batches:
+                self.launch(bt, bpm)
+        self.fence()
+        el = time.perf_counter() - t0
+        ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
+        ctx.set_stream(None)
+        launches, kms = self.kernel_time(self._lib.NEO_KERNEL_OPTIMIZE)
+        # one launch ALONE on the chip (outside the timed region): what a caller with a single request batch gets -- with
+        # `--streams` launches in flight each one lasts longer than it would by itself
+        solo = None
+        if self.rank == 0 and not self.use_dist:
+            ctx.check(ctx.lib.neo_profile_reset(ctx.h))
+            ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
+            for _ in range(3):
+                self.launch(self.batches[0], bpm)
+                self.fence()
+            ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
+            ctx.set_stream(None)
+            l_s, m_s = self.kernel_time(self._lib.NEO_KERNEL_OPTIMIZE)
+            solo = m_s / max(l_s, 1)
+        nfev_all = torch.stack([bt["nfev"] for bt in self.batches]).cpu().numpy().astype(np.int64)
+        nsamp_all = torch.stack([bt["nsamp"] for bt in self.batches]).cpu().numpy()
+        status_all = torch.stack([bt["status"] for bt in self.batches]).cpu().numpy()
+        # results the reference accepts: L-BFGS-B ended on its own (converged / abnormal line search: SciPy returns
+        # either without raising) and the weighted collision cost is within tolerance (expert_planner.py:235-237)
+        accepted = ((status_all & 0xff) <= 2) & ((status_all & 0x100) == 0)
+        # algorithmic bytes of ONE launch, mean over the step's batches (SURVEY.md 8.d2): S*C*e per evaluation + 2*n*4 + 20
+        bytes_launch = (float(nsamp_all.sum()) * 8 * self.esz + float(nfev_all.sum()) * (2 * self.n * 4 + 20)) / self.n_sets
+        b0_ = self.batches[0]
+        return dict(mode=mode, elapsed=el, kernel_ms=kms / max(launches, 1), launches=launches, nfev_all=nfev_all, solo_ms=solo,
+                    nsamp_all=nsamp_all, status_all=status_all, accepted_frac=float(accepted.mean()),
+                    bytes_launch=bytes_launch, mean_nit=float(b0_["nit"].float().mean().item()),
+                    b0=dict(x=b0_["x"].clone(), last=b0_["last"].clone(), nfev=b0_["nfev"].clone()))
+
+    def mode_line(self, r_):
+        """one arithmetic mode under the bench protocol (this rank; with N ranks `value` is the job's)"""
+        a, B = self.a, self.B
+        v_ = B * self.n_sets * a.steps / r_["elapsed"]
+        ach = r_["bytes_launch"] / (r_["kernel_ms"] * 1e-3) / 1e9
+        return {"value": v_, "unit": "traj/s", "ms_per_step": 1e3 * r_["elapsed"] / a.steps,
+                "accepted_frac": r_["accepted_frac"], "accepted_traj_per_s": v_ * r_["accepted_frac"],
+                "single_batch_ms": r_["solo_ms"],
+                "single_batch_traj_per_s": (B / (r_["solo_ms"] * 1e-3)) if r_["solo_ms"] else None,
+                "kernel_ms": r_["kernel_ms"], "roofline_frac": ach / HBM_PEAK_GBPS,
+                "roofline_frac_aggregate": r_["bytes_launch"] * self.n_sets * a.steps / r_["elapsed"] / 1e9 / HBM_PEAK_GBPS,
+                "mean_nfev": float(r_["nfev_all"].mean()), "max_nfev": int(r_["nfev_all"].max()),
+                "status_hist": np.bincount(r_["status_all"].reshape(-1) & 0xff, minlength=7).tolist(),
+                "sampling_arithmetic": "f64" if r_["mode"] == "f64" else "f32",
+                "solve_and_optimiser_arithmetic": "f32" if r_["mode"] == "f32x" else "f64"}
+
+    def esdf_build_time(self):
+        """ESDF construction, occupancy resident in HBM: the same call again, timed"""
+        torch, a, ctx = self.torch, self.a, self.ctx
+        d_occ_ = torch.from_numpy(self.occ).to(self.dev)
+        tb_ = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t1_ = time.perf_counter()
+            tmp_ = self.npa.ESDF3D.from_occupancy(d_occ_, self.res, self.synth.DOMAIN_ORIGIN, store=self.store, layout=a.layout, ctx=ctx)
+            torch.cuda.synchronize(); tb_.append(time.perf_counter() - t1_)
+            ctx.lib.neo_esdf_drop(ctx.h, tmp_.scene_id)
+        nv_ = a.grid ** 3
+        # EDT: 1 B occupancy in, 2 B row distances out and in, 4 B plane distances out and in, 4 B fp32 distance out = 17 B
+        # (+ 4 B the packing pass reads back); packing writes 1 (linear), 4 (yz4 / brick) or 8 (cell8) stored elements per voxel
+        elems_ = {"linear": 1, "yz4": 4, "cell8": 8, "brick": 4}[a.layout]
+        bpv_ = 17 + 4 + elems_ * self.esz
+        return {"what": "neo_esdf_build_3d: exact EDT of the occupancy grid (three separable integer passes) + layout "
+                        "packing, device to device, wall time of the whole call (allocations included)",
+                "voxels": nv_, "ms": 1e3 * min(tb_), "algorithmic_bytes_per_voxel": bpv_, "GBps": nv_ * bpv_ / min(tb_) / 1e9}
+
+
 def main():
     argv = sys.argv[1:]
     a = parse(argv)
+    a.argv = list(argv)
     if a.cpu_leg:
         return cpu_leg(a.cpu_leg)
     if a.gpus > 1 and not a.dry_run and not a.share_gpu and a.dist_backend == "nccl":
@@ -439,8 +699,6 @@ def main():
         a.gpus = world
     # NEO_BENCH_FORCE_DIST=1: run the process-group path (RCCL gather on the batches' streams) even with one rank
     use_dist = world > 1 or bool(os.environ.get("NEO_BENCH_FORCE_DIST"))
-    store = "f32"
-    n_scenes = 1
     bps_default = 40
     if a.scenes is None:
         a.scenes = 256 // max(world, 8)      # cfg4: 256 scenes over the 8 GPUs of a node = 32 per GPU
@@ -449,253 +707,35 @@ def main():
         a.lane_groups = True            # M = 3: eight trajectories per wavefront
         bps_default = 1
     elif a.config == "cfg4":
-        n_scenes, a.no_cpu = a.scenes, True
-        a.batch = 4096 * n_scenes
+        a.no_cpu = True
+        a.batch = 4096 * a.scenes
         bps_default = 1
     elif a.config == "cfg5":
-        a.waypoints, a.grid, store, a.no_cpu = 40, 600, "f16", True
+        a.waypoints, a.grid, a.no_cpu = 40, 600, True
         bps_default = 4
-    n_sets = a.batches_per_step or bps_default
-    M, D, B = a.waypoints + 1, 3, a.batch
-    n = D * (M - 1) + M
-    default_workload = (a.config == "cfg2" and a.batch == 4096 and a.waypoints == 20 and a.grid == 300
-                        and a.dtype == "f32x" and a.layout == "brick" and not a.planar)
+    a.batches_per_step = a.batches_per_step or bps_default
+    if a.dry_run:
+        return dry_run(a, rank, world, 3 * a.waypoints + a.waypoints + 1)
+    a.default_workload = (a.config == "cfg2" and a.batch == 4096 and a.waypoints == 20 and a.grid == 300
+                          and a.dtype == "f32x" and a.layout == "brick" and not a.planar)
     # one GPU, cfg2: all three arithmetic modes are timed under the same protocol
     modes = [a.dtype] + ([m_ for m_ in ("f32x", "f32", "f64") if m_ != a.dtype]
                          if (a.config == "cfg2" and world == 1 and not a.no_modes) else [])
-    if a.dry_run:
-        return dry_run(a, rank, world, n)
-    from neo_planner_amd import synth
-    res = 30.0 / a.grid
-    canopy = 0 if a.planar else CANOPY
-    t_setup = time.time()
-    occ = synth.occupancy_3d(rank, n=a.grid, res=res, canopy=canopy)                  # scene = rank (weak scaling)
-    sets = workload_sets(a, rank, M, D, n_sets, n_scenes)
-    head, tail, wp, ts = sets[0]
-
-    # ---------------- GPU side
-    import torch
-    import neo_planner_amd as npa
-    from neo_planner_amd import _lib
-    if a.share_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if use_dist:
-        import torch.distributed as dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        try:
-            if a.dist_backend == "nccl":
-                dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            else:
-                dist_.init_process_group(a.dist_backend, rank=rank, world_size=world)
-        except Exception as ex:
-            if "EADDRINUSE" in str(ex) or "address already in use" in str(ex).lower():
-                sys.exit(EADDRINUSE_RC)      # self_launch picks another port
-            raise
-    # one explicit (non-default) stream for everything: torch copies, our kernels, RCCL.  The default
-    # stream has handle 0, which the C ABI reads as "create your own stream".
-    tstream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(tstream)
-    assert tstream.cuda_stream != 0
-    ctx = npa.Context(local_rank, stream=tstream.cuda_stream)
-    # several launches in flight -> the throughput variant of the optimiser kernel (two wavefronts per SIMD)
-    def planner_for(mode):
-        p_ = npa.BatchPlanner(ctx=ctx, sample_dtype=mode, waves_per_simd=2 if a.streams > 1 else None,
-                              lane_groups=a.lane_groups)
-        p_.flags |= int(os.environ.get("NEO_BENCH_FLAGS_OR", "0"))     # kernel experiments
-        return p_
-    bp = planner_for(a.dtype)
-    bp._sync()
-    want_cpu = world == 1 and rank == 0 and not a.no_cpu
-    g3 = npa.ESDF3D.from_occupancy(torch.from_numpy(occ).to(dev), res, synth.DOMAIN_ORIGIN, store=store, layout=a.layout,
-                                   ctx=ctx, want_dist=want_cpu)
-    # ESDF construction, occupancy resident in HBM: the same call again, timed
-    esdf_build = None
-    if rank == 0 and world == 1:
-        d_occ_ = torch.from_numpy(occ).to(dev)
-        tb_ = []
-        for _ in range(3):
-            torch.cuda.synchronize(); t1_ = time.perf_counter()
-            tmp_ = npa.ESDF3D.from_occupancy(d_occ_, res, synth.DOMAIN_ORIGIN, store=store, layout=a.layout, ctx=ctx)
-            torch.cuda.synchronize(); tb_.append(time.perf_counter() - t1_)
-            ctx.lib.neo_esdf_drop(ctx.h, tmp_.scene_id)
-        nv_ = a.grid ** 3
-        # EDT: 1 B occupancy in, 2 B row distances out and in, 4 B plane distances out and in, 4 B fp32 distance out = 17 B
-        # (+ 4 B the packing pass reads back); packing writes 1 (linear), 4 (yz4) or 8 (cell8) stored elements per voxel
-        elems_ = {"linear": 1, "yz4": 4, "cell8": 8, "brick": 4}[a.layout]
-        bpv_ = 17 + 4 + elems_ * (4 if store == "f32" else 2)
-        esdf_build = {"what": "neo_esdf_build_3d: exact EDT of the occupancy grid (three separable integer passes) + layout "
-                              "packing, device to device, wall time of the whole call (allocations included)",
-                      "voxels": nv_, "ms": 1e3 * min(tb_), "algorithmic_bytes_per_voxel": bpv_,
-                      "GBps": nv_ * bpv_ / min(tb_) / 1e9}
-        del d_occ_
-    slots = None
-    scenes = [g3]
-    if n_scenes > 1:
-        # cfg4: every scene's field resident in this GPU's HBM, trajectories carry their scene's table slot
-        for s_ in range(1, n_scenes):
-            o_ = synth.occupancy_3d(rank * n_scenes + s_, n=a.grid, res=res, canopy=canopy)
-            scenes.append(npa.ESDF3D.from_occupancy(torch.from_numpy(o_).to(dev), res, synth.DOMAIN_ORIGIN, store=store,
-                                                    layout=a.layout, ctx=ctx))
-        sl = [ctx.lib.neo_scene_slot(ctx.h, sc.scene_id) for sc in scenes]
-        slots = torch.tensor(np.repeat(sl, 4096), dtype=torch.int32, device=dev)
-    init = None
-    if a.config == "cfg3":
-        # initializer warm start (random weights: the reference's trained ones are not in its tree).  One
-        # synthetic depth image per scene through the backbone once; the dense head runs per trajectory.
-        from neo_planner_amd import initializer as ini
-        torch.manual_seed(1234 + rank)
-        init = ini.BatchInitializer(device=dev)
-        if hasattr(ini, "raycast_depth"):
-            # pinhole depth image of the scene's boxes from the mean start pose, looking along +x
-            depth = ini.raycast_depth(synth.forest_boxes(rank), synth.canopy_boxes(rank, canopy) if canopy else [],
-                                      eye=head[:, 0].mean(axis=0))
-        else:
-            rng_i = np.random.default_rng(77 + rank)
-            depth = (255 * rng_i.random((ini.IMG_HEIGHT, ini.IMG_WIDTH))).astype(np.uint8)
-        t_bb = time.perf_counter()
-        feat = init.scene_feature(depth)
-        torch.cuda.synchronize()
-        backbone_ms_first = 1e3 * (time.perf_counter() - t_bb)
-        t_bb = time.perf_counter()
-        for _ in range(5):
-            feat = init.scene_feature(depth)
-        torch.cuda.synchronize()
-        backbone_ms = 1e3 * (time.perf_counter() - t_bb) / 5
-        goal_dir = tail[:, 0] - head[:, 0]
-        motion = np.concatenate([head[:, 1], np.tile(np.eye(3).reshape(-1), (B, 1)), np.zeros((B, 3)), head[:, 1],
-                                 goal_dir, tail[:, 1]], axis=1)
-        d_motion = torch.from_numpy(motion.astype(np.float32)).to(dev)
-        d_R = torch.eye(3, dtype=torch.float64, device=dev).expand(B, 3, 3).contiguous()
-        d_p0 = torch.from_numpy(head[:, 0]).to(dev)
-        line = torch.from_numpy(np.stack([head[:, 0] + goal_dir * f for f in (1 / 3, 2 / 3)], axis=2)).to(dev)   # [B,3,2]
-        T_lo, T_hi = bp.cfg.T_min, bp.cfg.T_max
-    from neo_planner_amd import sharding
-    w = torch.tensor(bp.cfg.weights, dtype=torch.float64, device=dev)
-    # `--streams` launches in flight; every request batch has its own inputs, state and result buffers and always runs
-    # on the same stream (batch r -> stream r mod streams), so reuse of its buffers is ordered by that stream
-    n_lanes = max(1, a.streams)
-    streams = [tstream] + [torch.cuda.Stream(device=dev) for _ in range(n_lanes - 1)]
-    batches = []
-    for r, (h_, t_, wp_, ts_) in enumerate(sets):
-        st_ = streams[r % n_lanes]
-        with torch.cuda.stream(st_):
-            x0 = torch.from_numpy(bp.pack_x(wp_, ts_)).to(dev)
-            order = None if a.no_order else torch.from_numpy(bp.expected_effort_order(h_, t_, ts_)).to(dev)
-            batches.append(dict(
-                st=st_, x0=x0, x=torch.empty_like(x0), head=torch.from_numpy(h_).to(dev), tail=torch.from_numpy(t_).to(dev),
-                order=order, nsamp=torch.zeros(B, dtype=torch.int64, device=dev),
-                costs=torch.zeros(B, 4, dtype=torch.float64, device=dev), last=torch.zeros(B, 4, dtype=torch.float64, device=dev),
-                nit=torch.zeros(B, dtype=torch.int32, device=dev), nfev=torch.zeros(B, dtype=torch.int32, device=dev),
-                status=torch.zeros(B, dtype=torch.int32, device=dev),
-                gathered=torch.empty(world * B, n + 5, dtype=torch.float32, device=dev) if use_dist else None))
-    b0 = batches[0]
-
-    def warm_start(x0_):
-        """network output -> x0: body-frame waypoints (a small correction on the straight line, the net
-        being untrained) and durations clamped into (T_min, T_max), then tau = map_T2tau(ts)"""
-        out = init.net.head(feat, d_motion).double()
-        local = out[:, :6].reshape(B, 2, 3)
-        world_ = torch.einsum("bij,bwj->bwi", d_R, local) + d_p0[:, None, :]
-        wp_ = line + 0.05 * (world_.transpose(1, 2) - d_p0[:, :, None])
-        eps = 1e-3 * (T_hi - T_lo)
-        ts_ = (2.5 + out[:, 6:]).clamp(T_lo + eps, T_hi - eps)
-        tau_ = -torch.log((T_hi - T_lo) / (ts_ - T_lo) - 1.0)
-        x0_[:, :D * (M - 1)] = wp_.reshape(B, -1)
-        x0_[:, D * (M - 1):] = tau_
-
-    def launch(bt, bpm):
-        ctx.set_stream(bt["st"].cuda_stream)
-        ctx.check(ctx.lib.neo_optimize_sample_counter(ctx.h, ctypes.c_void_p(bt["nsamp"].data_ptr())))
-        ctx.check(ctx.lib.neo_optimize_dispatch_order(
-            ctx.h, ctypes.c_void_p(bt["order"].data_ptr()) if bt["order"] is not None else None, B))
-        with torch.cuda.stream(bt["st"]):
-            if init is not None:
-                with torch.no_grad():
-                    warm_start(bt["x0"])
-            # start points are read from x0, results written to x: no copy per launch (neo_optimize_batch_from_dev)
-            bpm.optimize_dev(g3, bt["x"], bt["head"], bt["tail"], bt["costs"], bt["last"], bt["nit"], bt["nfev"],
-                             bt["status"], slots=slots, x0=bt["x0"])
-            if use_dist:
-                # results to every rank: final x, total cost, 4 cost terms (SURVEY.md 8.e1).  The gather runs
-                # behind the batch on the process group's own stream; this batch's stream does not wait for it
-                # (the fence at the end of the timed region does), only the batch's next use of its buffers does.
-                if bt.get("work") is not None:
-                    bt["work"].wait()
-                bt["packed"] = sharding.pack_results(bt["x"], bt["costs"], w)
-                _, bt["work"] = sharding.gather_results(bt["packed"], world, out=bt["gathered"], force=use_dist,
-                                                        async_op=True)
-
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist_.barrier()
-        torch.cuda.synchronize()
-
-    esz = 4 if store == "f32" else 2
-
-    def time_mode(mode):
-        """W warm-up steps, then exactly K timed steps of the hot path in arithmetic mode `mode`, fenced by a barrier
-        and a device synchronisation on both sides; returns the timing and what the launches of the last step left"""
-        bpm = bp if mode == a.dtype else planner_for(mode)
-        bpm._sync()
-        fence()
-        for k in range(a.warmup):
-            for bt in batches:
-                launch(bt, bpm)
-        fence()
-        ctx.check(ctx.lib.neo_profile_reset(ctx.h))
-        ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
-        t0 = time.perf_counter()
-        for k in range(a.steps):
-            for bt in batches:
-                launch(bt, bpm)
-        fence()
-        el = time.perf_counter() - t0
-        ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
-        ctx.set_stream(None)
-        launches = ctypes.c_int64()
-        kms = ctypes.c_double()
-        ctx.check(ctx.lib.neo_profile_read(ctx.h, _lib.NEO_KERNEL_OPTIMIZE, ctypes.byref(launches), ctypes.byref(kms)))
-        # one launch ALONE on the chip (outside the timed region): what a caller with a single request batch gets -- with
-        # `--streams` launches in flight each one lasts longer than it would by itself
-        solo = None
-        if rank == 0 and not use_dist:
-            ctx.check(ctx.lib.neo_profile_reset(ctx.h))
-            ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
-            for _ in range(3):
-                launch(batches[0], bpm)
-                fence()
-            ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
-            ctx.set_stream(None)
-            l_s = ctypes.c_int64(); m_s = ctypes.c_double()
-            ctx.check(ctx.lib.neo_profile_read(ctx.h, _lib.NEO_KERNEL_OPTIMIZE, ctypes.byref(l_s), ctypes.byref(m_s)))
-            solo = m_s.value / max(l_s.value, 1)
-        nfev_all = torch.stack([bt["nfev"] for bt in batches]).cpu().numpy().astype(np.int64)
-        nsamp_all = torch.stack([bt["nsamp"] for bt in batches]).cpu().numpy()
-        status_all = torch.stack([bt["status"] for bt in batches]).cpu().numpy()
-        # results the reference accepts: L-BFGS-B ended on its own (converged / abnormal line search: SciPy returns
-        # either without raising) and the weighted collision cost is within tolerance (expert_planner.py:235-237)
-        accepted = ((status_all & 0xff) <= 2) & ((status_all & 0x100) == 0)
-        kernel_ms = kms.value / max(launches.value, 1)
-        # algorithmic bytes of ONE launch, mean over the step's batches (SURVEY.md 8.d2): S*C*e per evaluation + 2*n*4 + 20
-        bytes_launch = (float(nsamp_all.sum()) * 8 * esz + float(nfev_all.sum()) * (2 * n * 4 + 20)) / n_sets
-        b0_ = batches[0]
-        return dict(mode=mode, elapsed=el, kernel_ms=kernel_ms, launches=int(launches.value), nfev_all=nfev_all, solo_ms=solo,
-                    nsamp_all=nsamp_all, status_all=status_all, accepted_frac=float(accepted.mean()),
-                    bytes_launch=bytes_launch, mean_nit=float(b0_["nit"].float().mean().item()),
-                    b0=dict(x=b0_["x"].clone(), last=b0_["last"].clone(), nfev=b0_["nfev"].clone()))
+    R = Rank(a, rank, local_rank, world, use_dist)
+    torch, dist_ = R.torch, R.dist
+    B, M, D, n, n_sets = R.B, R.M, R.D, R.n, R.n_sets
+    report = None
+    if rank == 0 and not a.no_report:
+        import bench_report as report
+    esdf_build = R.esdf_build_time() if (rank == 0 and world == 1) else None
 
     t_gpu0 = time.time()
-    main_run = time_mode(a.dtype)
+    main_run = R.time_mode(a.dtype)
     elapsed = main_run["elapsed"]
     rank_rate = B * n_sets * a.steps / elapsed
-    rccl_ranks, per_rank = None, None
-    gather_ok = None
+    rccl_ranks, per_rank, gather_ok = None, None, None
     if use_dist:
-        cdev = dev if a.dist_backend == "nccl" else torch.device("cpu")     # (gloo: small host tensors)
+        cdev = R.dev if a.dist_backend == "nccl" else torch.device("cpu")     # (gloo: small host tensors)
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist_.all_reduce(tmax, op=dist_.ReduceOp.MAX)
         rates = torch.zeros(world, dtype=torch.float64, device=cdev)
@@ -704,318 +744,29 @@ def main():
         elapsed = float(tmax.item())
         rccl_ranks = dist_.get_world_size()
         # the gathered rows are the ranks' rows: this rank's slice bit for bit, every rank's slice by its checksum
-        for bt in batches:
+        for bt in R.batches:
             if bt.get("work") is not None:
                 bt["work"].wait()
         torch.cuda.synchronize()
-        bt = batches[-1]
+        bt = R.batches[-1]
         mine = bt["gathered"][rank * B:(rank + 1) * B]
         sums = torch.zeros(world, dtype=torch.float64, device=cdev)
         dist_.all_gather_into_tensor(sums, bt["packed"].double().nan_to_num().sum().reshape(1).to(cdev))
         got = torch.stack([bt["gathered"][r_ * B:(r_ + 1) * B].double().nan_to_num().sum() for r_ in range(world)]).to(cdev)
         gather_ok = bool(torch.equal(mine.view(torch.int32), bt["packed"].view(torch.int32)) and torch.equal(got, sums))
     mode_runs = {a.dtype: main_run}
-    solo_ms = main_run["solo_ms"]
     for m_ in modes[1:]:
-        mode_runs[m_] = time_mode(m_)
-    bp._sync()
-
-    # ---- the reference's ACCEPTED result is warm_start_plan's: up to five plan_once attempts, the failed ones re-seeded
-    # with N(0, 0.5) jitter (expert_planner.py:186-203); `value` counts first attempts.  Here the whole chain is timed
-    # under the same protocol, as BatchPlanner.plan runs it on the requests of a step: the first launches of the step's
-    # batches, then ONE compacted re-launch per attempt of every request that failed so far.  Which requests fail, and
-    # their re-seeded guesses, are found in an untimed pass (a caller learns them from the status arrays between
-    # attempts); the timed region replays every launch of the chain, first attempts included, and an attempt's launch
-    # waits for every launch of the attempt before it (stream events), as it would for the statuses.
-    retries = None
-    if rank == 0 and not use_dist and a.config == "cfg2" and init is None and n_scenes == 1 and not a.no_retries:
-        bp._sync()
-        fence()
-        failed_of = lambda st_: ((st_ & 0xff) > 3) | ((st_ & 0x100) != 0)
-        t_prep = time.time()
-        for bt in batches:
-            launch(bt, bp)
-        fence()
-        head_all = np.concatenate([st_[0] for st_ in sets]); tail_all = np.concatenate([st_[1] for st_ in sets])
-        n_req = B * n_sets
-        todo = np.flatnonzero(failed_of(torch.stack([bt["status"] for bt in batches]).cpu().numpy().reshape(-1)))
-        attempts = np.ones(n_req, dtype=np.int64)
-        chain = []
-        for att in range(1, 5):
-            if todo.size == 0:
-                break
-            wp_n, ts_n = bp.init_guess(head_all[todo], tail_all[todo], M - 1)
-            noise = np.stack([np.random.default_rng([20260, int(i), att]).normal(0.0, 0.5, (D, M - 1)) for i in todo])
-            nb_ = int(todo.size)
-            st_ = streams[att % n_lanes]
-            with torch.cuda.stream(st_):
-                e_ = dict(B=nb_, st=st_, x0=torch.from_numpy(bp.pack_x(wp_n + noise, ts_n)).to(dev),
-                          head=torch.from_numpy(np.ascontiguousarray(head_all[todo])).to(dev),
-                          tail=torch.from_numpy(np.ascontiguousarray(tail_all[todo])).to(dev),
-                          costs=torch.zeros(nb_, 4, dtype=torch.float64, device=dev), last=torch.zeros(nb_, 4, dtype=torch.float64, device=dev),
-                          nit=torch.zeros(nb_, dtype=torch.int32, device=dev), nfev=torch.zeros(nb_, dtype=torch.int32, device=dev),
-                          status=torch.zeros(nb_, dtype=torch.int32, device=dev), nsamp=torch.zeros(nb_, dtype=torch.int64, device=dev),
-                          order=torch.from_numpy(bp.expected_effort_order(head_all[todo], tail_all[todo], ts_n)).to(dev))
-                e_["x"] = torch.empty_like(e_["x0"])
-            chain.append(e_)
-
-            def launch_retry(e_):
-                ctx.set_stream(e_["st"].cuda_stream)
-                ctx.check(ctx.lib.neo_optimize_sample_counter(ctx.h, ctypes.c_void_p(e_["nsamp"].data_ptr())))
-                ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, ctypes.c_void_p(e_["order"].data_ptr()), e_["B"]))
-                with torch.cuda.stream(e_["st"]):
-                    bp.optimize_dev(g3, e_["x"], e_["head"], e_["tail"], e_["costs"], e_["last"], e_["nit"], e_["nfev"],
-                                    e_["status"], x0=e_["x0"])
-            launch_retry(e_)
-            st_.synchronize()
-            attempts[todo] += 1
-            todo = todo[failed_of(e_["status"].cpu().numpy())]
-        solved_total = n_req - int(todo.size)
-        prep_s = time.time() - t_prep
-
-        def chain_step():
-            for bt in batches:
-                launch(bt, bp)
-            done_prev = []
-            for st_ in streams:                      # attempt 2 needs the statuses of every first launch
-                ev_ = torch.cuda.Event(); ev_.record(st_); done_prev.append(ev_)
-            for e_ in chain:
-                for ev_ in done_prev:
-                    e_["st"].wait_event(ev_)
-                launch_retry(e_)
-                ev_ = torch.cuda.Event(); ev_.record(e_["st"]); done_prev = [ev_]
-        fence()
-        chain_step()
-        fence()
-        k_steps = max(2, a.steps // 4)
-        t0 = time.perf_counter()
-        for _ in range(k_steps):
-            chain_step()
-        fence()
-        el_r = time.perf_counter() - t0
-        ctx.set_stream(None)
-        retries = {"what": "warm_start_plan for every request of a step (expert_planner.py:186-203; BatchPlanner.plan's chain): the first "
-                           "launch of every batch, then ONE compacted re-launch per attempt of the requests that failed so far "
-                           "(OverflowError statuses or `collision cost too large`), re-seeded straight line + N(0, 0.5), at most 5 "
-                           f"attempts; every launch of the chain inside the timed region, {n_lanes} batches in flight, an attempt waits "
-                           "for the attempt before it; the failed sets and their re-seeded guesses come from an untimed pass",
-                   "max_attempts": 5, "steps": k_steps, "ms_per_step": 1e3 * el_r / k_steps,
-                   "requests_per_s": n_req * k_steps / el_r,
-                   "accepted_after_retries_traj_per_s": solved_total * k_steps / el_r,
-                   "accepted_frac_first_attempt": main_run["accepted_frac"], "accepted_frac_after_retries": solved_total / n_req,
-                   "mean_attempts": float(attempts.sum()) / n_req, "launches_per_step": n_sets + len(chain),
-                   "retry_launch_sizes": [int(e_["B"]) for e_ in chain],
-                   "retry_trajectories_per_step": int(sum(e_["B"] for e_ in chain)), "untimed_preparation_s": prep_s}
-    kernel_ms = main_run["kernel_ms"]
-    launches = ctypes.c_int64(main_run["launches"])
-    pp = lambda t: ctypes.c_void_p(t.data_ptr())
-
-    # ---- the ESDF-lookup kernel on its own (outside the timed region): add_sampled_cost +
-    # add_sampled_grad_CT for batch 0 at the initial guess, coefficients resident in HBM
-    esdf = None
-    if rank == 0 and n_scenes == 1:
-        coeffs = torch.zeros(B, 6 * M, D, dtype=torch.float64, device=dev)
-        cost1 = torch.zeros(B, dtype=torch.float64, device=dev)
-        c4 = torch.zeros(B, 4, dtype=torch.float64, device=dev)
-        grad1 = torch.zeros(B, n, dtype=torch.float64, device=dev)
-        st1 = torch.zeros(B, dtype=torch.int32, device=dev)
-        ctx.check(ctx.lib.neo_cost_grad_batch_dev(ctx.h, g3.scene_id, B, M, D, pp(b0["x0"]), pp(b0["head"]), pp(b0["tail"]),
-                                                  pp(cost1), pp(c4), pp(grad1), pp(coeffs), pp(st1)))
-        ns_piece = np.floor(ts / bp.cfg.delta_t).astype(np.int64)
-        n_samples = int(ns_piece.sum())
-        esz = 4 if store == "f32" else 2
-        # S * C * e + 2 n 4 + 20 bytes per evaluation (C = 8 corners of e bytes)
-        by_8d2 = n_samples * 8.0 * esz + B * (2 * n * 4 + 20)
-        # ... or with what this stand-alone kernel really moves besides the field: fp64 coefficients in, their
-        # partials out, durations in / partials out, 2 cost terms
-        by_ops = n_samples * 8.0 * esz + B * (2 * 6 * M * D * 8 + 2 * M * 8 + 16)
-        # footprint of the field: distinct 128-byte lines the launch's lookups touch (linear voxel order)
-        cf = coeffs.cpu().numpy().reshape(B, M, 6, D)
-        jmax = int(ns_piece.max())
-        tj = (np.arange(jmax) * bp.cfg.delta_t)[None, None, :]                                   # [1,1,J]
-        pw = np.stack([tj ** k for k in range(6)], axis=-1)                                       # [1,1,J,6]
-        pos = np.einsum("bmkd,xyjk->bmjd", cf, pw)                                                # [B,M,J,D]
-        valid = np.arange(jmax)[None, None, :] < ns_piece[:, :, None]
-        u = (pos[valid] - np.asarray(synth.DOMAIN_ORIGIN)) / res - 0.5
-        inside = ((u >= -0.5) & (u < a.grid - 0.5)).all(axis=1)
-        i0 = np.clip(np.floor(u[inside]).astype(np.int64), 0, a.grid - 2)
-        ids = []
-        for dz in (0, 1):
-            for dy in (0, 1):
-                for dx in (0, 1):
-                    ids.append((((i0[:, 2] + dz) * a.grid + i0[:, 1] + dy) * a.grid + i0[:, 0] + dx) * esz // 128)
-        footprint = int(np.unique(np.concatenate(ids)).size) * 128
-        l2 = ctypes.c_int64(); m2 = ctypes.c_double()
-        whole = n_sets > 1 and init is None
-        coeffs_a = d_ts_a = None
-        if whole:
-            Ba = B * n_sets
-            coeffs_a = torch.zeros(Ba, 6 * M, D, dtype=torch.float64, device=dev)
-            for r_, bt in enumerate(batches):
-                ctx.check(ctx.lib.neo_cost_grad_batch_dev(ctx.h, g3.scene_id, B, M, D, pp(bt["x0"]), pp(bt["head"]),
-                                                          pp(bt["tail"]), pp(cost1), pp(c4), pp(grad1),
-                                                          pp(coeffs_a[r_ * B:(r_ + 1) * B]), pp(st1)))
-            ts_a = np.ascontiguousarray(np.concatenate([st_[3] for st_ in sets], axis=0))
-            head_a = np.concatenate([st_[0] for st_ in sets]); tail_a = np.concatenate([st_[1] for st_ in sets])
-            d_ts_a = torch.from_numpy(ts_a).to(dev)
-            ns_a = int(np.floor(ts_a / bp.cfg.delta_t).astype(np.int64).sum())
-            by_a = ns_a * 8.0 * esz + Ba * (2 * n * 4 + 20)
-        d_ts = torch.from_numpy(np.ascontiguousarray(ts)).to(dev)
-
-        def time_sample(scene, nb, co, dts, order_np, reps):
-            """mean launch duration (HIP events on the kernel's stream) of sample_kernel over nb trajectories"""
-            c2 = torch.zeros(nb, 2, dtype=torch.float64, device=dev)
-            gC = torch.zeros(nb, 6 * M, D, dtype=torch.float64, device=dev)
-            gT = torch.zeros(nb, M, dtype=torch.float64, device=dev)
-            od = torch.from_numpy(order_np).to(dev) if order_np is not None else None
-            ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, pp(od) if od is not None else None, nb))
-            run = lambda: ctx.check(ctx.lib.neo_sampled_terms_batch_dev(ctx.h, scene, nb, M, D, pp(co), pp(dts), pp(c2), pp(gC), pp(gT)))
-            for _ in range(3):
-                run()
-            torch.cuda.synchronize()
-            ctx.check(ctx.lib.neo_profile_reset(ctx.h))
-            ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
-            for _ in range(reps):
-                run()
-            torch.cuda.synchronize()
-            ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
-            ctx.check(ctx.lib.neo_profile_read(ctx.h, _lib.NEO_KERNEL_ESDF_SAMPLE, ctypes.byref(l2), ctypes.byref(m2)))
-            ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, None, 0))
-            return 1e3 * m2.value / max(l2.value, 1), int(l2.value), (c2, gC, gT)
-
-        def esdf_block(scene, layout_name, default_wl):
-            """the ESDF-lookup kernel on one field: the 4096-trajectory launch and the launch over every request batch of a
-            step, in the chosen dispatch order, the other order timed beside it (same bits either way: checked)"""
-            orders = {"index": None, "spatial": npa.BatchPlanner.spatial_order(head, tail)}
-            other = "index" if a.esdf_order == "spatial" else "spatial"
-            us, nl, out_main = time_sample(scene, B, coeffs, d_ts, orders[a.esdf_order], 50)
-            us_o, _, out_o = time_sample(scene, B, coeffs, d_ts, orders[other], 20)
-            same = all(torch.equal(x_, y_) for x_, y_ in zip(out_main, out_o))
-            pm_s, src_s = pmc_profile(f"sample_kernel@{B}", default_wl)
-            e = {"kernel": "sample_kernel", "layout": layout_name, "dispatch_order": a.esdf_order, "bound": "hbm",
-                 "achieved": by_8d2 / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
-                 "unit": "GB/s", "frac": by_8d2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                 "frac_8d2": by_8d2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                 "frac_with_operands": by_ops / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                 "kernel_us": us, "launches": nl, f"kernel_us_{other}_order": us_o, "orders_give_the_same_bits": bool(same),
-                 "samples_per_launch": n_samples,
-                 "algorithmic_bytes_per_launch": by_8d2, "bytes_per_launch_with_operands": by_ops,
-                 "lookups_per_s": n_samples / (us * 1e-6),
-                 "esdf_footprint_bytes": footprint, "esdf_bytes": a.grid ** 3 * esz,
-                 "traffic": hbm_traffic(pm_s), "l2_hit_rate": l2_hit(pm_s), "traffic_source": src_s, "traffic_rule": traffic_rule(pm_s)}
-            if e["traffic"]:
-                # the kernel against what it really moves: 128-byte lines for 32-byte lookups
-                e["traffic_GBps"] = e["traffic"] / (us * 1e-6) / 1e9
-                e["traffic_over_algorithmic"] = e["traffic"] / by_8d2
-                e["frac_traffic_of_hbm_peak"] = e["traffic_GBps"] / HBM_PEAK_GBPS
-                e["frac_traffic_of_gather_roofline"] = e["traffic_GBps"] / GATHER_LINE_ROOFLINE_GBPS
-                e["gather_roofline"] = {"GBps_of_128B_lines": GATHER_LINE_ROOFLINE_GBPS, "source": "profiles/r03_gather_calib.json",
-                                        "what": "random 32-byte lookups (two adjacent 16-byte loads per lane) over a 432 MB buffer, "
-                                                "the rate the chip sustains for this access shape"}
-                lines = pm_s.get("TCC_EA0_RDREQ_128B_sum") or (pm_s.get("FETCH_SIZE", 0) * 1024.0 * 2 / 128)
-                e["lookups_per_fetched_line"] = n_samples / max(lines, 1.0)
-            # the same kernel over ALL request batches of a step in one launch (n_sets * B trajectories): with more
-            # wavefronts than the chip holds at once the launch is bound by throughput, not by the run time of one wavefront
-            if whole:
-                orders_a = {"index": None, "spatial": npa.BatchPlanner.spatial_order(head_a, tail_a)}
-                us_a, nl_a, _ = time_sample(scene, Ba, coeffs_a, d_ts_a, orders_a[a.esdf_order], 20)
-                us_ao, _, _ = time_sample(scene, Ba, coeffs_a, d_ts_a, orders_a[other], 8)
-                w_ = {"trajectories": Ba, "kernel_us": us_a, "launches": nl_a, f"kernel_us_{other}_order": us_ao,
-                      "dispatch_order": a.esdf_order, "samples_per_launch": ns_a, "algorithmic_bytes_per_launch": by_a,
-                      "achieved": by_a / (us_a * 1e-6) / 1e9, "frac_8d2": by_a / (us_a * 1e-6) / 1e9 / HBM_PEAK_GBPS}
-                pm_a, src_a = pmc_profile(f"sample_kernel@{Ba}", default_wl)
-                if pm_a and (src_a != src_s or pm_a != pm_s):
-                    tr_a = hbm_traffic(pm_a)
-                    w_.update(traffic=tr_a, l2_hit_rate=l2_hit(pm_a), traffic_source=src_a, traffic_rule=traffic_rule(pm_a))
-                    if tr_a:
-                        lines_a = pm_a.get("TCC_EA0_RDREQ_128B_sum") or (pm_a.get("FETCH_SIZE", 0) * 1024.0 * 2 / 128)
-                        w_.update(traffic_GBps=tr_a / (us_a * 1e-6) / 1e9, traffic_over_algorithmic=tr_a / by_a,
-                                  lookups_per_fetched_line=ns_a / max(lines_a, 1.0),
-                                  frac_traffic_of_hbm_peak=tr_a / (us_a * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                                  frac_traffic_of_gather_roofline=tr_a / (us_a * 1e-6) / 1e9 / GATHER_LINE_ROOFLINE_GBPS)
-                e["whole_step_launch"] = w_
-            return e
-
-        esdf = esdf_block(g3.scene_id, a.layout, default_workload)
-        if a.layout != "brick" and a.config in ("cfg2", "cfg5") and not a.planar:
-            # the same launches on the corner-brick layout of the same field (NEO_LAYOUT_BRICK: a 128-byte line per block of
-            # 2 x 2 x 2 cells): fewer lines per path -- counters: profiles/r04_*_pmc_esdf_locality_*.json
-            d_occ2 = torch.from_numpy(occ).to(dev)
-            gb = npa.ESDF3D.from_occupancy(d_occ2, res, synth.DOMAIN_ORIGIN, store=store, layout="brick", ctx=ctx)
-            del d_occ2
-            eb = esdf_block(gb.scene_id, "brick", False)
-            esdf["brick_layout"] = {k: eb[k] for k in ("layout", "dispatch_order", "kernel_us", "frac_8d2", "frac_with_operands",
-                                                       "lookups_per_s", "orders_give_the_same_bits") if k in eb}
-            esdf["brick_layout"].update({k: v for k, v in eb.items() if k.startswith("kernel_us_")})
-            if "whole_step_launch" in eb:
-                esdf["brick_layout"]["whole_step_launch"] = {k: v for k, v in eb["whole_step_launch"].items()
-                                                             if k in ("trajectories", "kernel_us", "frac_8d2", "dispatch_order")
-                                                             or k.startswith("kernel_us_")}
-            ctx.check(ctx.lib.neo_esdf_drop(ctx.h, gb.scene_id))
-            bp._sync()
-    nfev_all, nsamp_all, status_all = main_run["nfev_all"], main_run["nsamp_all"], main_run["status_all"]
-    status_h = status_all[0]
-    bytes_launch = main_run["bytes_launch"]
-    achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
-    value = world * rank_rate if not use_dist else world * B * n_sets * a.steps / elapsed
-    pm_o, src_o = pmc_profile(f"optimize_kernel@{B}", default_workload)
-
-    def mode_line(r_):
-        """one arithmetic mode under the bench protocol (this rank; with N ranks `value` above is the job's)"""
-        v_ = B * n_sets * a.steps / r_["elapsed"]
-        ach = r_["bytes_launch"] / (r_["kernel_ms"] * 1e-3) / 1e9
-        return {"value": v_, "unit": "traj/s", "ms_per_step": 1e3 * r_["elapsed"] / a.steps,
-                "accepted_frac": r_["accepted_frac"], "accepted_traj_per_s": v_ * r_["accepted_frac"],
-                "single_batch_ms": r_["solo_ms"],
-                "single_batch_traj_per_s": (B / (r_["solo_ms"] * 1e-3)) if r_["solo_ms"] else None,
-                "kernel_ms": r_["kernel_ms"], "roofline_frac": ach / HBM_PEAK_GBPS,
-                "roofline_frac_aggregate": r_["bytes_launch"] * n_sets * a.steps / r_["elapsed"] / 1e9 / HBM_PEAK_GBPS,
-                "mean_nfev": float(r_["nfev_all"].mean()), "max_nfev": int(r_["nfev_all"].max()),
-                "status_hist": np.bincount(r_["status_all"].reshape(-1) & 0xff, minlength=7).tolist(),
-                "sampling_arithmetic": "f64" if r_["mode"] == "f64" else "f32",
-                "solve_and_optimiser_arithmetic": "f32" if r_["mode"] == "f32x" else "f64"}
-
-    # ---- cfg1 (BASELINE.json configs[0]): ONE plan() of the reference's own shape through the reference-shaped API
-    cfg1 = None
-    if rank == 0 and world == 1 and a.config == "cfg2":
-        import contextlib
-        import io
-        occ2 = synth.occupancy_2d(3)
-        m2 = npa.ESDF(ctx=ctx)
-        m2.occupancy_map_cb(synth.OccupancyGridMsg(occ2))
-        h2 = np.array([[0.0, 0.0], [0.0, 0.0]]); t2 = np.array([[5.0, 0.3], [0.8, 0.0]])
-        pl1 = npa.MinJerkPlanner(npa.PlannerConfig(), ctx=ctx)
-        with contextlib.redirect_stdout(io.StringIO()):
-            pl1.plan(m2, h2, t2)
-            t1 = time.perf_counter()
-            for _ in range(20):
-                pl1.plan(m2, h2, t2)
-            plan_ms = 1e3 * (time.perf_counter() - t1) / 20
-            t1 = time.perf_counter()
-            for _ in range(20):
-                pl1.batch_plan(m2, h2, t2)
-            batch_plan_ms = 1e3 * (time.perf_counter() - t1) / 20
-        # ... and that shape in batches: 8192 M = 3 replans of the 2-D map per launch, fp64, default kernel and lane groups
-        hb, tb, wb, tsb = synth.replan_requests(5, 8192, 2, D=2, length_range=(4.0, 6.0), jitter=0.3)
-        batch_rate = {}
-        for name_, lg_ in (("default_kernel", False), ("lane_groups", True)):
-            bq = npa.BatchPlanner(ctx=ctx, sample_dtype="f64", lane_groups=lg_)
-            xq = bq.pack_x(wb, tsb)
-            bq.optimize(m2, xq, hb, tb)
-            t1 = time.perf_counter()
-            for _ in range(3):
-                rq = bq.optimize(m2, xq, hb, tb)
-            batch_rate[name_] = 3 * 8192 / (time.perf_counter() - t1)
-        cfg1 = {"what": "one plan() / batch_plan() call of the reference's shape: M = 3, D = 2, 300 x 300 nearest-cell map, fp64 "
-                        "(expert_planner.py:62-80, :142-168); scenario of tests/golden g3 / __graft_entry__.smoke()",
-                "plan_ms_gpu": plan_ms, "batch_plan_ms_gpu": batch_plan_ms, "plan_nfev": int(pl1.last_nfev),
-                "batched_replans_per_s_fp64_host_buffers": batch_rate,
-                "batched_note": "8192 replans of this shape per neo_optimize_batch call (host pointers in and out, PCIe "
-                                "included): one trajectory per wavefront / eight per wavefront (NEO_FLAG_LANE_GROUPS)",
-                "plan_final_cost_gpu": float(pl1.final_cost)}
-        bp._sync()
+        mode_runs[m_] = R.time_mode(m_)
+    R.bp._sync()
 
     if rank == 0:
+        solo_ms, kernel_ms, bytes_launch = main_run["solo_ms"], main_run["kernel_ms"], main_run["bytes_launch"]
+        nfev_all, nsamp_all, status_all = main_run["nfev_all"], main_run["nsamp_all"], main_run["status_all"]
+        achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
+        value = world * rank_rate if not use_dist else world * B * n_sets * a.steps / elapsed
+        kernel_name = ("optimize_group_kernel" if (a.lane_groups and M <= 16 and n <= 32 and a.layout != "cell8"
+                                                   and a.dtype in ("f32", "f32x")) else "optimize_kernel")
+        traffic = report.kernel_traffic(R, f"{kernel_name}@{B}") if report else {}
         out = {
             "metric": "trajectories/sec (batched replan)", "value": value, "unit": "traj/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
@@ -1025,137 +776,61 @@ def main():
             # what a caller with ONE request batch gets: a single launch of B trajectories alone on the chip (`value` keeps
             # `--streams` launches in flight and is the throughput figure)
             "single_batch_ms": solo_ms, "single_batch_traj_per_s": (B / (solo_ms * 1e-3)) if solo_ms else None,
-            "accepted_after_retries": retries,
-            "config": {"workload": f"{a.config}: request batches of B={B} trajectories x {M - 1} waypoints (M={M} pieces, D=3, "
-                                   f"n={n}), {n_sets} batch(es) per step per GPU, {n_scenes} x {a.grid}^3 {store} ESDF per GPU "
-                                   f"(trilinear, layout {a.layout}; " +
-                                   ("planar requests at z = 2 m" if a.planar else
-                                    f"pillars + {CANOPY} canopy boxes, requests filling the volume") +
-                                   "), each trajectory optimised to L-BFGS-B termination (maxcor 10, maxls 20, tol 1e-4)"
-                                   + ("; x0 from the initializer net (random weights) each launch" if init is not None else ""),
+            "config": {"workload": f"{a.config}: {n_sets} x {B} trajectories x {M - 1} waypoints per step per GPU, "
+                                   f"{R.n_scenes} x {a.grid}^3 {R.store} ESDF per GPU (trilinear, " +
+                                   ("planar requests" if a.planar else f"pillars + {CANOPY} canopy boxes") +
+                                   "), each optimised to L-BFGS-B termination"
+                                   + ("; x0 from the initializer net (random weights)" if R.init is not None else ""),
                        "batch_per_launch": B, "batches_per_step": n_sets, "trajectories_per_step_per_gpu": B * n_sets,
-                       "pieces": M, "dims": D, "esdf_voxels": a.grid ** 3,
+                       "pieces": M, "dims": D, "variables": n, "esdf_voxels": a.grid ** 3, "layout": a.layout,
+                       "lbfgsb": "maxcor 10, maxls 20, tol 1e-4 (expert_planner.py:213-225)",
                        "sampling_arithmetic": "f32" if a.dtype == "f32x" else a.dtype,
                        "solve_and_optimiser_arithmetic": "f32" if a.dtype == "f32x" else "f64",
                        "parallelism": f"scene-sharded x{world}",
-                       "launches_in_flight_per_gpu": n_lanes, "lane_groups": bool(a.lane_groups)},
+                       "launches_in_flight_per_gpu": R.n_lanes, "lane_groups": bool(a.lane_groups)},
             "rccl_ranks": rccl_ranks, "per_rank_traj_per_s": per_rank, "gather_ok": gather_ok,
             "dist_backend": (a.dist_backend if use_dist else None),
-            "scaling_efficiency_vs_rank_mean": (value / (world * float(np.mean(per_rank)))) if per_rank else None,
-            "roofline": {"bound": "hbm",
-                         "kernel": "optimize_group_kernel" if (a.lane_groups and M <= 16 and n <= 32 and a.layout != "cell8"
-                                                               and a.dtype in ("f32", "f32x")) else "optimize_kernel",
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": hbm_traffic(pm_o), "traffic_source": src_o, "traffic_rule": traffic_rule(pm_o),
-                         "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes of this "
-                                         "command (counter KB x 1024; the x 2 is MI355X_MICROARCH.md's gfx950 correction, confirmed "
-                                         "for these 16-byte-per-lane gathers against TCC_EA0_RDREQ_128B: profiles/r03_gather_calib.json)",
-                         "kernel_ms": kernel_ms, "launches": int(launches.value),
+            "roofline": {"bound": "hbm", "kernel": kernel_name,
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic.get("traffic"), "traffic_source": traffic.get("source"),
+                         "traffic_rule": traffic.get("rule"),
+                         "kernel_ms": kernel_ms, "launches": main_run["launches"],
                          # `achieved` follows the contract: bytes of one launch / its average duration (HIP events).
                          # With several launches in flight they overlap and each one lasts longer than it
                          # would alone; the chip-wide rate is all launches' bytes over the timed region:
-                         "concurrent_launches": n_lanes,
+                         "concurrent_launches": R.n_lanes,
                          "kernel_ms_one_launch_alone": solo_ms,
                          "frac_one_launch_alone": (bytes_launch / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if solo_ms else None,
                          "achieved_aggregate": bytes_launch * n_sets * a.steps / elapsed / 1e9,
                          "frac_aggregate": bytes_launch * n_sets * a.steps / elapsed / 1e9 / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "evals_per_launch": float(nfev_all.sum()) / n_sets, "samples_per_launch": float(nsamp_all.sum()) / n_sets},
-            "esdf_kernel": esdf, "esdf_build": esdf_build,
+            "esdf_build": esdf_build,
             "optimizer": {"mean_nfev": float(nfev_all.mean()), "max_nfev": int(nfev_all.max()),
                           "mean_nit": main_run["mean_nit"],
-                          "status_hist": np.bincount(status_h & 0xff, minlength=7).tolist(),
+                          "status_hist": np.bincount(status_all[0] & 0xff, minlength=7).tolist(),
                           "collision_flag_frac": float(((status_all & 0x100) != 0).mean())},
-            "modes": {m_: mode_line(r_) for m_, r_ in mode_runs.items()},
+            "modes": {m_: R.mode_line(r_) for m_, r_ in mode_runs.items()},
             "headline_mode": a.dtype,
-            "cfg1": cfg1,
             "timed_region_s": elapsed,
-            "setup_s": t_gpu0 - t_setup,
+            "setup_s": t_gpu0 - R.t_setup,
         }
-        if init is not None:
-            out["initializer"] = {"backbone_ms_per_scene": backbone_ms, "backbone_ms_first_call": backbone_ms_first,
-                                  "weights": "random (the reference's trained weights are not in its tree): parity unpinned"}
-        if want_cpu:
-            cpu_out, arr = run_cpu_leg(a, g3.dist, res, synth.DOMAIN_ORIGIN, head, tail, wp, ts)
+        if R.init_report:
+            out["initializer"] = R.init_report
+        cpu_out = arr = None
+        if R.want_cpu:
+            cpu_out, arr = run_cpu_leg(a, R.g3.dist, R.res, R.synth.DOMAIN_ORIGIN, *R.sets[0])
             out["cpu_baseline"] = cpu_out["cpu_baseline"]
             out["cpu_native"] = cpu_out["cpu_native"]
-            nq = D * (M - 1)
-
-            def delta(bt_x, bt_last, bt_nfev, idx, ref_cost, ref_nfev, ref_wp):
-                """GPU results of batch 0 against a CPU optimiser's on the trajectories `idx` (cost of the last
-                evaluated point, as the reference reports it, expert_planner.py:233; control points = max |dx| / max |x|)"""
-                good = np.isfinite(ref_cost)
-                lc = (bt_last * w).sum(dim=1).cpu().numpy()[idx][good]
-                rel = np.abs(lc - ref_cost[good]) / np.maximum(np.abs(ref_cost[good]), 1e-12)
-                same = bt_nfev.cpu().numpy()[idx][good] == ref_nfev[good]
-                gw = bt_x[:, :nq].cpu().numpy()[idx][good]
-                dx = np.abs(gw - ref_wp[good]).max(axis=1) / np.maximum(np.abs(ref_wp[good]).max(axis=1), 1e-12)
-                return {"n": int(good.sum()), "frac_same_nfev": float(same.mean()),
-                        "control_points_frac_within_1e_4": float((dx <= 1e-4).mean()),
-                        "control_points_rel_median": float(np.median(dx)),
-                        "control_points_rel_max_on_runs_with_same_nfev": float(dx[same].max()) if same.any() else None,
-                        "final_cost_frac_within_1e_4": float((rel <= 1e-4).mean()), "final_cost_rel_median": float(np.median(rel)),
-                        "final_cost_frac_within_1e_2": float((rel <= 1e-2).mean()),
-                        "gpu_median_cost": float(np.median(lc)), "cpu_median_cost": float(np.median(ref_cost[good]))}
-            par = {"tolerance": "north_star: final control points within 1e-4 relative of the CPU optimiser's"}
-            for m_, r_ in mode_runs.items():
-                rb = r_["b0"]
-                pm_ = {"vs_cpu_native": delta(rb["x"], rb["last"], rb["nfev"], arr["nat_idx"], arr["nat_cost"], arr["nat_nfev"],
-                                             arr["nat_wp"]),
-                       "vs_numpy_port": delta(rb["x"], rb["last"], rb["nfev"], arr["np_idx"], arr["np_cost"], arr["np_nfev"],
-                                              arr["np_wp"])}
-                out["modes"][m_]["parity"] = pm_
-                if m_ == a.dtype:
-                    par["gpu_timed_mode_vs_cpu_native"] = pm_["vs_cpu_native"]
-                    par["gpu_timed_mode_vs_numpy_port"] = pm_["vs_numpy_port"]
-            if cfg1 is not None and "cfg1" in cpu_out:
-                cfg1.update(cpu_out["cfg1"])
-            par["per_evaluation_and_decision_replay"] = (
-                "tests/test_gpu_replay.py: every point every run of a 256-trajectory cfg2 batch evaluates is re-evaluated by "
-                "the fp64 CPU oracle (value 4e-5 / gradient 2e-4 in the all-fp32 mode, 2e-5 / 2e-4 mixed, 1e-10 / 1e-8 fp64) "
-                "and every L-BFGS-B decision is re-derived on the host from the recorded values; profiles/r03_replay_*.json")
-            # the three modes against the REFERENCE-GENERATED fixtures on the reference's own 2-D map (tools/ref_fixture_parity.py;
-            # thresholds: tests/test_gpu_reference_fixtures.py): G6 = 256 plan_once runs of M = 21, share of finals within 1e-4
-            # of the real reference's, beside the reference under another BLAS kernel set against itself
-            try:
-                sys.path.insert(0, os.path.join(REPO, "tools"))
-                import ref_fixture_parity as rfp
-                g6 = rfp.g6_report()
-                g1 = rfp.g1_report()
-                g3 = rfp.g3_summary(rfp.g3_report())
-                keep = ("n", "finals_within_1e_4", "finals_within_1e_2", "cost_within_1e_4", "cost_within_1e_2", "same_nfev",
-                        "x_rel_median", "cost_rel_median", "mean_nfev", "same_exception", "exceptions", "exits")
-                par["vs_reference_fixtures"] = {
-                    "what": g6["what"],
-                    "g6_finals_within_1e_4_of_the_reference": {m_: v_["finals_within_1e_4"] for m_, v_ in g6["device_vs_reference"].items()},
-                    "g6_reference_vs_itself_other_blas_kernels": g6["reference_vs_itself"]["self_agreement_min"],
-                    "g6": {"reference_vs_itself": g6["reference_vs_itself"],
-                           "device_vs_reference": {m_: {k_: v_[k_] for k_ in keep if k_ in v_} for m_, v_ in g6["device_vs_reference"].items()}},
-                    "g1_per_evaluation": {m_: {k_: v_[k_] for k_ in ("n", "tolerance", "within_tolerance", "cost_max", "cost_median",
-                                                                      "grad_max", "grad_median", "coeffs_max")} for m_, v_ in g1.items()},
-                    "g1_note": "evaluations beyond a mode's tolerance sit at discontinuities of the reference objective (nearest-cell "
-                               "faces, int(T / delta_t)): tests/test_gpu_reference_fixtures.py holds each to the reference's own jump there",
-                    "g3_recorded_runs": g3}
-                bp._sync()
-            except Exception as ex:       # (fixtures missing in a stripped checkout: say so, do not fail the bench line)
-                par["vs_reference_fixtures"] = {"error": f"{type(ex).__name__}: {ex}"}
-            # exit statuses side by side: GPU modes (modes.*.status_hist), cpu_native, each control
-            par["exit_status_hist"] = {"order": "CONVERGED_GRAD, CONVERGED_F, ABNORMAL, MAXITER, NUMERIC_RANGE, NONFINITE, BAD_SCENE",
-                                       "gpu": {m_: np.bincount(r_["status_all"][0] & 0xff, minlength=7).tolist() for m_, r_ in mode_runs.items()},
-                                       "cpu_native": cpu_out["cpu_native"].get("status_hist"),
-                                       "controls": {k_: v_.get("status_hist") for k_, v_ in cpu_out["parity_control"].items()},
-                                       "note": "GPU rows: batch 0 of the timed run (4096 runs); cpu_native and controls: the runs of "
-                                               "batch 0 the CPU finished inside its time budget"}
-            par["control"] = cpu_out["parity_control"]
-            par["reading"] = ("the objective is discontinuous (int(T/dt) sample counts): two faithful CPU implementations "
-                              "part at the rates under `control`; the GPU rows are to be read against those, not against 1.0")
-            out["parity"] = par
+        if report:
+            report.extend(R, out, mode_runs, cpu_out, arr)
+        details = write_details(a, out)
         # RCCL prints a version banner through C stdio; push it out first so that the JSON is the last line
         try:
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        print(compact_line(out, details), flush=True)
     if use_dist:
         dist_.barrier()
         dist_.destroy_process_group()
