@@ -170,11 +170,15 @@ int neo_esdf_upload_3d(neo_ctx *ctx, int scene_id, const void *dist, int src_dty
  * Device memory: besides the stored field the build needs 10 bytes per voxel of intermediates (NEO_ERR_HIP if they do not
  * fit); they are kept in the context for the next build while they are at most 512 MB and released otherwise.
  * At most 4096 voxels per axis.  Volumes whose squared diagonal leaves room in 31 bits (all of BASELINE.json's) take a
- * faster form of the line passes and, for rows of 4-byte aligned length up to 1024, of the x pass; the environment
- * variable NEO_EDT_GENERIC=1 forces the general form (same results; the tests run both).  300^3 on one MI355X: 0.5 ms. */
+ * faster form of the line passes and, for rows of 4-byte aligned length up to 1024, of the x pass;
+ * neo_esdf_build_config(ctx, NEO_EDT_GENERIC_LINES) forces the general form (same results; the tests run both).
+ * 300^3 on one MI355X: 0.5 ms. */
 int neo_esdf_build_3d(neo_ctx *ctx, int scene_id, const uint8_t *occupancy, int occ_is_device, int nx,
                       int ny, int nz, double resolution, const double origin[3], int store_dtype,
                       int layout, float *out_dist);
+/* per-context switches of neo_esdf_build_3d (0 = defaults): comparison runs and tests */
+#define NEO_EDT_GENERIC_LINES 1 /* the general form of the y / z line passes for every volume */
+int neo_esdf_build_config(neo_ctx *ctx, int flags);
 int neo_esdf_drop(neo_ctx *ctx, int scene_id);
 /* point queries, replaces get_edt_dis / get_edt_grad called from Python
  * (astar_planner.py:134, traj_planner_node.py:474).  pts[n][D_map], grad[n][D_map]. */
@@ -276,13 +280,20 @@ int neo_optimize_trace_xg(neo_ctx *ctx, double *dev_xg, int cap);
  * putting the runs expected to be long first shortens the launch (a late long run is its tail);
  * NULL = identity; it must be a permutation of 0..B-1 and is ignored by launches of another batch size.
  * neo_planner_amd.BatchPlanner sorts by time slack (sum(ts) * v_max / distance).
- * neo_sampled_terms_batch_dev launches of exactly B trajectories honour the same permutation: there the lever is
- * locality -- workgroup i runs on XCD i mod 8, each XCD has its own L2, and BatchPlanner.spatial_order deals requests
- * that fly through the same part of the field to the same XCD. */
+ * LIFETIME: the array is the caller's and is read by every later neo_optimize_batch[_dev | _from_dev] launch of B
+ * trajectories on this context until another order (or NULL) is set: keep it allocated until those launches have
+ * completed.  Only the optimiser kernels read it. */
 int neo_optimize_dispatch_order(neo_ctx *ctx, const int32_t *dev_order, int B);
 /* the same from a HOST permutation (copied into a context-owned device buffer); NULL or B = 0 resets.
  * Either way the permutation only applies to launches of exactly B trajectories. */
 int neo_optimize_dispatch_order_host(neo_ctx *ctx, const int32_t *host_order, int B);
+/* the ESDF-lookup kernel's own permutation (neo_sampled_terms_batch[_dev] launches of exactly B trajectories; results stay
+ * in the caller's order, bit-identical): there the lever is locality -- workgroup i runs on XCD i mod 8, each XCD has its
+ * own L2, and BatchPlanner.spatial_order deals requests that fly through the same part of the field to the same XCD.
+ * `order` is a host (on_device = 0) or device (on_device = 1) array of B ints; it is COPIED into a context-owned buffer
+ * (stream-ordered), so the caller may free it after the call (a device array: once the context's stream has passed the
+ * copy).  NULL or B = 0 resets.  Independent of neo_optimize_dispatch_order. */
+int neo_sampled_terms_dispatch_order(neo_ctx *ctx, const int32_t *order, int on_device, int B);
 int neo_profile_read(neo_ctx *ctx, int kernel, int64_t *launches, double *total_ms);
 int neo_profile_reset(neo_ctx *ctx);
 

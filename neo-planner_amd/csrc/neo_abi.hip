@@ -982,6 +982,7 @@ int neo_ctx_destroy(neo_ctx *c) {
   for (auto &kv : c->maps)
     if (kv.second.data) hipFree(kv.second.data);
   if (c->order_buf) hipFree(c->order_buf);
+  if (c->sample_order) hipFree(c->sample_order);
   if (c->tickets) hipFree(c->tickets);
   if (c->table2d) hipFree(c->table2d);
   if (c->table3d) hipFree(c->table3d);
@@ -1297,9 +1298,8 @@ int neo_esdf_build_3d(neo_ctx *c, int scene_id, const uint8_t *occ, int occ_is_d
         const long long span = (diag2 + 2LL * nline * nline) << qb;
         return (span < (1LL << 31) && ((long long)nline << (qb + 1)) < (1LL << 23)) ? qb : 0;
       };
-      // (NEO_EDT_GENERIC=1 in the environment: the general form for every volume -- the tests run both)
-      const char *force_generic = getenv("NEO_EDT_GENERIC");
-      const bool generic = force_generic && force_generic[0] == '1';
+      // (neo_esdf_build_config(ctx, NEO_EDT_GENERIC_LINES): the general form for every volume -- the tests run both)
+      const bool generic = (c->edt_flags & NEO_EDT_GENERIC_LINES) != 0;
       const int qby = generic ? 0 : key_bits(ny), qbz = generic ? 0 : key_bits(nz);
       // pass Y: lines along y (stride nx) in every z slab; pass Z: lines along z (stride nx * ny) for every y row
       if (qby) {
@@ -1810,6 +1810,39 @@ int neo_optimize_dispatch_order_host(neo_ctx *c, const int32_t *host_order, int 
   HIPCHK(c, hipStreamSynchronize(c->stream));  // the host array may go away after the call
   c->dispatch_order = c->order_buf;
   c->order_B = B;
+  return NEO_OK;
+}
+
+int neo_sampled_terms_dispatch_order(neo_ctx *c, const int32_t *order, int on_device, int B) {
+  if (!c || B < 0) return NEO_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> g(c->mu);
+  hipSetDevice(c->device);
+  if (!order || B == 0) {
+    c->sample_order_B = 0;
+    return NEO_OK;
+  }
+  if ((size_t)B > c->sample_order_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (launches that read the old copy have finished)
+    if (c->sample_order) hipFree(c->sample_order);
+    c->sample_order = nullptr;
+    c->sample_order_cap = 0;
+    c->sample_order_B = 0;
+    HIPCHK(c, hipMalloc((void **)&c->sample_order, (size_t)B * sizeof(int)));
+    c->sample_order_cap = (size_t)B;
+  }
+  // stream-ordered copy into the context's own buffer: the caller's array may go away after the call (a host array once
+  // the synchronisation below has returned, a device array once the stream has passed this point)
+  HIPCHK(c, hipMemcpyAsync(c->sample_order, order, (size_t)B * sizeof(int),
+                           on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  if (!on_device) HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->sample_order_B = B;
+  return NEO_OK;
+}
+
+int neo_esdf_build_config(neo_ctx *c, int flags) {
+  if (!c || (flags & ~NEO_EDT_GENERIC_LINES)) return NEO_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> g(c->mu);
+  c->edt_flags = flags;
   return NEO_OK;
 }
 

@@ -1049,7 +1049,7 @@ __device__ __forceinline__ void thomas_solve(int M, const Num (&Lo)[2][2], const
 // In: L, Dg, U, R of joint p on the lanes of piece p (1 <= p <= M-1; boundary values already folded into R, L_1 = 0,
 // U_{M-1} = 0); other lanes are made identity rows here.  Out: y on those lanes.
 // `mult` (LDS, may be nullptr): when given, every level's multipliers a, g of every joint and the final pivot inverses are
-// written there -- [level][M][8] (negated) then [M][4] -- for pcr_solve_transposed: K^-1 = Dfin^-1 P_last ... P_1 with P_k = I + (a, g of
+// written there -- [level][M + 1][8] (negated) then [M + 1][4] -- for pcr_solve_transposed: K^-1 = Dfin^-1 P_last ... P_1 with P_k = I + (a, g of
 // level k), hence K^-T = P_1^T ... P_last^T Dfin^-T, and the adjoint system K^T lambda = r needs no reduction of its own.
 template <int DL, class LG, typename Num>
 __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2], Num (&U)[2][2], Num (&R)[2][DL],
@@ -1098,8 +1098,8 @@ __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2]
     // zero by then (L_i = 0 for i <= s, U_i = 0 for i + s >= M, by induction over the levels), and zero times a finite
     // value is the zero the clamped fetch gave.  The last level's L' and U' (zero up to rounding, never used) are formed
     // like the others: cheaper than the selects that kept them out.  Every lane stores its multipliers -- the lanes of a
-    // joint the same values to the same place, the lanes without a joint into slots nobody reads (piece 0, and the one slot past
-    // the level, which the next level's writes or pcr_mult_elems' slack cover).
+    // joint the same values to the same place, the lanes without a joint into slots nobody reads: piece 0, and slot M, which
+    // every level and the table of pivot inverses have for themselves (M + 1 slots each: pcr_mult_elems).
     const bool keep = mult != nullptr;
     const int ps = min(p, M);  // (store slot: every lane beyond the last piece shares the one past it)
     for (int s = 1; s < s_end; s <<= 1, ++level) {
@@ -1160,7 +1160,7 @@ __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2]
         pg[i] = fma2(Ur[i].xx, In[0], Ur[i].yy * In[1]);
       }
       if (keep) {
-        Quad *dst = reinterpret_cast<Quad *>(mult + ((size_t)level * M + ps) * 8);
+        Quad *dst = reinterpret_cast<Quad *>(mult + ((size_t)level * (M + 1) + ps) * 8);
         dst[0] = Quad{pa[0].x, pa[0].y, pa[1].x, pa[1].y};  // (stored negated: what sits in the registers)
         dst[1] = Quad{pg[0].x, pg[0].y, pg[1].x, pg[1].y};
       }
@@ -1179,7 +1179,7 @@ __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2]
     }
     invert();
     if (xch != nullptr) lds_wave_sync();  // (the exchange table is the caller's staging buffer again)
-    if (keep) *reinterpret_cast<Quad *>(mult + (size_t)level * M * 8 + (size_t)ps * 4) = Quad{Ir[0].x, Ir[0].y, Ir[1].x, Ir[1].y};
+    if (keep) *reinterpret_cast<Quad *>(mult + (size_t)level * (M + 1) * 8 + (size_t)ps * 4) = Quad{Ir[0].x, Ir[0].y, Ir[1].x, Ir[1].y};
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
       y[0][d] = fmaf(Ir[0].x, R[0][d], Ir[0].y * R[1][d]);
@@ -1233,7 +1233,7 @@ __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2]
         g[i][j] = -fma(U[i][0], In[0][j], U[i][1] * In[1][j]);
       }
     if (writer) {
-      Quad *dst = reinterpret_cast<Quad *>(mult + ((size_t)level * M + p) * 8);
+      Quad *dst = reinterpret_cast<Quad *>(mult + ((size_t)level * (M + 1) + p) * 8);
       // (stored NEGATED: a and g are formed as -(...), and the products themselves are what sits in registers)
       dst[0] = Quad{-a[0][0], -a[0][1], -a[1][0], -a[1][1]};
       dst[1] = Quad{-g[0][0], -g[0][1], -g[1][0], -g[1][1]};
@@ -1263,7 +1263,7 @@ __device__ __forceinline__ void pcr_solve(int M, Num (&L)[2][2], Num (&Dg)[2][2]
       }
   }
   invert();
-  if (writer) *reinterpret_cast<Quad *>(mult + (size_t)level * M * 8 + (size_t)p * 4) = Quad{I[0][0], I[0][1], I[1][0], I[1][1]};
+  if (writer) *reinterpret_cast<Quad *>(mult + (size_t)level * (M + 1) * 8 + (size_t)p * 4) = Quad{I[0][0], I[0][1], I[1][0], I[1][1]};
 #pragma unroll
   for (int d = 0; d < DL; ++d) {
     y[0][d] = fma(I[0][0], R[0][d], I[0][1] * R[1][d]);
@@ -1278,10 +1278,11 @@ __host__ __device__ __forceinline__ int pcr_levels(int M, bool f32 = true) {
   for (int s = 1; s < s_end; s <<= 1) ++n;
   return n;
 }
-// (+ 8: the lanes beyond the last piece write one slot past each region)
+// ([level][M + 1][8] multipliers, then [M + 1][4] pivot inverses: slot M of every region takes the stores of the lanes
+//  beyond the last piece, so no region's stores land in another one)
 // floats of LDS the exchange table of pcr_solve takes: I, L, U of pieces 0 .. M, then one pair per lane and held dimension
 __host__ __device__ __forceinline__ int pcr_xch_elems(int M, int DL) { return (M + 1) * 12 + kWave * 2 * DL; }
-__host__ __device__ __forceinline__ int pcr_mult_elems(int M) { return (pcr_levels(M) * 8 + 4) * M + 8; }
+__host__ __device__ __forceinline__ int pcr_mult_elems(int M) { return (pcr_levels(M) * 8 + 4) * (M + 1); }
 
 // The adjoint system K^T lambda = r from the multipliers pcr_solve left in `mult`:
 //     lambda = P_1^T ... P_last^T (Dfin^-T r),     (P_k^T w)_j = w_j + a_{j+s}^T w_{j+s} + g_{j-s}^T w_{j-s},   s = 2^k.
@@ -1300,7 +1301,7 @@ __device__ __forceinline__ void pcr_solve_transposed(int M, const Num *mult, con
   const int nlev = pcr_levels(M, sizeof(Num) == 4);
   Num w[2][DL];
   {
-    const Quad I = *reinterpret_cast<const Quad *>(mult + (size_t)nlev * M * 8 + (size_t)pj * 4);
+    const Quad I = *reinterpret_cast<const Quad *>(mult + (size_t)nlev * (M + 1) * 8 + (size_t)pj * 4);
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
       w[0][d] = in ? fma(I.x, R[0][d], I.z * R[1][d]) : Num(0.0);  // Dfin^-T r
@@ -1309,7 +1310,7 @@ __device__ __forceinline__ void pcr_solve_transposed(int M, const Num *mult, con
   }
   for (int k = nlev - 1; k >= 0; --k) {
     const int s = 1 << k;
-    const Quad *src = reinterpret_cast<const Quad *>(mult + ((size_t)k * M + pj) * 8);
+    const Quad *src = reinterpret_cast<const Quad *>(mult + ((size_t)k * (M + 1) + pj) * 8);
     const Quad a = src[0], g = src[1];
     const int ln = lane + s * LG::S, lp = lane - s * LG::S;
     const bool hn = ln < kWave, hp = lp >= 0;

@@ -68,6 +68,10 @@ struct neo_ctx {
   int trace_cap = 0;
   int *order_buf = nullptr;             // device copy of a host permutation (neo_optimize_dispatch_order_host)
   size_t order_cap = 0;
+  int *sample_order = nullptr;          // context-owned device copy of the ESDF-lookup kernel's permutation
+  size_t sample_order_cap = 0;          // (neo_sampled_terms_dispatch_order; never the optimiser's, never caller-owned)
+  int sample_order_B = 0;
+  int edt_flags = 0;                    // NEO_EDT_* (neo_esdf_build_config)
 };
 
 namespace neo {

@@ -16,6 +16,7 @@ LAYOUTS = {"linear": NEO_LAYOUT_LINEAR, "yz4": NEO_LAYOUT_YZ4, "cell8": NEO_LAYO
 NEO_TRAJ_CONVERGED_GRAD, NEO_TRAJ_CONVERGED_F, NEO_TRAJ_ABNORMAL = 0, 1, 2
 NEO_TRAJ_MAXITER, NEO_TRAJ_NUMERIC_RANGE, NEO_TRAJ_NONFINITE, NEO_TRAJ_BAD_SCENE = 3, 4, 5, 6
 NEO_TRAJ_FLAG_COLLISION = 0x100
+NEO_EDT_GENERIC_LINES = 1
 NEO_KERNEL_EVAL, NEO_KERNEL_OPTIMIZE, NEO_KERNEL_ESDF_BUILD, NEO_KERNEL_ESDF_SAMPLE = 0, 1, 2, 3
 NEO_FLAG_ONE_WAVE_PER_SIMD, NEO_FLAG_TWO_WAVES_PER_SIMD, NEO_FLAG_LANE_GROUPS = 32, 64, 128
 NEO_FLAG_F32_SOLVE = 2048
@@ -30,7 +31,8 @@ EXPORTS = [
     "neo_profile_reset", "neo_optimize_sample_counter", "neo_optimize_dispatch_order",
     "neo_sampled_terms_batch", "neo_sampled_terms_batch_dev", "neo_esdf_build_3d",
     "neo_optimize_dispatch_order_host", "neo_ctx_set_stream", "neo_optimize_trace",
-    "neo_optimize_batch_from_dev", "neo_optimize_trace_xg",
+    "neo_optimize_batch_from_dev", "neo_optimize_trace_xg", "neo_sampled_terms_dispatch_order",
+    "neo_esdf_build_config",
 ]
 
 
@@ -100,6 +102,8 @@ def load():
     L.neo_optimize_trace_xg.argtypes = [c_p, c_p, c_i]
     L.neo_optimize_dispatch_order.argtypes = [c_p, c_p, c_i]
     L.neo_optimize_dispatch_order_host.argtypes = [c_p, c_p, c_i]
+    L.neo_sampled_terms_dispatch_order.argtypes = [c_p, c_p, c_i, c_i]
+    L.neo_esdf_build_config.argtypes = [c_p, c_i]
     L.neo_sampled_terms_batch.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 5
     L.neo_sampled_terms_batch_dev.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 5
     for name in EXPORTS:

@@ -460,13 +460,17 @@ class BatchPlanner:
                                           _lib.ptr(st)))
         return dict(cost=cost, costs=costs, grad=grad, coeffs=coeffs, status=st)
 
-    def sampled_terms(self, map, coeffs, ts):
-        """add_sampled_cost + add_sampled_grad_CT (:392-466) for B trajectories: coeffs (B, 6M, D), ts (B, M)"""
+    def sampled_terms(self, map, coeffs, ts, order=None):
+        """add_sampled_cost + add_sampled_grad_CT (:392-466) for B trajectories: coeffs (B, 6M, D), ts (B, M).
+        `order`: optional permutation (B,) the ESDF-lookup kernel dispatches its workgroups in (`spatial_order`); the
+        results stay in the caller's order, bit-identical"""
         self._sync()
         c = self.ctx
         coeffs = _lib.as_f64(coeffs); ts = _lib.as_f64(ts)
         B, M = ts.shape
         D = coeffs.shape[2]
+        perm = None if order is None else np.ascontiguousarray(order, dtype=np.int32)
+        c.check(c.lib.neo_sampled_terms_dispatch_order(c.h, _lib.ptr(perm), 0, 0 if perm is None else B))
         costs2 = np.zeros((B, 2)); gC = np.zeros((B, 6 * M, D)); gT = np.zeros((B, M))
         c.check(c.lib.neo_sampled_terms_batch(c.h, map.scene_id, B, M, D, _lib.ptr(coeffs), _lib.ptr(ts),
                                               _lib.ptr(costs2), _lib.ptr(gC), _lib.ptr(gT)))
@@ -568,7 +572,7 @@ class BatchPlanner:
 
     @staticmethod
     def spatial_order(head, tail, xcds=8, cell=1.0, key=None, chunk=None):
-        """XCD-aware spatial dispatch order for the ESDF-lookup kernel (neo_optimize_dispatch_order): requests are keyed by
+        """XCD-aware spatial dispatch order for the ESDF-lookup kernel (neo_sampled_terms_dispatch_order): requests are keyed by
         a coarse Morton code of where they fly -- the midpoint of start and goal in cells of `cell` metres -- sorted, and
         the sorted list is dealt so that workgroups i, i + 8, i + 16, ... (one XCD: the hardware dispatches workgroups
         round-robin over the 8 XCDs, each with its own 4 MB L2) hold contiguous runs of it.  Requests whose

@@ -596,7 +596,7 @@ def test_dispatch_order_changes_nothing_but_the_order_of_execution():
                  rng.permutation(B).astype(np.int32)):
         assert sorted(perm.tolist()) == list(range(B))
         ctx.check(ctx.lib.neo_optimize_dispatch_order_host(ctx.h, _lib.ptr(np.ascontiguousarray(perm, dtype=np.int32)), B))
-        got = bp.sampled_terms(g3, e["coeffs"], ts)
+        got = bp.sampled_terms(g3, e["coeffs"], ts, order=perm)
         for k in ("costs2", "grad_C", "grad_T"):
             assert np.array_equal(got[k], ref_s[k]), k
         # (BatchPlanner.optimize installs its own order; drive the ABI directly to keep this one)
@@ -605,9 +605,26 @@ def test_dispatch_order_changes_nothing_but_the_order_of_execution():
         ctx.check(ctx.lib.neo_optimize_batch(ctx.h, g3.scene_id, None, B, M, D, _lib.ptr(x), _lib.ptr(head), _lib.ptr(tail), _lib.ptr(costs),
                                              _lib.ptr(last), _lib.ptr(nit), _lib.ptr(nfev), _lib.ptr(st)))
         assert np.array_equal(x, ref_o["x"]) and np.array_equal(nfev, ref_o["nfev"]) and np.array_equal(costs, ref_o["costs"])
-    # a permutation given for another batch size does not apply
-    got = bp.sampled_terms(g3, e["coeffs"][:500], ts[:500])
-    assert np.array_equal(got["grad_C"], ref_s["grad_C"][:500])
+    # a permutation given for another batch size does not apply; the ESDF-lookup kernel's order is the context's own copy
+    # (neo_sampled_terms_dispatch_order): a device array handed over may be freed right after the call
+    pd = torch.from_numpy(np.ascontiguousarray(perm, dtype=np.int32)).to(dev)
+    ctx.check(ctx.lib.neo_sampled_terms_dispatch_order(ctx.h, ctypes.c_void_p(pd.data_ptr()), 1, B))
+    pd.fill_(-1 << 20)       # (what a stale pointer would make the kernel index with)
+    del pd
+    ctx.synchronize()
+    coeffs_d = torch.from_numpy(e["coeffs"]).to(dev); ts_d = torch.from_numpy(np.ascontiguousarray(ts)).to(dev)
+    c2 = torch.zeros(B, 2, dtype=torch.float64, device=dev); gC = torch.zeros(B, 6 * M, D, dtype=torch.float64, device=dev)
+    gT = torch.zeros(B, M, dtype=torch.float64, device=dev)
+    pp = lambda t_: ctypes.c_void_p(t_.data_ptr())
+    ctx.check(ctx.lib.neo_sampled_terms_batch_dev(ctx.h, g3.scene_id, B, M, D, pp(coeffs_d), pp(ts_d), pp(c2), pp(gC), pp(gT)))
+    ctx.synchronize()
+    assert np.array_equal(gC.cpu().numpy(), ref_s["grad_C"]) and np.array_equal(c2.cpu().numpy(), ref_s["costs2"])
+    ctx.check(ctx.lib.neo_sampled_terms_dispatch_order(ctx.h, _lib.ptr(np.ascontiguousarray(perm, dtype=np.int32)), 0, B))
+    c2h = np.zeros((500, 2)); gCh = np.zeros((500, 6 * M, D)); gTh = np.zeros((500, M))
+    ctx.check(ctx.lib.neo_sampled_terms_batch(ctx.h, g3.scene_id, 500, M, D, _lib.ptr(np.ascontiguousarray(e["coeffs"][:500])),
+                                              _lib.ptr(np.ascontiguousarray(ts[:500])), _lib.ptr(c2h), _lib.ptr(gCh), _lib.ptr(gTh)))
+    assert np.array_equal(gCh, ref_s["grad_C"][:500])
+    ctx.check(ctx.lib.neo_sampled_terms_dispatch_order(ctx.h, None, 0, 0))
     ctx.check(ctx.lib.neo_optimize_dispatch_order_host(ctx.h, None, 0))
 
 

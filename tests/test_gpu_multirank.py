@@ -48,3 +48,23 @@ def test_cfg4_default_scene_count_matches_baseline_config():
     out = _bench(["--config", "cfg4", "--steps", "1", "--warmup", "1", "--no-cpu"])
     assert out["n_gpus"] == 1 and "32 x 300^3" in out["config"]["workload"]
     assert out["config"]["batch_per_launch"] == 32 * 4096 and out["value"] > 1e4
+
+
+def test_rccl_gather_behind_each_batch_with_one_rank():
+    """the process-group path on RCCL itself (backend "nccl"), as far as one GPU allows -- a one-rank
+    group (NEO_BENCH_FORCE_DIST=1): every batch's packed results go through an asynchronous all_gather_into_tensor on the
+    process group's stream behind the batch, the gathered rows are the rank's rows bit for bit, and the collective costs
+    the hot path next to nothing (it is off the critical path: DESIGN.md section 6)."""
+    args = ["--steps", "4", "--warmup", "2", "--no-cpu", "--no-report", "--no-modes"]
+    plain = _bench(args)
+    e = dict(os.environ)
+    os.environ["NEO_BENCH_FORCE_DIST"] = "1"
+    try:
+        dist = _bench(args + ["--dist-backend", "nccl"])
+    finally:
+        os.environ.clear()
+        os.environ.update(e)
+    assert "rccl_ranks" not in plain and "gather_ok" not in plain          # (no process group in the plain run)
+    assert dist["rccl_ranks"] == 1 and dist["dist_backend"] == "nccl" and dist["gather_ok"] is True
+    assert dist["n_gpus"] == 1 and dist["steps"] == 4
+    assert dist["value"] >= 0.95 * plain["value"], (dist["value"], plain["value"])

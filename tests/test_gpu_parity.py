@@ -22,7 +22,7 @@ from helpers import golden, load, rel_err
 pytestmark = pytest.mark.gpu
 
 import neo_planner_amd as npa
-from neo_planner_amd import synth
+from neo_planner_amd import _lib, synth
 from oracle import minco_np as onp
 
 
@@ -94,9 +94,9 @@ def test_esdf_build_3d_is_the_exact_edt(shape, seed):
         assert np.max(np.abs(dis - np.array([o3.lookup(p)[0] for p in pts]))) < 1e-12
 
 
-def test_esdf_build_3d_packed_key_and_general_line_passes_agree(monkeypatch):
+def test_esdf_build_3d_packed_key_and_general_line_passes_agree():
     """round 4: the y / z passes run on packed (cost, minimiser) keys where the volume's squared diagonal leaves room in 31
-    bits, and in the general form elsewhere (NEO_EDT_GENERIC=1 forces it); the x pass has a form with 8 / 16 voxels per
+    bits, and in the general form elsewhere (neo_esdf_build_config forces it); the x pass has a form with 8 / 16 voxels per
     lane for rows of 4-byte aligned length.  Every form against SciPy, on the shapes that take the fast forms by default."""
     from scipy import ndimage
     rng = np.random.default_rng(21)
@@ -108,11 +108,14 @@ def test_esdf_build_3d_packed_key_and_general_line_passes_agree(monkeypatch):
         occ[0] = 1
         occ[:, shape[1] // 2:, :] &= (rng.random((shape[0], shape[1] - shape[1] // 2, shape[2])) < 0.5)  # rows with nothing occupied
         want = (ndimage.distance_transform_edt(1 - occ) * 0.1).astype(np.float32)
-        for generic in ("0", "1"):
-            monkeypatch.setenv("NEO_EDT_GENERIC", generic)
-            g3 = npa.ESDF3D.from_occupancy(occ, 0.1, (0.0, 0.0, 0.0), layout="linear", want_dist=True)
-            assert np.array_equal(g3.dist, want), (shape, generic)
-    monkeypatch.delenv("NEO_EDT_GENERIC")
+        ctx = _lib.default_context()
+        try:
+            for generic in (0, _lib.NEO_EDT_GENERIC_LINES):
+                ctx.check(ctx.lib.neo_esdf_build_config(ctx.h, generic))
+                g3 = npa.ESDF3D.from_occupancy(occ, 0.1, (0.0, 0.0, 0.0), layout="linear", want_dist=True)
+                assert np.array_equal(g3.dist, want), (shape, generic)
+        finally:
+            ctx.check(ctx.lib.neo_esdf_build_config(ctx.h, 0))
 
 
 def test_esdf_build_3d_line_lengths_around_powers_of_two():
@@ -330,6 +333,47 @@ def test_sampled_terms_kernel_matches_oracle():
             assert rel_err(out["costs2"][0], pl.costs[2:]) < tol
             assert rel_err(out["grad_C"][0], pl.grad_C) < tol
             assert rel_err(out["grad_T"][0], pl.grad_T) < tol
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 7, 21, 41, 64])
+def test_flat_sample_sequence_on_ragged_durations(M):
+    """round 5: the fp32 ESDF-lookup kernel deals a trajectory's samples to the lanes as ONE sequence in contiguous blocks (a
+    lane crosses from a piece into the next).  Ragged durations: pieces shorter than delta_t (no sample at all), pieces
+    shorter than a block (several pieces inside one lane), one long piece among short ones, every piece alike -- against the
+    fp64 kernel (whole lanes per piece; pinned to the oracle above) on a continuous 3-D field, and bit-reproducible."""
+    import torch
+    rng = np.random.default_rng(500 + M)
+    dist = synth.esdf_3d(3, n=100, res=0.3, canopy=20)
+    g3 = npa.ESDF3D(dist, 0.3, synth.DOMAIN_ORIGIN, store="f32", layout="brick")
+    B, D = 48, 3
+    head, tail, wp, ts0 = synth.replan_requests(11, B, max(M - 1, 0), D=3, **synth.VOLUME) if M > 1 else (None,) * 4
+    if M == 1:
+        head = np.zeros((B, 3, 3)); tail = np.zeros((B, 3, 3))
+        head[:, 0] = rng.uniform([1, -10, 1], [5, 10, 20], (B, 3)); tail[:, 0] = head[:, 0] + rng.uniform(5, 12, (B, 3)) * [1, 0.3, 0.2]
+        wp = np.zeros((B, 3, 0)); ts0 = np.full((B, 1), 3.0)
+    bp64 = npa.BatchPlanner(sample_dtype="f64")
+    coeffs = bp64.cost_grad(g3, bp64.pack_x(wp, ts0), head, tail, want_coeffs=True)["coeffs"]
+    ts = rng.uniform(0.55, 4.8, (B, M))
+    ts[:8] = rng.uniform(0.02, 0.35, (8, M))                       # 0 .. 3 samples a piece
+    ts[8:16] = np.where(rng.random((8, M)) < 0.5, 0.05, ts[8:16])      # pieces without samples among ordinary ones
+    ts[16:24] = 0.12; ts[16:24, M // 2] = 4.7                          # one long piece among one-sample pieces
+    ts[24:28] = 2.5                                                    # every piece alike (a fresh guess)
+    ts[28] = 0.03                                                      # a trajectory without any sample
+    a = bp64.sampled_terms(g3, coeffs, ts)
+    bp32 = npa.BatchPlanner(sample_dtype="f32")
+    b = bp32.sampled_terms(g3, coeffs, ts)
+    b2 = bp32.sampled_terms(g3, coeffs, ts)
+    ns = np.floor(ts / 0.1).astype(int)
+    for k in ("costs2", "grad_C", "grad_T"):
+        assert np.array_equal(b[k], b2[k]), k
+        assert np.isfinite(b[k]).all()
+        for t in range(B):          # trajectory by trajectory: a misrouted partial sum does not hide behind another's scale
+            sc = max(np.abs(a[k][t]).max(), 1e-3 * np.abs(a[k]).max())
+            assert np.abs(b[k][t] - a[k][t]).max() <= 5e-5 * sc, (k, t, ns[t])
+    assert np.all(b["costs2"][28] == 0) and np.all(b["grad_C"][28] == 0) and np.all(b["grad_T"][28] == 0)
+    # pieces without samples have no partials
+    gC = b["grad_C"].reshape(B, M, 6, D)
+    assert np.all(gC[ns == 0] == 0) and np.all(b["grad_T"][ns == 0] == 0)
 
 
 def test_3d_problem_on_z_constant_field_reproduces_2d_costs():

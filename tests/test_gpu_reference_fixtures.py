@@ -74,13 +74,19 @@ def test_g6_shares_within_1e_4_of_the_reference_beside_the_reference_against_its
     # fp64: parts from the reference no more often than the reference from itself under another BLAS kernel set
     assert dev["f64"]["finals_within_1e_4"] >= ref["self_agreement_min"] - slack
     assert dev["f64"]["x_rel_median"] < 1e-9 and dev["f64"]["same_exception"] >= 0.95
-    for mode, within, c2 in (("f32", 0.6, 0.8), ("f32x", 0.45, 0.7)):
+    # measured on the MI355X (profiles/r04_h_reference_fixture_parity.json, 251 runs): finals within 1e-4 of the reference's on
+    # 73.3 % (f32) and 51.0 % (f32x) -- the reference against itself: 89.6 %; cost within 1e-2 on 90.8 % / 75.7 %.  The
+    # assertions are those shares minus two standard deviations of a share of n runs (a kernel change that re-rounds an
+    # fp32 sum moves individual runs across the 1e-4 line; it must not move the share).
+    for mode, within, c2 in (("f32", 0.733, 0.908), ("f32x", 0.510, 0.757)):
         m = dev[mode]
-        # measured (profiles/r04_reference_fixture_parity.json): finals within 1e-4 of the reference's on 72.5 % (f32) and
-        # 54.6 % (f32x) of the 251 runs -- the reference against itself: 89.6 %; cost within 1e-2 on 90 % / 79 %
-        assert m["finals_within_1e_4"] >= within - slack, (mode, m)
-        assert m["cost_within_1e_2"] >= c2 - slack, (mode, m)
-        assert m["same_exception"] >= 0.97, (mode, m)                  # `collision cost too large` on the same requests
+        two_sigma = lambda p_: 2.0 * np.sqrt(p_ * (1.0 - p_) / n)
+        assert m["finals_within_1e_4"] >= within - two_sigma(within), (mode, m)
+        assert m["cost_within_1e_2"] >= c2 - two_sigma(c2), (mode, m)
+        # what a user of the timed mode gets: the reference's cost level (median final cost of the runs no worse than the
+        # reference's by more than 1e-3) and its accept / `collision cost too large` decision on >= 99 % of the requests
+        assert m["median_final_cost"] <= m["reference_median_final_cost"] * (1.0 + 1e-3), (mode, m)
+        assert m["same_exception"] >= 0.99, (mode, m)
         assert abs(m["mean_nfev"] - ref["mean_nfev"]) <= 0.15 * ref["mean_nfev"], (mode, m)
         # exits: every run ends by L-BFGS-B's own tests; the fp32 modes end fewer line searches ABNORMALly than the
         # reference (f32x: 3 against 32 of 251 -- a search that has contracted below fp32 resolution repeats a point and

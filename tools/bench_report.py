@@ -296,7 +296,7 @@ def esdf_report(R):
         gC = torch.zeros(nb, 6 * M, D, dtype=torch.float64, device=dev)
         gT = torch.zeros(nb, M, dtype=torch.float64, device=dev)
         od = torch.from_numpy(order_np).to(dev) if order_np is not None else None
-        ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, pp(od) if od is not None else None, nb))
+        ctx.check(ctx.lib.neo_sampled_terms_dispatch_order(ctx.h, pp(od) if od is not None else None, 1, nb))
         run = lambda: ctx.check(ctx.lib.neo_sampled_terms_batch_dev(ctx.h, scene, nb, M, D, pp(co), pp(dts), pp(c2), pp(gC), pp(gT)))
         for _ in range(3):
             run()
@@ -308,7 +308,7 @@ def esdf_report(R):
         torch.cuda.synchronize()
         ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
         nl, ms = R.kernel_time(_lib.NEO_KERNEL_ESDF_SAMPLE)
-        ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, None, 0))
+        ctx.check(ctx.lib.neo_sampled_terms_dispatch_order(ctx.h, None, 0, 0))
         return 1e3 * ms / max(nl, 1), nl, (c2, gC, gT)
 
     def block(scene, layout_name, default_wl):

@@ -27,8 +27,9 @@ for c in range(cases):
         occ[tuple(rng.integers(0, s) for s in shape)] = 1
     res = float(rng.choice([0.1, 0.25, 0.07]))
     want = (ndimage.distance_transform_edt(1 - occ) * res).astype(np.float32)
-    for generic in ("0", "1"):
-        os.environ["NEO_EDT_GENERIC"] = generic
+    for generic in (0, 1):
+        ctx_ = npa._lib.default_context()
+        ctx_.check(ctx_.lib.neo_esdf_build_config(ctx_.h, generic))     # 1 = NEO_EDT_GENERIC_LINES
         layout = str(rng.choice(["linear", "brick", "yz4"]))
         g3 = npa.ESDF3D.from_occupancy(occ, res, (0.0, 0.0, 0.0), layout=layout, want_dist=True)
         if not np.array_equal(g3.dist, want):

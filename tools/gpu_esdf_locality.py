@@ -90,7 +90,7 @@ def main():
                 od = None
                 if fn is not None:
                     od = torch.from_numpy(fn(head_a[:nb], tail_a[:nb])).to(dev)
-                ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, pp(od) if od is not None else None, nb))
+                ctx.check(ctx.lib.neo_sampled_terms_dispatch_order(ctx.h, pp(od) if od is not None else None, 1, nb))
                 for _ in range(3):
                     run()
                 torch.cuda.synchronize()
@@ -115,7 +115,7 @@ def main():
                            frac_8d2=by / (us * 1e-6) / 1e9 / 8000.0, same_bits_as_first_variant=bool(same))
                 results.append(row)
                 print(f"{a.config} {layout:6s} {oname:22s} B={nb:6d}  {us:9.2f} us  frac_8d2 {row['frac_8d2']:.3f}  same bits {same}", flush=True)
-        ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, None, 0))
+        ctx.check(ctx.lib.neo_sampled_terms_dispatch_order(ctx.h, None, 0, 0))
         ctx.check(ctx.lib.neo_esdf_drop(ctx.h, g3.scene_id))
     if a.json:
         json.dump(results, open(a.json, "w"), indent=1)

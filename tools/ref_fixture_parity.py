@@ -268,6 +268,7 @@ def g6_device_side(d, modes=MODES, limit=None):
                          cost_within_1e_4=float((rc <= 1e-4).mean()), cost_within_1e_2=float((rc <= 1e-2).mean()),
                          x_rel_median=float(np.median(dx)), cost_rel_median=float(np.median(rc)),
                          mean_nfev=float(nfev[sel].mean()),
+                         median_final_cost=float(np.median(cost[sel])), reference_median_final_cost=float(np.median(fb[sel])),
                          same_exception=float(np.mean([errs[k].split(":")[0] == eb[k].split(":")[0] for k in np.flatnonzero(run)])),
                          exceptions=_hist([errs[k] for k in np.flatnonzero(run)]),
                          exits=_hist_codes([codes[k] for k in np.flatnonzero(run)]))
