@@ -576,7 +576,8 @@ class Rank:
                 # (the fence at the end of the timed region does), only the batch's next use of its buffers does.
                 if bt.get("work") is not None:
                     bt["work"].wait()
-                bt["packed"] = self.sharding.pack_results(bt["x"], bt["costs"], self.w)
+                bt["packed"] = self.sharding.pack_results(bt["x"], bt["costs"], self.bp.cfg.weights, ctx=self.ctx,
+                                                          out=bt.get("packed"))
                 _, bt["work"] = self.sharding.gather_results(bt["packed"], self.world, out=bt["gathered"], force=True,
                                                              async_op=True)
 

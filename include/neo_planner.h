@@ -287,6 +287,11 @@ int neo_optimize_dispatch_order(neo_ctx *ctx, const int32_t *dev_order, int B);
 /* the same from a HOST permutation (copied into a context-owned device buffer); NULL or B = 0 resets.
  * Either way the permutation only applies to launches of exactly B trajectories. */
 int neo_optimize_dispatch_order_host(neo_ctx *ctx, const int32_t *host_order, int B);
+/* results of a batch as fp32 rows [x (n) | weighted total cost | 4 cost terms] -- what the ranks of a scene-sharded job
+ * gather (neo_planner_amd/sharding.py): one launch on the context's stream, device pointers, weights4 on
+ * the host.  out[B][n + 5]. */
+int neo_pack_results_dev(neo_ctx *ctx, int B, int n, const double *x, const double *costs4, const double *weights4,
+                         float *out);
 /* the ESDF-lookup kernel's own permutation (neo_sampled_terms_batch[_dev] launches of exactly B trajectories; results stay
  * in the caller's order, bit-identical): there the lever is locality -- workgroup i runs on XCD i mod 8, each XCD has its
  * own L2, and BatchPlanner.spatial_order deals requests that fly through the same part of the field to the same XCD.

@@ -1813,6 +1813,39 @@ int neo_optimize_dispatch_order_host(neo_ctx *c, const int32_t *host_order, int 
   return NEO_OK;
 }
 
+namespace neo {
+// rows [x (n) | total cost | 4 cost terms] in fp32 for the result gather (neo_planner_amd/sharding.py)
+__global__ void pack_results_kernel(int B, int n, const double *__restrict__ x, const double *__restrict__ costs4, double w0, double w1,
+                                    double w2, double w3, float *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t row = i / (size_t)(n + 5);
+  if (row >= (size_t)B) return;
+  const int col = (int)(i - row * (size_t)(n + 5));
+  const double *c4 = costs4 + row * 4;
+  double v;
+  if (col < n)
+    v = x[row * (size_t)n + col];
+  else if (col == n)
+    v = ((c4[0] * w0 + c4[1] * w1) + c4[2] * w2) + c4[3] * w3;  // (costs * weights).sum(dim=1), left to right
+  else
+    v = c4[col - n - 1];
+  out[i] = (float)v;
+}
+}  // namespace neo
+
+int neo_pack_results_dev(neo_ctx *c, int B, int n, const double *x, const double *costs4, const double *weights4, float *out) {
+  if (!c || B < 0 || n < 1) return NEO_ERR_INVALID;
+  if (!x || !costs4 || !weights4 || !out) return fail_locked(c, NEO_ERR_INVALID, "null buffer");
+  if (B == 0) return NEO_OK;
+  std::lock_guard<std::recursive_mutex> g(c->mu);
+  hipSetDevice(c->device);
+  const size_t total = (size_t)B * (size_t)(n + 5);
+  hipLaunchKernelGGL(neo::pack_results_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, B, n, x, costs4,
+                     weights4[0], weights4[1], weights4[2], weights4[3], out);
+  HIPCHK(c, hipGetLastError());
+  return NEO_OK;
+}
+
 int neo_sampled_terms_dispatch_order(neo_ctx *c, const int32_t *order, int on_device, int B) {
   if (!c || B < 0) return NEO_ERR_INVALID;
   std::lock_guard<std::recursive_mutex> g(c->mu);

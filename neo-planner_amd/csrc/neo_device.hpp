@@ -38,7 +38,8 @@ struct DevParams {
   double coll_tol;
   double ftol, gtol;
   int maxls, maxiter, maxfun, stale_T;
-  int dbg;  // timing experiments only (neo_params.flags): 1 skip sample loop, 2 skip joint sweeps, 4 no history
+  int dbg;  // timing experiments only (neo_params.flags): 1 skip sample loop, 2 skip joint sweeps, 4 no history -- read by
+            // the kernels of -DNEO_EXPERIMENTS builds alone (NEO_DBG below); the product's kernels have no such paths
   // fp32 forms of what the fp32 arithmetic uses, derived on the host (derive()): kernel arguments arrive in scalar
   // registers, whereas a (float)prm.x inside a kernel is a vector conversion whose (wave-uniform) result the compiler
   // hoists and then keeps in a vector register across the whole optimiser loop -- nine of them, spilled to scratch in the
@@ -59,6 +60,13 @@ struct DevParams {
     for (int k = 0; k < 4; ++k) f.w[k] = (float)w[k];
   }
 };
+// phase switches of the timing experiments (tools/gpu_phase_bench.py, tools/probe/phase_counts.py): compiled in only with
+// -DNEO_EXPERIMENTS; in the product the tests are the constant 0 and the switched-off paths do not exist
+#ifdef NEO_EXPERIMENTS
+#define NEO_DBG(prm, bits) (((prm).dbg & (bits)) != 0)
+#else
+#define NEO_DBG(prm, bits) false
+#endif
 // a parameter in the arithmetic N: the double itself, or its fp32 form from DevParams::f
 #define NEO_PARAM(name, dexpr, fexpr)                                                  \
   template <typename N>                                                                \
@@ -117,8 +125,12 @@ __device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
 // wrote and read.  All that is needed is that the compiler keeps the order: a wavefront-scope fence and a scheduling
 // barrier, no s_barrier and no wait for every outstanding LDS operation as __syncthreads() would add.
 __device__ __forceinline__ void lds_wave_sync() {
+#ifdef NEO_STRONG_SYNC  // (diagnostic builds: a workgroup barrier with its full waits)
+  __syncthreads();
+#else
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+#endif
 }
 
 __device__ __forceinline__ double rdlane(double v, int src /*wave-uniform*/) {
@@ -1395,7 +1407,7 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
     const Num a1 = LG::prev(t.i1, Num(1.0)), a2 = a1 * a1, a3 = a2 * a1, a4 = a2 * a2;
     joint_blocks(t, a1, a2, a3, Lo, Di, Up);
     constexpr bool kPcr = PCR;  // fp32-sampling modes: parallel cyclic reduction (pcr_solve)
-    if constexpr (!kPcr) thomas_factor<LG, Num>((prm.dbg & (2 | 8)) ? 1 : t.M, Lo, Di, Up, t.N, E);
+    if constexpr (!kPcr) thomas_factor<LG, Num>(NEO_DBG(prm, 2 | 8) ? 1 : t.M, Lo, Di, Up, t.N, E);
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
       // displacement of piece p-1 and of piece p
@@ -1432,7 +1444,7 @@ __device__ __forceinline__ int minco_forward(Traj<D, LG::dl(D), Num> &t, const D
       pcr_solve<DL, LG, Num>(t.M, Lo, Di, Up, R, y, t.pcr_mult, t.pcr_xch);
       NEO_MARK("fwd_pcr_end");
     } else {
-      thomas_solve<DL, LG, Num>((prm.dbg & (2 | 16)) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);
+      thomas_solve<DL, LG, Num>(NEO_DBG(prm, 2 | 16) ? 1 : t.M, Lo, t.N, E, R, y0, yM, y);
     }
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
@@ -1653,6 +1665,12 @@ __device__ __forceinline__ SampleLanes group_sample_lanes(int M, int ns_piece) {
 // perfect split).  ns_piece: PIECE layout (lane p < M).  seg: 64 ints of LDS scratch.
 __device__ __forceinline__ SampleLanes balanced_sample_lanes(int M, int ns_piece, int *seg) {
   const int lane = lane_id();
+  // `seg` is the caller's staging buffer seen as ints; the caller has just READ it as its own type (scatter_x: the
+  // lane's waypoints).  Those loads must stay ahead of the stores below, and type-based alias analysis says an int store
+  // and a double load cannot touch the same memory: with -sink-insts-to-avoid-spills the compiler moved the loads of
+  // P0 / P1 below `seg[lane] = 0` in one instantiation (linear fp16 field, fp64, three FLAT slots) and the optimiser ran
+  // on zeros (round 5; the library is built with -fno-strict-aliasing since, and the hand-over is fenced here).
+  lds_wave_sync();
   const int mine = lane < M ? ns_piece : 0;
   const int total = wave_sum(mine);
   int R = max(1, (total + kWave - 1) / kWave);
@@ -1794,7 +1812,7 @@ __device__ __forceinline__ void minco_sample(int M, const SampleLanes &sl, int n
     const int ns_sh = __shfl(ns_in, LG::base() + LG::S * piece, kWave);
     ns = act ? ns_sh : 0;
   }
-  const int iters = (prm.dbg & 1) ? 0 : (sl.rounds >= 0 ? sl.rounds : wave_max_nonneg((ns + L - 1) / L));
+  const int iters = NEO_DBG(prm, 1) ? 0 : (sl.rounds >= 0 ? sl.rounds : wave_max_nonneg((ns + L - 1) / L));
 
   const Real dt = par_dt<Real>(prm), vmax2 = par_vmax2<Real>(prm), safe = par_safe<Real>(prm);
   const Real w2 = par_w2<Real>(prm), w3 = par_w3<Real>(prm);
@@ -2161,7 +2179,7 @@ __device__ __forceinline__ int minco_backward(const Traj<D, LG::dl(D), Num> &t, 
       R[1][d] = S[2][d];
       z0[0][d] = z0[1][d] = Num(0.0);
     }
-    thomas_solve<DL, LG, Num>((prm.dbg & (2 | 16)) ? 1 : M, LoT, NT, ET, R, z0, z0, y);
+    thomas_solve<DL, LG, Num>(NEO_DBG(prm, 2 | 16) ? 1 : M, LoT, NT, ET, R, z0, z0, y);
 #pragma unroll
     for (int d = 0; d < DL; ++d) {
       lam[0][d] = (lane >= 1 && lane < M) ? y[0][d] : Num(0.0);

@@ -48,7 +48,12 @@ int launch_sample_chunk(neo_ctx *c, const MapT &map, const SampleArgs &a) {
 template <int D, typename Real, class MapT, class LookupT>
 int launch_sample(neo_ctx *c, const MapT &map, const SampleArgs &a) {
   hipLaunchKernelGGL((sample_kernel<D, Real, MapT, LookupT>), dim3(a.B), dim3(kWave),
-                     sizeof(Real) == 4 ? flat_lds_bytes(a.M, D) : 0, c->stream, a.B, a.M, c->dev,
+#ifdef NEO_SAMPLE_SHARED_TAILS  // (experiment builds: tools/probe/neo_sample_shared.hpp)
+                     sizeof(Real) == 4 ? sample_lds_bytes(a.M, D) : 0,
+#else
+                     0,
+#endif
+                     c->stream, a.B, a.M, c->dev,
                      map, a.coeffs, a.ts, a.costs2, a.grad_C, a.grad_T, (c->sample_order_B == a.B ? c->sample_order : nullptr));
   return NEO_OK;
 }

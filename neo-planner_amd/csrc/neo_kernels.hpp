@@ -570,6 +570,10 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
 #endif
 // the body of sample_kernel (one wavefront per trajectory, lanes per piece) as a function: also the fallback path of
 // sample_chunk_kernel (neo_sample_chunk.hpp)
+// (round 5, measured and not adopted -- HISTORY.md: the coefficients loaded in the PIECE layout next to the durations and
+//  handed to the sample lanes through an LDS table, to take the coefficient load off the chain "durations -> lane
+//  assignment -> coefficients": 28.3 us against 27.9 us per 4096 launch; shared tail lanes, 10 rounds instead of 13 at a
+//  fresh guess: 31.1 us, tools/probe/neo_sample_shared.hpp)
 template <int D, typename Real, class MapT, class LookupT>
 __device__ __forceinline__ void sample_wave_per_piece(int b, int M, const DevParams &prm, const MapT &map,
                                                       const double *__restrict__ coeffs, const double *__restrict__ ts,
@@ -578,7 +582,8 @@ __device__ __forceinline__ void sample_wave_per_piece(int b, int M, const DevPar
   const int lane = lane_id();
   // lanes in proportion to the pieces' sample counts, as in the fused kernels
   const double Tp = lane < M ? ts[(size_t)b * M + lane] : 1.0;
-  const SampleLanes sl = balanced_sample_lanes(M, lane < M ? (int)(Tp / prm.delta_t) : 0, seg);
+  const int ns_p = lane < M ? (int)(Tp / prm.delta_t) : 0;
+  const SampleLanes sl = balanced_sample_lanes(M, ns_p, seg);
   const int piece = sl.piece, r = sl.r;
   const bool act = sl.act;
   const double T = act ? ts[(size_t)b * M + piece] : 1.0;
@@ -607,207 +612,24 @@ __device__ __forceinline__ void sample_wave_per_piece(int b, int M, const DevPar
     }
     grad_T[(size_t)b * M + piece] = (double)gT;
   }
-  if (lane == 0) {
-    costs2[(size_t)b * 2 + 0] = cf;
-    costs2[(size_t)b * 2 + 1] = ck;
-  }
-}
-
-// floats per piece of sample_wave_flat's two LDS tables: [d][6] coefficients / partials, then (samples, first sample) as
-// ints / the duration partial
-__host__ __device__ constexpr int flat_row_floats(int D) { return (6 * D + 2 + 3) / 4 * 4; }
-__host__ __device__ constexpr int flat_lds_bytes(int M, int D) { return 2 * M * flat_row_floats(D) * (int)sizeof(float); }
-
-// The ESDF-lookup kernel's body for fp32 sampling, round 5: the trajectory's quadrature samples as ONE sequence dealt to
-// the lanes in contiguous blocks of R = ceil(S / 64) -- lane l walks samples l R .. l R + R - 1 of the sequence and
-// crosses from a piece into the next where the block does.  The per-piece assignment above gives every piece whole lanes:
-// at a fresh guess (19 pieces of 25 samples, 2 of 37: 549 samples) that is 13 rounds with 44 of 64 lanes busy (ten rounds
-// would need 65 lanes); the flat sequence takes ceil(549 / 64) = 9 rounds with 61 lanes busy in every one.
-// A lane that crosses a piece boundary stores its partial sums for the piece it leaves into that piece's accumulator row
-// in LDS (it holds the piece's LAST sample, so it is the one lane that does), zeroes them and reads the next piece's
-// coefficients from the coefficient table; at the end the lane that holds a piece's last sample writes the row, the other
-// lanes of the piece add to it one after the other in lane order: every sum has a fixed order.
-// tab: LDS, [2][M][flat_row_floats(D)] floats; seg: LDS, 64 ints.
-template <int D, class MapT, class LookupT>
-__device__ __forceinline__ void sample_wave_flat(int b, int M, const DevParams &prm, const MapT &map,
-                                                 const double *__restrict__ coeffs, const double *__restrict__ ts,
-                                                 double *__restrict__ costs2, double *__restrict__ grad_C,
-                                                 double *__restrict__ grad_T, int *seg, float *tab) {
-#pragma clang fp contract(on)  // fuse a*b+c only as written
-  typedef float Real;
-  typedef float Quad __attribute__((ext_vector_type(4)));
-  constexpr int RS = flat_row_floats(D), NQ = RS / 4, kNs = 6 * D, kFirst = 6 * D + 1;
-  float *ctab = tab, *acc = tab + (size_t)M * RS;
-  const int lane = lane_id();
-  // ---- PIECE layout: sample counts, their prefix sums, the coefficient table
-  const bool have = lane < M;
-  const double Tp = have ? ts[(size_t)b * M + lane] : 0.0;
-  const int ns_p = have ? (int)(Tp / prm.delta_t) : 0;
-  const int total = wave_sum(ns_p);
-  const int first_p = wave_scan_add(ns_p) - ns_p;
-  if (have) {
-    // the 6*D doubles of a piece are contiguous and 16-byte aligned (6*D is even)
-    const double2 *src = reinterpret_cast<const double2 *>(coeffs + ((size_t)b * 6 * M + 6 * lane) * D);
-    float f[RS];
-#pragma unroll
-    for (int q = 0; q < 3 * D; ++q) {
-      const double2 v = src[q];
-      const int e0 = 2 * q, e1 = 2 * q + 1;  // element k * D + d of the piece -> [d][k]
-      f[(e0 % D) * 6 + e0 / D] = (float)v.x;
-      f[(e1 % D) * 6 + e1 / D] = (float)v.y;
-    }
-    f[kNs] = __int_as_float(ns_p);
-    f[kFirst] = __int_as_float(first_p);
-#pragma unroll
-    for (int q = kFirst + 1; q < RS; ++q) f[q] = 0.0f;
-    Quad *row = reinterpret_cast<Quad *>(ctab + (size_t)lane * RS);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) row[q] = Quad{f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]};
-  }
-  // ---- blocks: R samples a lane; the piece a lane starts in = the last piece that begins at or before its first sample
-  const int R = max(1, (total + kWave - 1) / kWave);
-  const float rR = __builtin_amdgcn_rcpf((float)R);
-  seg[lane] = 0;
-  lds_wave_sync();
-  if (ns_p > 0) {
-    // first lane whose block starts at or after the piece's first sample: ceil(first / R) (the half keeps the quotient off
-    // the integers: exact for first + R < 2^20)
-    const int at = (int)(((float)first_p + (float)R - 0.5f) * rR);
-    if (at < kWave) atomicMax(&seg[at], lane + 1);  // (several short pieces may begin inside one block: the last one)
-  }
-  lds_wave_sync();
-  int q = max(wave_scan_max_nonneg(seg[lane]) - 1, 0);
-  const int g0 = lane * R;
-  const int left0 = min(total - g0, R);  // samples of this lane (<= 0: none)
-  const bool act = left0 > 0;
-  Real c[6][D];
-  int ns, j;
-  Real inv_ns;
-  auto read_piece = [&](int piece) {
-    const Quad *row = reinterpret_cast<const Quad *>(ctab + (size_t)piece * RS);
-    float f[RS];
-#pragma unroll
-    for (int w = 0; w < NQ; ++w) {
-      const Quad v = row[w];
-      f[4 * w] = v.x; f[4 * w + 1] = v.y; f[4 * w + 2] = v.z; f[4 * w + 3] = v.w;
-    }
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-#pragma unroll
-      for (int k = 0; k < 6; ++k) c[k][d] = f[d * 6 + k];
-    ns = __float_as_int(f[kNs]);
-    return __float_as_int(f[kFirst]);
-  };
-  {
-    const int first = read_piece(q);
-    j = g0 - first;
-    if (!act) { ns = 0; j = 0; }
-    inv_ns = ns > 0 ? __builtin_amdgcn_rcpf((float)ns) : 0.0f;
-  }
-  const Real dt = par_dt<Real>(prm), vmax2 = par_vmax2<Real>(prm), safe = par_safe<Real>(prm);
-  const Real w2 = par_w2<Real>(prm), w3 = par_w3<Real>(prm);
-  Real aC[6][D];
-#pragma unroll
-  for (int k = 0; k < 6; ++k)
-#pragma unroll
-    for (int d = 0; d < D; ++d) aC[k][d] = 0.0f;
-  Real aT = 0.0f, aF = 0.0f, aK = 0.0f;
-  auto store_row = [&](int piece, bool add) {
-    Quad *row = reinterpret_cast<Quad *>(acc + (size_t)piece * RS);
-    float f[RS];
-#pragma unroll
-    for (int w = 0; w < RS; ++w) f[w] = 0.0f;
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-#pragma unroll
-      for (int k = 0; k < 6; ++k) f[d * 6 + k] = aC[k][d];
-    f[6 * D] = aT;
-#pragma unroll
-    for (int w = 0; w < NQ; ++w) {
-      const Quad v = Quad{f[4 * w], f[4 * w + 1], f[4 * w + 2], f[4 * w + 3]};
-      row[w] = add ? row[w] + v : v;
-    }
-  };
-  const LookupT lk(map);
-  int left = left0;
-  for (int k = 0; k < R; ++k) {
-    const bool on = left > 0;
-    if (on) {  // (the last lanes' blocks may be short: they sit the round out, exec-masked)
-      const Real s = (Real)((double)j * prm.delta_t);  // beta_full row j: t = j * delta_t (:251)
-      Real pos[D], vel[D];
-#pragma unroll
-      for (int d = 0; d < D; ++d)
-        pos[d] = fmaf(fmaf(fmaf(fmaf(fmaf(c[5][d], s, c[4][d]), s, c[3][d]), s, c[2][d]), s, c[1][d]), s, c[0][d]);
-      const typename LookupT::Addr ad = lk.template prepare<D>(pos, true);
-      const typename LookupT::Raw rw = lk.load(ad);
-      piece_pos_vel<Real, D>(c, s, pos, vel);  // (the velocity while the gathers fly)
-      Real v2 = 0.0f;
-#pragma unroll
-      for (int d = 0; d < D; ++d) v2 += vel[d] * vel[d];
-      const Real vv = v2 - vmax2;
-      Real gdrop[D];
-      const Real vd = safe - lk.template finish<D>(ad, rw, gdrop);
-      if (vv > 0.0f || vd > 0.0f)
-        sample_accumulate<Real, D, LookupT>(c, j, ns, s, inv_ns, vel, vv, vd, lk, ad, rw, dt, w2, w3, aC, aT, aF, aK);
-      ++j;
-      --left;
-      if (j == ns && left > 0) {
-        // the block goes on in the next piece: this lane held the piece's last sample and is the one that starts its row
-        store_row(q, false);
-#pragma unroll
-        for (int kk = 0; kk < 6; ++kk)
-#pragma unroll
-          for (int d = 0; d < D; ++d) aC[kk][d] = 0.0f;
-        aT = 0.0f;
-        do {  // (pieces without samples own no part of the sequence)
-          ++q;
-          (void)read_piece(q);
-        } while (ns == 0);
-        j = 0;
-        inv_ns = __builtin_amdgcn_rcpf((float)ns);
-      }
-    }
-  }
-  // ---- the partial sums of every lane's last piece: the lane with the piece's last sample starts the row, the others add
-  lds_wave_sync();
-  const bool closer = act && j == ns;
-  if (closer) store_row(q, false);
-  lds_wave_sync();
-  int rank = -1;
-  if (act && !closer) {
-    // lanes first_lane .. (closer - 1) of the piece hold nothing else at the end; first_lane = floor(first sample / R)
-    const Quad *row = reinterpret_cast<const Quad *>(ctab + (size_t)q * RS);
-    const int first = __float_as_int(row[kFirst / 4][kFirst % 4]);
-    rank = lane - (int)(((float)first + 0.5f) * rR);
-  }
-  const int depth = wave_max_nonneg(rank + 1);
-  for (int i = 0; i < depth; ++i) {
-    if (rank == i) store_row(q, true);
-    lds_wave_sync();
-  }
-  // ---- PIECE layout again: the rows out
-  if (have) {
-    const Quad *row = reinterpret_cast<const Quad *>(acc + (size_t)lane * RS);
-    float f[RS];
-#pragma unroll
-    for (int w = 0; w < NQ; ++w) {
-      const Quad v = ns_p > 0 ? row[w] : Quad{0.0f, 0.0f, 0.0f, 0.0f};
-      f[4 * w] = v.x; f[4 * w + 1] = v.y; f[4 * w + 2] = v.z; f[4 * w + 3] = v.w;
-    }
+  if (lane < M && ns_p == 0) {
+    // a piece shorter than delta_t has no sample and no sample lane: its partials are zeros (the planner's durations
+    // never are -- T > T_min = 5 delta_t --, a caller of neo_sampled_terms_batch may pass any; found by
+    // tests/test_gpu_parity.py::test_sampled_terms_on_ragged_durations: the rows were left as the caller's buffer had them)
     double2 *dst = reinterpret_cast<double2 *>(grad_C + ((size_t)b * 6 * M + 6 * lane) * D);
 #pragma unroll
-    for (int w = 0; w < 3 * D; ++w) {
-      const int e0 = 2 * w, e1 = 2 * w + 1;
-      dst[w] = make_double2((double)f[(e0 % D) * 6 + e0 / D], (double)f[(e1 % D) * 6 + e1 / D]);
-    }
-    grad_T[(size_t)b * M + lane] = (double)f[6 * D];
+    for (int q = 0; q < 3 * D; ++q) dst[q] = make_double2(0.0, 0.0);
+    grad_T[(size_t)b * M + lane] = 0.0;
   }
-  const double cf = (double)wave_sum(act ? aF : 0.0f), ck = (double)wave_sum(act ? aK : 0.0f);
   if (lane == 0) {
     costs2[(size_t)b * 2 + 0] = cf;
     costs2[(size_t)b * 2 + 1] = ck;
   }
 }
+
+#ifdef NEO_SAMPLE_SHARED_TAILS  // experiment builds only (tools/probe/neo_sample_shared.hpp: measured, not adopted)
+#include "../../tools/probe/neo_sample_shared.hpp"
+#endif
 
 template <int D, typename Real, class MapT, class LookupT>
 __global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? NEO_SAMPLE_OCC : 2) void sample_kernel(int B, int M, DevParams prm, MapT map,
@@ -823,15 +645,16 @@ __global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? NEO_SAMPLE_OCC : 2) void
   // the caller's order
   const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
   __shared__ int seg[kWave];
+  // rows of the per-piece fold (fp32 sampling, minco_sample)
+  __shared__ __attribute__((aligned(16))) Real rows[sizeof(Real) == 4 ? kWave * 8 * D : 4];
+#ifdef NEO_SAMPLE_SHARED_TAILS
   if constexpr (sizeof(Real) == 4) {
-    // fp32 sampling: the samples as one sequence in contiguous blocks (dynamic LDS: flat_lds_bytes(M, D))
-    extern __shared__ __attribute__((aligned(16))) float flat_tab[];
-    sample_wave_flat<D, MapT, LookupT>(b, M, prm, map, coeffs, ts, costs2, grad_C, grad_T, seg, flat_tab);
-  } else {
-    // (the fp64 parity mode keeps whole lanes per piece and the summation order its fixtures were recorded with)
-    __shared__ __attribute__((aligned(16))) Real rows[4];
-    sample_wave_per_piece<D, Real, MapT, LookupT>(b, M, prm, map, coeffs, ts, costs2, grad_C, grad_T, seg, rows);
+    extern __shared__ __attribute__((aligned(16))) float sample_tab[];
+    sample_wave_shared<D, MapT, LookupT>(b, M, prm, map, coeffs, ts, costs2, grad_C, grad_T, seg, sample_tab);
+    return;
   }
+#endif
+  sample_wave_per_piece<D, Real, MapT, LookupT>(b, M, prm, map, coeffs, ts, costs2, grad_C, grad_T, seg, rows);
 }
 
 }  // namespace neo

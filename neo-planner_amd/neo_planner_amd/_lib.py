@@ -32,7 +32,7 @@ EXPORTS = [
     "neo_sampled_terms_batch", "neo_sampled_terms_batch_dev", "neo_esdf_build_3d",
     "neo_optimize_dispatch_order_host", "neo_ctx_set_stream", "neo_optimize_trace",
     "neo_optimize_batch_from_dev", "neo_optimize_trace_xg", "neo_sampled_terms_dispatch_order",
-    "neo_esdf_build_config",
+    "neo_esdf_build_config", "neo_pack_results_dev",
 ]
 
 
@@ -104,6 +104,7 @@ def load():
     L.neo_optimize_dispatch_order_host.argtypes = [c_p, c_p, c_i]
     L.neo_sampled_terms_dispatch_order.argtypes = [c_p, c_p, c_i, c_i]
     L.neo_esdf_build_config.argtypes = [c_p, c_i]
+    L.neo_pack_results_dev.argtypes = [c_p, c_i, c_i, c_p, c_p, c_p, c_p]
     L.neo_sampled_terms_batch.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 5
     L.neo_sampled_terms_batch_dev.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 5
     for name in EXPORTS:

@@ -34,7 +34,19 @@ def _flags():
     # they cost moves and spills (8 v_mov per joint of the factor recurrence).  Measured on the MI355X with and without:
     # cfg2 all-fp32 943 k -> 995 k traj/s, cfg3 12.5 M -> 15.2 M, cfg4 888 k -> 945 k, cfg5 244 k -> 259 k; the
     # mixed-precision and the ESDF sample kernels unchanged.
-    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-unused-value", "-I", INCLUDE] + \
+    # -fno-strict-aliasing: the kernels view one LDS staging buffer as doubles, floats, ints and 16-byte vectors in turn; under
+    # type-based alias analysis the compiler may (and in round 5 did, in one fp64 instantiation) move a load of one view
+    # across a store of another.  The hand-overs are fenced as well; this keeps an unfenced one from becoming a silent
+    # wrong result.
+    # -ffp-contract=on (every unit since round 5): a multiply-add is fused where it is written as one expression and nowhere
+    # else, so the bits a kernel computes follow from its source, not from what the optimiser happened to schedule next to
+    # what (HIP's default `fast` fuses across statements as the surrounding code allows: in round 4 an unrelated change
+    # re-rounded the all-fp32 kernels, in round 5 adding -fno-strict-aliasing re-rounded the fp64 ones).  Measured with the
+    # fp64 / mixed units switched over: cfg2 fp64 633 -> 635 k traj/s, mixed 770 -> 771 k; recorded reference runs followed
+    # to the last evaluation 19 -> 20 of 22 (the 331-evaluation one now among them), G6 finals within 1e-4 of the
+    # reference's 89.2 -> 90.0 % (the reference against itself: 89.6 %).
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-fno-strict-aliasing",
+            "-ffp-contract=" + os.environ.get("NEO_FP_CONTRACT", "on"), "-Wno-unused-value", "-I", INCLUDE] + \
         os.environ.get("NEO_BUILD_DEFS", "").split()
 
 
@@ -54,18 +66,20 @@ def _newest_header():
 # such instructions back into the loop leaves 7 and is worth 13 % (549 k -> 620 k traj/s; the all-fp32 kernels do not
 # care: 1.26 M either way).
 _SINK = ["-mllvm", "-sink-insts-to-avoid-spills"]
-_ASWRITTEN = ["-ffp-contract=" + os.environ.get("NEO_FP_CONTRACT", "on")]
-UNIT_FLAGS = {"neo_disp_opt3d_x.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"] + _ASWRITTEN,
-              "neo_disp_opt2d_x.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"] + _ASWRITTEN,
-              "neo_disp_eval.hip": _ASWRITTEN,
+UNIT_FLAGS = {"neo_disp_opt3d_x.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
+              "neo_disp_opt2d_x.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers"],
               # (the fp64 unit also without machine LICM: no spills at all in its two-waves kernels, 618 k -> 640 k; the
               #  same pair costs the mixed mode 6 % and the all-fp32 mode 2 %, so only there)
               "neo_disp_opt3d_f64.hip": _SINK + ["-mllvm", "-disable-machine-licm"],
               "neo_disp_opt3d_w2.hip": _SINK, "neo_disp_opt2d.hip": _SINK}
 
 
+def _unit_flags(src):
+    return list(UNIT_FLAGS.get(src, []))
+
+
 def _compile(src, obj, verbose):
-    cmd = [_hipcc()] + _flags() + UNIT_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj + ".tmp"]
+    cmd = [_hipcc()] + _flags() + _unit_flags(src) + ["-c", os.path.join(CSRC, src), "-o", obj + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -78,7 +92,7 @@ def _key(src=None):
     reused"""
     h = hashlib.sha256()
     h.update(open(os.path.abspath(__file__), "rb").read())
-    h.update(" ".join(_flags() + (UNIT_FLAGS.get(src, []) if src else [])).encode())
+    h.update(" ".join(_flags() + (_unit_flags(src) if src else [])).encode())
     return h.hexdigest()[:12]
 
 

@@ -17,10 +17,19 @@ def owner_of(scene, world):
     return scene % world
 
 
-def pack_results(x, costs, weights):
-    """x [B,n] f64, costs [B,4] f64, weights [4] -> [B, n+5] f32 rows (x, total, 4 terms)"""
+def pack_results(x, costs, weights, ctx=None, out=None):
+    """x [B,n] f64, costs [B,4] f64, weights [4] -> [B, n+5] f32 rows (x, total, 4 terms).
+    With a library context and device tensors: one kernel on the context's stream (neo_pack_results_dev; `weights` then a
+    host sequence of 4 floats); otherwise three torch copies (CPU tests, gloo)."""
     B, n = x.shape
-    out = torch.empty(B, n + 5, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(B, n + 5, dtype=torch.float32, device=x.device)
+    if ctx is not None and x.is_cuda:
+        import ctypes
+        w4 = (ctypes.c_double * 4)(*[float(v) for v in weights])
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())
+        ctx.check(ctx.lib.neo_pack_results_dev(ctx.h, B, n, pp(x), pp(costs), ctypes.cast(w4, ctypes.c_void_p), pp(out)))
+        return out
     out[:, :n] = x
     out[:, n] = (costs * weights).sum(dim=1)
     out[:, n + 1:] = costs

@@ -336,11 +336,11 @@ def test_sampled_terms_kernel_matches_oracle():
 
 
 @pytest.mark.parametrize("M", [1, 2, 3, 7, 21, 41, 64])
-def test_flat_sample_sequence_on_ragged_durations(M):
-    """round 5: the fp32 ESDF-lookup kernel deals a trajectory's samples to the lanes as ONE sequence in contiguous blocks (a
-    lane crosses from a piece into the next).  Ragged durations: pieces shorter than delta_t (no sample at all), pieces
-    shorter than a block (several pieces inside one lane), one long piece among short ones, every piece alike -- against the
-    fp64 kernel (whole lanes per piece; pinned to the oracle above) on a continuous 3-D field, and bit-reproducible."""
+def test_sampled_terms_on_ragged_durations(M):
+    """the ESDF-lookup kernel on ragged durations: pieces shorter than delta_t (no sample at all -- round 5: their partials were
+    left as the caller's buffer had them), pieces with one or two samples, one long piece among short ones, every piece alike,
+    a trajectory without any sample -- fp32 sampling against fp64 (pinned to the oracle above) on a continuous 3-D field,
+    trajectory by trajectory, and bit-reproducible."""
     import torch
     rng = np.random.default_rng(500 + M)
     dist = synth.esdf_3d(3, n=100, res=0.3, canopy=20)
@@ -368,12 +368,15 @@ def test_flat_sample_sequence_on_ragged_durations(M):
         assert np.array_equal(b[k], b2[k]), k
         assert np.isfinite(b[k]).all()
         for t in range(B):          # trajectory by trajectory: a misrouted partial sum does not hide behind another's scale
+            # (1e-3: these durations do not belong to the coefficients, so samples sit right at the penalties' thresholds,
+            #  where fp32 positions move a cubed difference by 1e-4 relative; a misrouted sum is an error of order one)
             sc = max(np.abs(a[k][t]).max(), 1e-3 * np.abs(a[k]).max())
-            assert np.abs(b[k][t] - a[k][t]).max() <= 5e-5 * sc, (k, t, ns[t])
+            assert np.abs(b[k][t] - a[k][t]).max() <= 1e-3 * sc, (k, t, ns[t])
     assert np.all(b["costs2"][28] == 0) and np.all(b["grad_C"][28] == 0) and np.all(b["grad_T"][28] == 0)
     # pieces without samples have no partials
     gC = b["grad_C"].reshape(B, M, 6, D)
     assert np.all(gC[ns == 0] == 0) and np.all(b["grad_T"][ns == 0] == 0)
+    assert np.all(a["grad_C"].reshape(B, M, 6, D)[ns == 0] == 0) and np.all(a["grad_T"][ns == 0] == 0)
 
 
 def test_3d_problem_on_z_constant_field_reproduces_2d_costs():
@@ -462,22 +465,17 @@ def _run_entry(pl, d, m):
     return err
 
 
-# Reference runs the device does not follow to the last evaluation (profiles/r02_g3_report.json, tools/g3_divergence_report.py
-# on the MI355X).  Both are the SAME replan request recorded twice (seeds 4 and 5 draw the same map): same exceptions, same
-# number of L-BFGS-B runs and iterations (10), every evaluation the two runs have in common agrees in f to 1e-12 relative,
-# but the LAST line search (iteration 10, f flat to 13 digits between trial steps) ends on a different trial point:
-# SciPy takes 37 / 39 evaluations, the device 40 / 35 -- dcsrch's sufficient-decrease test `f <= finit + stp * gtest`
-# decided by the last bits of f.  Final control points 1.3e-4 apart (durations 3.1e-4), final cost 9e-7: a hair outside
-# north_star's 1e-4 on x, inside it on cost.  The CPU control (bench.py `parity.control`) shows any two implementations
-# that differ in the last bit part on 37 % of cfg2 runs; on the 18 recorded reference scenarios it is these 2.
+# Reference runs the device does not follow to the last evaluation (tools/experiments/gpu_g3_status.py on the MI355X; round 5,
+# every unit built with -ffp-contract=on).  Both are the SAME replan request recorded twice (seeds 4 and 5 draw the same
+# map): same exceptions, same number of L-BFGS-B runs and iterations (10), every evaluation the two runs have in common
+# agrees in f to 1e-12 relative, but the LAST line search (iteration 10, f flat to 13 digits between trial steps) takes
+# one trial step more or fewer: SciPy 37 / 39 evaluations, the device 36 / 40 -- dcsrch's sufficient-decrease test
+# `f <= finit + stp * gtest` decided by the last bits of f -- and ends on the reference's point all the same (finals
+# 1e-14 apart).  (Rounds 2 - 4, default contraction: 40 / 35 evaluations, finals 1.3e-4 apart, and the 331-evaluation
+# M = 21 run g3_trace_once_M21_c0 left the reference's path around evaluation 134; it is followed to the end now.)
 KNOWN_PARTED = {
-    "g3_trace_replan_s4.npz": dict(x_rel_max=2e-4, cost_rel_max=1e-5, nfev=(40, 37)),
-    "g3_trace_replan_s5.npz": dict(x_rel_max=2e-4, cost_rel_max=1e-5, nfev=(35, 39)),
-    # a converging M = 21 run of 331 evaluations, far beyond the horizon over which ANY two implementations stay together
-    # (the product's own L-BFGS-B on the host, with a bit-identical objective, leaves SciPy's path at evaluation ~134:
-    # tests/test_lbfgs_host.py LONG_RUNS).  Asserted: the device follows the reference's recorded evaluations for at least
-    # the first 100 (test_parted_runs_first_divergence) and converges to a comparable minimum.
-    "g3_trace_once_M21_c0.npz": dict(x_rel_max=1e-1, cost_rel_max=5e-2, long_run=True),
+    "g3_trace_replan_s4.npz": dict(x_rel_max=1e-9, cost_rel_max=1e-9),
+    "g3_trace_replan_s5.npz": dict(x_rel_max=1e-9, cost_rel_max=1e-9),
 }
 
 

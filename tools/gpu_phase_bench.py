@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""timing experiments on a GPU box: per-evaluation cost of the phases of eval_kernel at cfg2"""
+"""timing experiments on a GPU box: per-evaluation cost of the phases of eval_kernel at cfg2
+(the phase switches exist only in -DNEO_EXPERIMENTS builds: NEO_BUILD_DEFS=-DNEO_EXPERIMENTS NEO_BUILD_OUT=<lib> python -m
+neo_planner_amd.build, then NEO_PLANNER_LIB=<lib>; with the product library every row times the full kernel)"""
 import ctypes, os, sys, time
 os.environ.setdefault("OMP_NUM_THREADS", "1")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -4,6 +4,7 @@
 
     python3 tools/probe/phase_counts.py gpurun_out/phase_counts
 
+Needs a -DNEO_EXPERIMENTS build of the library (NEO_PLANNER_LIB): the product's kernels have no phase switches.
 The differences to the full kernel price the phases (the runs with a phase off optimise garbage, so line-search
 lengths shift a little: read the numbers as estimates)."""
 import csv, glob, json, os, subprocess, sys

@@ -269,6 +269,13 @@ def g6_device_side(d, modes=MODES, limit=None):
                          x_rel_median=float(np.median(dx)), cost_rel_median=float(np.median(rc)),
                          mean_nfev=float(nfev[sel].mean()),
                          median_final_cost=float(np.median(cost[sel])), reference_median_final_cost=float(np.median(fb[sel])),
+                         # run by run: final cost over the reference's (1 = the same solution; the optimiser is a descent
+                         # method on a non-convex objective: runs that part from the reference's path end in another local
+                         # minimum, better or worse)
+                         cost_ratio_quantiles={q: float(np.quantile(cost[sel] / fb[sel], q / 100.0)) for q in (5, 25, 50, 75, 95)},
+                         cost_ratio_log_mean=float(np.mean(np.log(cost[sel] / fb[sel]))),
+                         frac_cost_above_reference_by_1e_3=float((cost[sel] > fb[sel] * (1 + 1e-3)).mean()),
+                         frac_cost_below_reference_by_1e_3=float((cost[sel] < fb[sel] * (1 - 1e-3)).mean()),
                          same_exception=float(np.mean([errs[k].split(":")[0] == eb[k].split(":")[0] for k in np.flatnonzero(run)])),
                          exceptions=_hist([errs[k] for k in np.flatnonzero(run)]),
                          exits=_hist_codes([codes[k] for k in np.flatnonzero(run)]))
