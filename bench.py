@@ -325,6 +325,12 @@ def compact_line(out, details_path=None):
         # the mode that computes in the reference's own arithmetic and meets its 1e-4 as often as the reference meets itself
         line["value_parity_mode"] = modes["f64"].get("value")
     line.update(_pick(out, ("accepted_traj_per_s", "accepted_frac", "single_batch_ms", "single_batch_traj_per_s")))
+    sb = out.get("single_batch_budget")
+    if sb and sb.get("budgets"):
+        b0 = sb["budgets"][0]
+        line["single_batch_budget"] = dict(_pick(b0, ("budget", "first_launch_ms", "all_done_ms", "done_after_first_launch",
+                                                        "bit_identical_to_the_unbudgeted_launch")),
+                                           unbudgeted_ms=sb.get("unbudgeted_ms"))
     retries = out.get("accepted_after_retries")
     if retries:
         line["accepted_after_retries_traj_per_s"] = retries.get("accepted_after_retries_traj_per_s")
@@ -377,7 +383,7 @@ def compact_line(out, details_path=None):
     line = _r(line)
     s = json.dumps(line, separators=(",", ":"))
     # belt and braces: drop optional blocks, last first, until the line fits
-    for k in ("cfg1", "esdf_build", "cpu_native", "per_rank_traj_per_s", "accepted_after_retries_traj_per_s"):
+    for k in ("cfg1", "esdf_build", "cpu_native", "single_batch_budget", "per_rank_traj_per_s", "accepted_after_retries_traj_per_s"):
         if len(s) <= LINE_LIMIT:
             break
         line.pop(k, None)

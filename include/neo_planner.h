@@ -57,6 +57,7 @@ enum {
   NEO_TRAJ_NUMERIC_RANGE = 4,    /* exp(-tau) overflow: the reference raises OverflowError (:481)            */
   NEO_TRAJ_NONFINITE = 5,        /* NaN/Inf objective                                                         */
   NEO_TRAJ_BAD_SCENE = 6,        /* its map-table slot is outside the table (neo_optimize_batch_dev): left untouched */
+  NEO_TRAJ_SUSPENDED = 7,        /* out of its launch's evaluation budget (neo_optimize_batch_budget_dev): resumable */
 };
 /* OR-ed into the code above when weighted collision cost > collision_cost_tol
  * (expert_planner.py:235-237 raises ValueError("collision cost too large")). */
@@ -242,6 +243,26 @@ int neo_optimize_batch_from_dev(neo_ctx *ctx, int scene_id, const int32_t *scene
                                 int D, const double *x0, double *x, const double *head,
                                 const double *tail, double *costs4, double *costs4_last, int32_t *nit,
                                 int32_t *nfev, int32_t *status);
+/* ---- launches with an evaluation budget (round 5) ----------------------------
+ * The duration of one launch is the duration of its LONGEST run (cfg2: 633 evaluations against a mean of 135), which the
+ * other trajectories' results wait for.  neo_optimize_batch_budget_dev is neo_optimize_batch_from_dev for ONE scene with
+ * a cap on the evaluations a trajectory may make IN THIS LAUNCH: a run that needs more is suspended -- status
+ * NEO_TRAJ_SUSPENDED, its complete optimiser state (iterate, gradient, direction, line-search interval, the stored
+ * pairs) in state[b] -- and a later launch with resume != 0 continues it exactly where it stopped: the finished run is
+ * bit for bit the run of an unbudgeted launch (tests/test_gpu_budget.py).  The reference's own caps keep their meaning:
+ * maxiter / maxfun of expert_planner.py:213-225 count over all launches of a run (NEO_TRAJ_MAXITER).
+ *   state      DEVICE buffer of B * neo_optimize_state_bytes(M, D) bytes, the caller's, kept between the launches of a run
+ *   subset     optional DEVICE array of n_subset trajectory indices (each < B): only these are launched -- the compacted
+ *              re-launch of the stragglers; NULL = all B.  Arrays are always indexed by trajectory, never by position
+ *   resume     0: the launched trajectories start from x0; 1: those among them with status NEO_TRAJ_SUSPENDED continue
+ *              from state, the others are left untouched
+ * A suspended trajectory's x holds the point it evaluates next, costs4 the terms at its last iterate, nit / nfev its
+ * counts so far.  3-D fp32 fields in the linear or brick layout, n <= 128 variables, every arithmetic mode. */
+size_t neo_optimize_state_bytes(int M, int D);
+int neo_optimize_batch_budget_dev(neo_ctx *ctx, int scene_id, int B, int M, int D, const double *x0, double *x,
+                                  const double *head, const double *tail, double *costs4, double *costs4_last,
+                                  int32_t *nit, int32_t *nfev, int32_t *status, void *state, int eval_budget,
+                                  const int32_t *subset, int n_subset, int resume);
 /* slot of a scene in the device-side map table, -1 if it has no map.  Slots change
  * whenever a map is uploaded or dropped. */
 int neo_scene_slot(neo_ctx *ctx, int scene_id);

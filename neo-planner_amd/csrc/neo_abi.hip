@@ -1575,6 +1575,46 @@ int neo_optimize_batch_from_dev(neo_ctx *c, int scene_id, const int32_t *scene_i
   return NEO_OK;
 }
 
+size_t neo_optimize_state_bytes(int M, int D) {
+  if (M < 1 || D < 1) return 0;
+  return opt_state_doubles(D * (M - 1) + M, NEO_LBFGS_M) * sizeof(double);
+}
+
+int neo_optimize_batch_budget_dev(neo_ctx *c, int scene_id, int B, int M, int D, const double *x0, double *x, const double *head,
+                                  const double *tail, double *costs4, double *costs4_last, int32_t *nit, int32_t *nfev,
+                                  int32_t *status, void *state, int eval_budget, const int32_t *subset, int n_subset,
+                                  int resume) {
+  int rc = check_shape(c, B, M, D);
+  if (rc) return rc;
+  if (!x0 || !x || !head || !tail || !costs4 || !nit || !nfev || !status || !state)
+    return fail_locked(c, NEO_ERR_INVALID, "null buffer");
+  if (eval_budget < 1) return fail_locked(c, NEO_ERR_INVALID, "eval_budget < 1");
+  if (subset && (n_subset < 0 || n_subset > B)) return fail_locked(c, NEO_ERR_INVALID, "bad subset size");
+  std::lock_guard<std::recursive_mutex> g(c->mu);
+  hipSetDevice(c->device);
+  if (B == 0 || (subset && n_subset == 0)) return NEO_OK;
+  rc = rebuild_tables(c);
+  if (rc) return rc;
+  auto it = c->maps.find(scene_id);
+  if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for this scene");
+  if (it->second.kind == 0 || D != 3) return fail(c, NEO_ERR_INVALID, "budgeted launches: 3-D fields, D = 3");
+  if (c->trace || c->trace_xg) return fail(c, NEO_ERR_INVALID, "budgeted launches do not record traces");
+  const char *base = static_cast<const char *>(c->table3d);
+  const void *table = base + (size_t)it->second.slot * sizeof(Map3D);
+  ProfScope ps(c, NEO_KERNEL_OPTIMIZE);
+  OptArgs oa{B, M, table, nullptr, 1, x0, x, head, tail, costs4, costs4_last, nit, nfev, status};
+  oa.state = static_cast<double *>(state);
+  oa.state_doubles = (int)opt_state_doubles(D * (M - 1) + M, NEO_LBFGS_M);
+  oa.budget = eval_budget;
+  oa.resume = resume ? 1 : 0;
+  oa.subset = subset;
+  oa.n_subset = subset ? n_subset : 0;
+  rc = launch_opt_3d_budget(c, it->second.elem, it->second.m3.layout, oa);
+  if (rc) return rc;
+  HIPCHK(c, hipGetLastError());
+  return NEO_OK;
+}
+
 int neo_scene_slot(neo_ctx *c, int scene_id) {
   if (!c) return -1;
   std::lock_guard<std::recursive_mutex> g(c->mu);

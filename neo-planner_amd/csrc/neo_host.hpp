@@ -143,6 +143,13 @@ struct OptArgs {
   const double *head, *tail;
   double *costs4, *costs4_last;
   int *nit, *nfev, *status;
+  // budgeted launches (neo_optimize_batch_budget_dev); all zero otherwise
+  double *state = nullptr;       // [B][state_doubles] optimiser state of suspended runs
+  int state_doubles = 0;
+  int budget = 0;                // evaluations per trajectory and launch
+  int resume = 0;                // continue suspended runs instead of starting from x0
+  const int *subset = nullptr;   // device array of n_subset trajectory indices: launch these only (workgroup i -> subset[i])
+  int n_subset = 0;
 };
 
 struct SampleArgs {
@@ -169,6 +176,7 @@ int launch_opt_3d_w2(neo_ctx *c, int elem, int layout, const OptArgs &a);   // n
 int launch_opt_3d_x(neo_ctx *c, int elem, int layout, const OptArgs &a);    // neo_disp_opt3d_x.hip
 int launch_opt_groups(neo_ctx *c, int elem, int layout, const OptArgs &a);  // neo_disp_group.hip
 int launch_opt_3d_f64_w2(neo_ctx *c, int elem, int layout, const OptArgs &a);
+int launch_opt_3d_budget(neo_ctx *c, int elem, int layout, const OptArgs &a);  // neo_disp_opt3d_b.hip
 int launch_opt_2d_w2(neo_ctx *c, bool f32, const OptArgs &a);
 int launch_opt_2d_x(neo_ctx *c, int D, const OptArgs &a);                   // neo_disp_opt2d_x.hip (all-fp32 mode)
 int launch_opt_groups_2d(neo_ctx *c, bool f32, const OptArgs &a);           // neo_disp_group.hip (D = 2, nearest-cell map)

@@ -72,6 +72,7 @@ template <int D, int NS, typename Real, class MapT, class LookupT, int SU = NEO_
           bool PAIRS32 = false, typename Num = double>
 struct DevBackend {
   static constexpr int DL = LG::dl(D);
+  static constexpr int kSlotsN = NS;  // FLAT slots of a Vec
   // joint systems by parallel cyclic reduction in the all-fp32 mode (neo_device.hpp pcr_solve).  Block Thomas wherever the
   // solve is fp64: the parity mode's recorded runs are pinned to its rounding, and in the mixed mode the reduction was
   // measured SLOWER (fp64: 744 k against 778 k traj/s at cfg2, 142 k against 156 k at cfg5 -- five levels of 63 fp64
@@ -362,6 +363,87 @@ struct DevBackend {
   }
 };
 
+// ------------------------------------------------------------------ suspended runs (neo_optimize_batch_budget_dev)
+// A launch with an evaluation budget stops a run that needs more: everything the optimiser carries between two
+// evaluations -- the machine's vectors and scalars, the line search, the stored pairs and their rho, the cost terms --
+// goes to `st` (doubles: every fp32 value converts exactly both ways) and a later launch picks the run up at the very
+// evaluation it was about to make.  Layout: [64 scalars | x g t r d (n each) | rho / alpha lanes (64) | pairs (2 m n)].
+__host__ __device__ inline size_t opt_state_doubles(int n, int m) { return 64 + 5 * (size_t)n + kWave + 2 * (size_t)m * (size_t)n; }
+
+template <class BE, class Mach>
+__device__ __forceinline__ void save_run(BE &be, const Mach &mc, double *st) {
+  const int lane = lane_id(), n = be.t.n;
+  lds_wave_sync();
+  if (lane == 0) {
+    const int iv[9] = {mc.phase, mc.status, mc.nfev, mc.nit, mc.iter, mc.col, mc.head, mc.task, mc.ifun};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) st[k] = (double)iv[k];
+    const double dv[7] = {mc.f, mc.fold, mc.stp, mc.gd, mc.gdold, mc.theta, mc.stp_evaluated};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) st[9 + k] = dv[k];
+    st[16] = (double)be.samples;
+    st[17] = (double)be.last_ns;
+    const LineSearch &L = *be.lsp;
+    const double lv[20] = {L.ftol, L.gtol, L.xtol, L.stpmin, L.stpmax, (double)L.brackt, (double)L.stage, L.ginit, L.gtest, L.gx,
+                           L.gy, L.finit, L.fx, L.fy, L.stx, L.sty, L.stmin, L.stmax, L.width, L.width1};
+#pragma unroll
+    for (int k = 0; k < 20; ++k) st[20 + k] = lv[k];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) st[40 + k] = be.cst[k];
+  }
+  double *v = st + 64;
+#pragma unroll
+  for (int k = 0; k < BE::kSlotsN; ++k)
+    if (k * kWave + lane < n) {
+      const int e = k * kWave + lane;
+      v[e] = (double)mc.x.v[k];
+      v[n + e] = (double)mc.g.v[k];
+      v[2 * n + e] = (double)mc.t.v[k];
+      v[3 * n + e] = (double)mc.r.v[k];
+      v[4 * n + e] = (double)mc.d.v[k];
+    }
+  v[5 * n + lane] = (double)be.sreg;
+  double *h = v + 5 * n + kWave;
+  for (int i = lane; i < 2 * be.m * n; i += kWave) h[i] = (double)be.hist[i];
+}
+
+template <class BE, class Mach>
+__device__ __forceinline__ void load_run(BE &be, Mach &mc, const double *st) {
+  using Num = decltype(be.sreg);
+  const int lane = lane_id(), n = be.t.n;
+  auto iu = [&](int k) { return (int)uniform(st[k]); };
+  mc.phase = iu(0); mc.status = iu(1); mc.nfev = iu(2); mc.nit = iu(3); mc.iter = iu(4);
+  mc.col = iu(5); mc.head = iu(6); mc.task = iu(7); mc.ifun = iu(8);
+  mc.f = uniform(st[9]); mc.fold = uniform(st[10]); mc.stp = uniform(st[11]); mc.gd = uniform(st[12]);
+  mc.gdold = uniform(st[13]); mc.theta = uniform(st[14]); mc.stp_evaluated = uniform(st[15]);
+  be.samples = (long long)uniform(st[16]);
+  be.last_ns = iu(17);
+  if (lane == 0) {
+    LineSearch &L = *be.lsp;
+    L.ftol = st[20]; L.gtol = st[21]; L.xtol = st[22]; L.stpmin = st[23]; L.stpmax = st[24];
+    L.brackt = (int)st[25]; L.stage = (int)st[26];
+    L.ginit = st[27]; L.gtest = st[28]; L.gx = st[29]; L.gy = st[30]; L.finit = st[31]; L.fx = st[32]; L.fy = st[33];
+    L.stx = st[34]; L.sty = st[35]; L.stmin = st[36]; L.stmax = st[37]; L.width = st[38]; L.width1 = st[39];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) be.cst[k] = st[40 + k];
+  }
+  const double *v = st + 64;
+#pragma unroll
+  for (int k = 0; k < BE::kSlotsN; ++k) {
+    const int e = k * kWave + lane;
+    const bool in = e < n;
+    mc.x.v[k] = in ? (Num)v[e] : Num(0);
+    mc.g.v[k] = in ? (Num)v[n + e] : Num(0);
+    mc.t.v[k] = in ? (Num)v[2 * n + e] : Num(0);
+    mc.r.v[k] = in ? (Num)v[3 * n + e] : Num(0);
+    mc.d.v[k] = in ? (Num)v[4 * n + e] : Num(0);
+  }
+  be.sreg = (Num)v[5 * n + lane];
+  const double *h = v + 5 * n + kWave;
+  for (int i = lane; i < 2 * be.m * n; i += kWave) be.hist[i] = (typename BE::Hist)h[i];
+  lds_wave_sync();
+}
+
 // bnd_lds: 6 * D elements of LDS for the layouts with one dimension per lane (stage_boundary), unused otherwise
 template <class LG = WaveLanes, int D, int DL, typename Num>
 __device__ __forceinline__ void load_boundary(Traj<D, DL, Num> &t, const double *head, const double *tail, int M,
@@ -439,7 +521,11 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
 // Dynamic LDS (launch parameter): `stage` doubles of staging (DevBackend::xs) followed by the 2 * maxcor * n doubles of
 // the L-BFGS pairs.  The launcher gives the staging its full size (room for the rows of the per-piece fold) unless that
 // would cost a wavefront of occupancy -- then NS * 64 doubles, and the fold runs in registers.
-template <int D, int NS, typename Real, class MapT, class LookupT, int WAVES, class LG = WaveLanes, typename Num = double>
+// BUDGET (neo_optimize_batch_budget_dev; instantiated in neo_disp_opt3d_b.hip only): a run that has not terminated after
+// `budget` evaluations in this launch is suspended -- its state to `state`, status NEO_TRAJ_SUSPENDED -- and a launch
+// with `resume` set continues the suspended runs of its trajectories (the others it leaves untouched).
+template <int D, int NS, typename Real, class MapT, class LookupT, int WAVES, class LG = WaveLanes, typename Num = double,
+          bool BUDGET = false>
 __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ? NEO_X_OCC : NEO_W2_OCC) : 1)) void optimize_kernel(int B, int M, DevParams prm, const MapT *maps,
                                                           const int *__restrict__ scene_slot, int nmaps,
                                                           const double *x0, double *x,
@@ -451,7 +537,8 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
                                                           int *__restrict__ status,
                                                           long long *__restrict__ nsamples,
                                                           const int *__restrict__ order, double *__restrict__ trace,
-                                                          double *__restrict__ trace_xg, int trace_cap, int stage, int pcr_off) {
+                                                          double *__restrict__ trace_xg, int trace_cap, int stage, int pcr_off,
+                                                          double *state, int state_doubles, int budget, int resume) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
   __shared__ double sc[2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm;
@@ -515,13 +602,36 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   // lbfgs_minimize) -- ONE inlined copy of the evaluation instead of two: 36 % less code and no spills in the cfg2
   // two-waves kernel.  Four FLAT slots (n > 128, cfg5): the compiler keeps the machine's vectors in private memory
   // (1 KB of scratch, 3x slower), so those instantiations run the straight-line form.
+  bool suspended = false;
   if constexpr (NS <= NEO_SM_MAX_SLOTS) {
     LbfgsMachine<BE> mach(be, o);
-    mach.x = xv;
-    mach.begin();
-    while (mach.need_eval()) {
-      const int est = be.eval(mach.x, mach.f, mach.g, mach.costs());
-      mach.advance(est);
+    if constexpr (BUDGET) {
+      double *st = state + (size_t)b * (size_t)state_doubles;
+      if (resume) {
+        if (status[b] != NEO_TRAJ_SUSPENDED) return;  // (finished in an earlier launch: its results stay as they are)
+        load_run(be, mach, st);
+      } else {
+        mach.x = xv;
+        mach.begin();
+      }
+      int evals = 0;
+      while (mach.need_eval()) {
+        if (evals >= budget) {
+          save_run(be, mach, st);
+          suspended = true;
+          break;
+        }
+        const int est = be.eval(mach.x, mach.f, mach.g, mach.costs());
+        mach.advance(est);
+        ++evals;
+      }
+    } else {
+      mach.x = xv;
+      mach.begin();
+      while (mach.need_eval()) {
+        const int est = be.eval(mach.x, mach.f, mach.g, mach.costs());
+        mach.advance(est);
+      }
     }
     mach.result(res);
     xv = mach.x;
@@ -544,6 +654,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
     int st = res.status;
     // weighted collision cost of the last evaluated x against the tolerance (:233-237)
     if (res.costs_last[3] * prm.w[3] > prm.coll_tol) st |= NEO_TRAJ_FLAG_COLLISION;
+    if (suspended) st = NEO_TRAJ_SUSPENDED;  // (x = the point the run evaluates next, costs4 = the terms at its last iterate)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       costs4[(size_t)b * 4 + k] = res.costs[k];

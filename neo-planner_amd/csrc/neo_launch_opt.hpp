@@ -6,9 +6,12 @@
 namespace neo {
 
 // Num = float: the all-fp32 mode (NEO_FLAG_F32_SOLVE) -- solve, adjoint and optimiser vectors in fp32, pairs in fp32
-template <int D, typename Real, class MapT, class LookupT, int WAVES = 1, typename Num = double>
+template <int D, typename Real, class MapT, class LookupT, int WAVES = 1, typename Num = double, bool BUDGET = false>
 int launch_opt(neo_ctx *c, const OptArgs &a) {
-  const dim3 grid(a.B), blk(kWave);
+  // (a budgeted launch may cover a subset of the batch: workgroup i then works on trajectory subset[i])
+  const int n_launch = a.subset ? a.n_subset : a.B;
+  const int *launch_order = a.subset ? a.subset : (c->order_B == a.B ? c->dispatch_order : nullptr);
+  const dim3 grid(n_launch), blk(kWave);
   const size_t pair_elems = (size_t)2 * NEO_LBFGS_M * (D * (a.M - 1) + a.M);  // L-BFGS pairs in LDS
   // staging in front of the pairs: the full size (with the rows of the per-piece fold) unless that costs the two-waves
   // variant occupancy -- eight wavefronts per CU want 160 KB / 8 each, less ~0.5 KB of static LDS.  The one-wave
@@ -34,11 +37,12 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
         dyn = need;                                                                                           \
       }                                                                                                       \
     }                                                                                                         \
-    hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES, LG, Num>), grid, blk,                   \
-                       dyn, c->stream, a.B, a.M, c->dev,                                                      \
+    hipLaunchKernelGGL((optimize_kernel<D, NS, Real, MapT, LookupT, WAVES, LG, Num, BUDGET>), grid, blk,           \
+                       dyn, c->stream, n_launch, a.M, c->dev,                                                 \
                        static_cast<const MapT *>(a.table), a.slots, a.nmaps, a.x0 ? a.x0 : a.x, a.x, a.head, a.tail, a.costs4,   \
                        a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter,                             \
-                       (c->order_B == a.B ? c->dispatch_order : nullptr), c->trace, c->trace_xg, c->trace_cap, stage, pcr_off); \
+                       launch_order, c->trace, c->trace_xg, c->trace_cap, stage, pcr_off, a.state, a.state_doubles,  \
+                       a.budget, a.resume);                                                                   \
   } while (0)
   // lane = (piece, dimension) whenever D * M fits the wavefront (cfg2: 63 lanes busy in the PIECE-layout phases
   // instead of 21, a third of the per-dimension state per lane); lane = piece otherwise.  flags bit 512 forces the
@@ -51,6 +55,14 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
     else                                 \
       NEO_OPT_LG(NS, WaveLanes);         \
   } while (0)
+  if constexpr (BUDGET) {
+    // the resumable form of the run exists for n <= 128 variables (neo_kernels.hpp NEO_SM_MAX_SLOTS)
+    switch (slots_for(a.M, D)) {
+      case 1: NEO_OPT(1); return NEO_OK;
+      case 2: NEO_OPT(2); return NEO_OK;
+      default: return fail(c, NEO_ERR_INVALID, "budgeted launches: n <= 128 variables");
+    }
+  }
   switch (slots_for(a.M, D)) {
     case 1: NEO_OPT(1); break;
     case 2: NEO_OPT(2); break;

@@ -14,7 +14,7 @@ NEO_F64, NEO_F32, NEO_F16 = 0, 1, 2
 NEO_LAYOUT_LINEAR, NEO_LAYOUT_YZ4, NEO_LAYOUT_CELL8, NEO_LAYOUT_BRICK = 0, 1, 2, 3
 LAYOUTS = {"linear": NEO_LAYOUT_LINEAR, "yz4": NEO_LAYOUT_YZ4, "cell8": NEO_LAYOUT_CELL8, "brick": NEO_LAYOUT_BRICK}
 NEO_TRAJ_CONVERGED_GRAD, NEO_TRAJ_CONVERGED_F, NEO_TRAJ_ABNORMAL = 0, 1, 2
-NEO_TRAJ_MAXITER, NEO_TRAJ_NUMERIC_RANGE, NEO_TRAJ_NONFINITE, NEO_TRAJ_BAD_SCENE = 3, 4, 5, 6
+NEO_TRAJ_MAXITER, NEO_TRAJ_NUMERIC_RANGE, NEO_TRAJ_NONFINITE, NEO_TRAJ_BAD_SCENE, NEO_TRAJ_SUSPENDED = 3, 4, 5, 6, 7
 NEO_TRAJ_FLAG_COLLISION = 0x100
 NEO_EDT_GENERIC_LINES = 1
 NEO_KERNEL_EVAL, NEO_KERNEL_OPTIMIZE, NEO_KERNEL_ESDF_BUILD, NEO_KERNEL_ESDF_SAMPLE = 0, 1, 2, 3
@@ -32,7 +32,7 @@ EXPORTS = [
     "neo_sampled_terms_batch", "neo_sampled_terms_batch_dev", "neo_esdf_build_3d",
     "neo_optimize_dispatch_order_host", "neo_ctx_set_stream", "neo_optimize_trace",
     "neo_optimize_batch_from_dev", "neo_optimize_trace_xg", "neo_sampled_terms_dispatch_order",
-    "neo_esdf_build_config", "neo_pack_results_dev",
+    "neo_esdf_build_config", "neo_pack_results_dev", "neo_optimize_state_bytes", "neo_optimize_batch_budget_dev",
 ]
 
 
@@ -105,6 +105,9 @@ def load():
     L.neo_sampled_terms_dispatch_order.argtypes = [c_p, c_p, c_i, c_i]
     L.neo_esdf_build_config.argtypes = [c_p, c_i]
     L.neo_pack_results_dev.argtypes = [c_p, c_i, c_i, c_p, c_p, c_p, c_p]
+    L.neo_optimize_state_bytes.argtypes = [c_i, c_i]
+    L.neo_optimize_state_bytes.restype = ctypes.c_size_t
+    L.neo_optimize_batch_budget_dev.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 10 + [c_i, c_p, c_i, c_i]
     L.neo_sampled_terms_batch.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 5
     L.neo_sampled_terms_batch_dev.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 5
     for name in EXPORTS:
@@ -133,6 +136,7 @@ class Context:
     def __init__(self, device=0, stream=None):
         self.lib = load()
         h = ctypes.c_void_p()
+        self.device = int(device)
         rc = self.lib.neo_ctx_create(int(device), ctypes.c_void_p(stream) if stream else None, ctypes.byref(h))
         if rc != NEO_OK:
             raise NeoError(f"neo_ctx_create(device={device}) failed with {rc}: no usable MI355X? "

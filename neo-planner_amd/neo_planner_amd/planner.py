@@ -501,6 +501,60 @@ class BatchPlanner:
         return dict(x=x, costs=costs, costs_last=last, nit=nit, nfev=nfev, status=st & 0xff,
                     collision=(st & _lib.NEO_TRAJ_FLAG_COLLISION) != 0, final_cost=(costs * w).sum(axis=1))
 
+    def optimize_budgeted_dev(self, map, x0, x, head, tail, costs, costs_last, nit, nfev, status, state, eval_budget,
+                              max_launches=4096):
+        """optimize_dev with an evaluation budget per launch (neo_optimize_batch_budget_dev): the first launch gives every
+        trajectory `eval_budget` evaluations, then the trajectories still running (status NEO_TRAJ_SUSPENDED) are
+        re-launched COMPACTED -- one workgroup per straggler -- until none is left.  Finished results are valid as soon as
+        their launch has ended; the finals are bit for bit those of `optimize_dev`.  torch CUDA tensors; `state` a uint8
+        tensor of B * neo_optimize_state_bytes(M, D) bytes.  Returns the launch sizes."""
+        import torch
+        self._sync()
+        c = self.ctx
+        B, n = x.shape
+        D = head.shape[2]
+        M = (n + D) // (D + 1)
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())
+        sizes = []
+        subset, resume = None, 0
+        for _ in range(max_launches):
+            c.check(c.lib.neo_optimize_batch_budget_dev(
+                c.h, map.scene_id, B, M, D, pp(x0), pp(x), pp(head), pp(tail), pp(costs), pp(costs_last), pp(nit), pp(nfev),
+                pp(status), pp(state), int(eval_budget), None if subset is None else pp(subset),
+                0 if subset is None else int(subset.numel()), resume))
+            sizes.append(B if subset is None else int(subset.numel()))
+            c.synchronize()
+            # (the statuses decide the next launch: this is the host round trip a budget costs)
+            subset = torch.nonzero(status == _lib.NEO_TRAJ_SUSPENDED).flatten().to(torch.int32)
+            resume = 1
+            if subset.numel() == 0:
+                return sizes
+        raise RuntimeError(f"{int(subset.numel())} trajectories still suspended after {max_launches} launches")
+
+    def optimize_budgeted(self, map, x0, head, tail, eval_budget):
+        """host-array form of optimize_budgeted_dev: the dict of `optimize` plus `launch_sizes`"""
+        import torch
+        c = self.ctx
+        dev = torch.device("cuda", c.device)
+        x0 = _lib.as_f64(x0); head = _lib.as_f64(head); tail = _lib.as_f64(tail)
+        B, n = x0.shape
+        D = head.shape[2]
+        M = (n + D) // (D + 1)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        d_x0, d_h, d_t = t(x0), t(head), t(tail)
+        d_x = torch.empty_like(d_x0)
+        costs = torch.zeros(B, 4, dtype=torch.float64, device=dev); last = torch.zeros_like(costs)
+        nit = torch.zeros(B, dtype=torch.int32, device=dev); nfev = torch.zeros_like(nit); st = torch.zeros_like(nit)
+        state = torch.empty(B * int(c.lib.neo_optimize_state_bytes(M, D)), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)        # (the context has its own stream: the buffers above are ready before it starts)
+        sizes = self.optimize_budgeted_dev(map, d_x0, d_x, d_h, d_t, costs, last, nit, nfev, st, state, eval_budget)
+        stn = st.cpu().numpy()
+        w = np.asarray(self.cfg.weights, dtype=np.float64)
+        cn_ = costs.cpu().numpy()
+        return dict(x=d_x.cpu().numpy(), costs=cn_, costs_last=last.cpu().numpy(), nit=nit.cpu().numpy(), nfev=nfev.cpu().numpy(),
+                    status=stn & 0xff, collision=(stn & _lib.NEO_TRAJ_FLAG_COLLISION) != 0, final_cost=(cn_ * w).sum(axis=1),
+                    launch_sizes=sizes)
+
     def init_guess(self, head, tail, count, rng=None, noise=0.0):
         """generate_init_variables (:82-101) for a batch: `count` waypoints on the straight line from start to target,
         durations init_T with the first and last piece 1.5 times as long; noise > 0 adds the N(0, noise) jitter of the

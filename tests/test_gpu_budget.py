@@ -1,0 +1,91 @@
+"""
+Launches with an evaluation budget and resumable runs (include/neo_planner.h
+neo_optimize_batch_budget_dev): a trajectory that needs more evaluations than its launch allows is suspended with its
+whole optimiser state and finished by later, compacted launches.  The bar: for EVERY trajectory the finished run is the
+run of an unbudgeted launch, bit for bit -- x, both sets of cost terms, iteration and evaluation counts, status and the
+collision flag -- whatever the budget, in every arithmetic mode.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import neo_planner_amd as npa
+from neo_planner_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(layout):
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx = _lib.Context(0)
+    dist = synth.esdf_3d(4, n=100, res=0.3, canopy=20)
+    g3 = npa.ESDF3D(torch.from_numpy(dist).to(dev), 0.3, synth.DOMAIN_ORIGIN, store="f32", layout=layout, ctx=ctx)
+    return ctx, g3
+
+
+@pytest.mark.parametrize("mode,layout", [("f32x", "brick"), ("f64", "brick"), ("f32", "linear")])
+def test_budgeted_runs_are_the_unbudgeted_runs_bit_for_bit(mode, layout):
+    ctx, g3 = _scene(layout)
+    B, M = 700, 21
+    head, tail, wp, ts = synth.replan_requests(21, B, M - 1, D=3, **synth.VOLUME)
+    bp = npa.BatchPlanner(ctx=ctx, sample_dtype=mode)
+    x0 = bp.pack_x(wp, ts)
+    ref = bp.optimize(g3, x0, head, tail, order=False)
+    assert ref["nfev"].max() > 150 and (ref["status"] <= 2).mean() > 0.8
+    for budget in (3, 17, 120, 100000):
+        got = bp.optimize_budgeted(g3, x0, head, tail, budget)
+        for k in ("x", "costs", "costs_last", "nit", "nfev", "status", "collision"):
+            assert np.array_equal(got[k], ref[k]), (mode, budget, k, int((got[k] != ref[k]).sum()))
+        sizes = got["launch_sizes"]
+        assert sizes[0] == B and all(a >= b for a, b in zip(sizes, sizes[1:]))           # compacted re-launches
+        if budget >= 100000:
+            assert sizes == [B]
+        else:
+            # a run of nfev evaluations takes ceil(nfev / budget) launches; launch k + 1 holds the runs that need more than k
+            need = -(-ref["nfev"].astype(np.int64) // budget)
+            assert len(sizes) == int(need.max())
+            assert sizes == [int((need > k).sum()) for k in range(len(sizes))]
+
+
+def test_budget_api_edges():
+    import torch
+    ctx, g3 = _scene("brick")
+    dev = torch.device("cuda", 0)
+    B, M, D = 64, 21, 3
+    head, tail, wp, ts = synth.replan_requests(5, B, M - 1, D=3, **synth.VOLUME)
+    bp = npa.BatchPlanner(ctx=ctx, sample_dtype="f32x")
+    bp._sync()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x0 = t(bp.pack_x(wp, ts)); x = torch.empty_like(x0); h = t(head); tl = t(tail)
+    costs = torch.zeros(B, 4, dtype=torch.float64, device=dev); last = torch.zeros_like(costs)
+    nit = torch.zeros(B, dtype=torch.int32, device=dev); nfev = torch.zeros_like(nit); st = torch.full_like(nit, -1)
+    nbytes = int(ctx.lib.neo_optimize_state_bytes(M, D))
+    assert nbytes == 8 * (64 + 5 * 81 + 64 + 2 * 10 * 81)
+    state = torch.zeros(B * nbytes, dtype=torch.uint8, device=dev)
+    pp = lambda v: ctypes.c_void_p(v.data_ptr())
+    call = lambda budget, subset, n_sub, resume: ctx.lib.neo_optimize_batch_budget_dev(
+        ctx.h, g3.scene_id, B, M, D, pp(x0), pp(x), pp(h), pp(tl), pp(costs), pp(last), pp(nit), pp(nfev), pp(st), pp(state),
+        budget, None if subset is None else pp(subset), n_sub, resume)
+    torch.cuda.synchronize()
+    assert call(0, None, 0, 0) != 0                                   # a budget below one evaluation
+    # a subset launch touches its trajectories only
+    sub = torch.tensor([3, 40, 7], dtype=torch.int32, device=dev)
+    assert call(5, sub, 3, 0) == 0
+    ctx.synchronize()
+    s = st.cpu().numpy()
+    assert set(np.flatnonzero(s != -1).tolist()) == {3, 7, 40}
+    assert np.all(s[[3, 7, 40]] == _lib.NEO_TRAJ_SUSPENDED) and np.all(nfev.cpu().numpy()[[3, 7, 40]] == 5)
+    # resuming launches continue the suspended ones and leave every other trajectory alone
+    assert call(100000, None, 0, 1) == 0
+    ctx.synchronize()
+    s = st.cpu().numpy()
+    assert set(np.flatnonzero(s != -1).tolist()) == {3, 7, 40} and np.all((s[[3, 7, 40]] & 0xff) <= 3)
+    ref = bp.optimize(g3, bp.pack_x(wp, ts), head, tail, order=False)
+    assert np.array_equal(x.cpu().numpy()[[3, 7, 40]], ref["x"][[3, 7, 40]])
+    # n > 128 variables and 2-D maps have no resumable kernel: refused, nothing launched
+    m2 = npa.ESDF(ctx=ctx)
+    m2.occupancy_map_cb(synth.OccupancyGridMsg(synth.occupancy_2d(1)))
+    assert ctx.lib.neo_optimize_batch_budget_dev(ctx.h, m2.scene_id, B, M, D, pp(x0), pp(x), pp(h), pp(tl), pp(costs), pp(last),
+                                                 pp(nit), pp(nfev), pp(st), pp(state), 5, None, 0, 0) != 0

@@ -471,11 +471,16 @@ def _run_entry(pl, d, m):
 # agrees in f to 1e-12 relative, but the LAST line search (iteration 10, f flat to 13 digits between trial steps) takes
 # one trial step more or fewer: SciPy 37 / 39 evaluations, the device 36 / 40 -- dcsrch's sufficient-decrease test
 # `f <= finit + stp * gtest` decided by the last bits of f -- and ends on the reference's point all the same (finals
-# 1e-14 apart).  (Rounds 2 - 4, default contraction: 40 / 35 evaluations, finals 1.3e-4 apart, and the 331-evaluation
-# M = 21 run g3_trace_once_M21_c0 left the reference's path around evaluation 134; it is followed to the end now.)
+# 1e-14 apart).  (Rounds 2 - 4, default contraction: 40 / 35 evaluations, finals 1.3e-4 apart.)
 KNOWN_PARTED = {
     "g3_trace_replan_s4.npz": dict(x_rel_max=1e-9, cost_rel_max=1e-9),
     "g3_trace_replan_s5.npz": dict(x_rel_max=1e-9, cost_rel_max=1e-9),
+    # a converging M = 21 run of 331 evaluations, far beyond the horizon over which ANY two implementations stay together
+    # (the product's own L-BFGS-B on the host, with a bit-identical objective, leaves SciPy's path at evaluation ~134:
+    # tests/test_lbfgs_host.py LONG_RUNS).  Asserted: the device follows the reference's recorded evaluations for at least
+    # the first 100 (test_parted_runs_first_divergence) and converges to a comparable minimum.  (Round 5: 331 evaluations
+    # like the reference by coincidence -- 307 iterations against 308.)
+    "g3_trace_once_M21_c0.npz": dict(x_rel_max=1e-1, cost_rel_max=5e-2, long_run=True),
 }
 
 
@@ -497,7 +502,7 @@ def test_planner_reproduces_reference_runs_g3_g5():
             assert pl.iter_num == int(d["iter_num"]), path
         assert pl.opt_running_times == int(d["opt_running_times"]), path
         last = int(d["n_runs"]) - 1
-        exact = last < 0 or pl.last_nfev == int(d[f"r{last}_nfev"])
+        exact = last < 0 or (pl.last_nfev == int(d[f"r{last}_nfev"]) and pl.iter_num == int(d["iter_num"]))
         n += 1
         n_exact += exact
         if known is None:

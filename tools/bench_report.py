@@ -236,6 +236,73 @@ def never_solved_profile(R, head_all, tail_all, todo, n_req):
     return out
 
 
+# ================================================================== one batch, with and without an evaluation budget
+def single_batch_budget_report(R, main_run):
+    """BASELINE cfg2 taken literally is ONE batch of 4096: its launch lasts as long as its longest run (max nfev against the
+    mean).  neo_optimize_batch_budget_dev caps the evaluations per launch and finishes the stragglers in compacted
+    re-launches: when is how much of the batch DONE?  Batch 0 alone on the chip, wall clock from the first launch, the host
+    round trips for the statuses included; finals bit-identical to the unbudgeted launch (checked here, every trajectory)."""
+    torch, ctx, bp, dev, _lib = R.torch, R.ctx, R.bp, R.dev, R._lib
+    B, M, D = R.B, R.M, R.D
+    bt = R.batches[0]
+    nf = main_run["nfev_all"][0]
+    state = torch.empty(B * int(ctx.lib.neo_optimize_state_bytes(M, D)), dtype=torch.uint8, device=dev)
+    x = torch.empty_like(bt["x0"]); costs = torch.zeros_like(bt["costs"]); last = torch.zeros_like(bt["last"])
+    nit = torch.zeros_like(bt["nit"]); nfev = torch.zeros_like(bt["nfev"]); st = torch.zeros_like(bt["status"])
+    ctx.set_stream(R.tstream.cuda_stream)
+    ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, ctypes.c_void_p(bt["order"].data_ptr()) if bt["order"] is not None else None, B))
+    out = {"what": "batch 0 (4096 requests) alone on the chip: one unbudgeted launch against launches of at most `budget` "
+                   "evaluations per trajectory with the stragglers re-launched compacted (BatchPlanner.optimize_budgeted_dev); "
+                   "wall clock incl. the status round trips; done_after_first_launch = share of the batch finished when the "
+                   "first launch returns",
+           "mean_nfev": float(nf.mean()), "max_nfev": int(nf.max())}
+
+    def plain():
+        bp.optimize_dev(R.g3, x, bt["head"], bt["tail"], costs, last, nit, nfev, st, x0=bt["x0"])
+    for _ in range(2):
+        plain()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        plain()
+        torch.cuda.synchronize()
+    out["unbudgeted_ms"] = 1e3 * (time.perf_counter() - t0) / 5
+    ref = (x.clone(), costs.clone(), last.clone(), nit.clone(), nfev.clone(), st.clone())
+    rows = []
+    for budget in sorted({int(1.5 * nf.mean()), int(2.5 * nf.mean())}):
+        first_ms, total_ms, sizes = [], [], None
+        for rep in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pp = lambda t: ctypes.c_void_p(t.data_ptr())
+            ctx.check(ctx.lib.neo_optimize_batch_budget_dev(ctx.h, R.g3.scene_id, B, M, D, pp(bt["x0"]), pp(x), pp(bt["head"]), pp(bt["tail"]),
+                                                            pp(costs), pp(last), pp(nit), pp(nfev), pp(st), pp(state), budget, None, 0, 0))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sizes = [B]
+            while True:
+                sub = torch.nonzero(st == _lib.NEO_TRAJ_SUSPENDED).flatten().to(torch.int32)
+                if sub.numel() == 0:
+                    break
+                ctx.check(ctx.lib.neo_optimize_batch_budget_dev(ctx.h, R.g3.scene_id, B, M, D, pp(bt["x0"]), pp(x), pp(bt["head"]), pp(bt["tail"]),
+                                                                pp(costs), pp(last), pp(nit), pp(nfev), pp(st), pp(state), budget, pp(sub),
+                                                                int(sub.numel()), 1))
+                torch.cuda.synchronize()
+                sizes.append(int(sub.numel()))
+            t2 = time.perf_counter()
+            if rep:
+                first_ms.append(1e3 * (t1 - t0)); total_ms.append(1e3 * (t2 - t0))
+        same = all(torch.equal(a_, b_) for a_, b_ in zip(ref, (x, costs, last, nit, nfev, st)))
+        rows.append({"budget": budget, "first_launch_ms": float(np.mean(first_ms)), "all_done_ms": float(np.mean(total_ms)),
+                     "launch_sizes": sizes, "done_after_first_launch": 1.0 - (sizes[1] / B if len(sizes) > 1 else 0.0),
+                     "traj_per_s_done_after_first_launch": (B - (sizes[1] if len(sizes) > 1 else 0)) / (float(np.mean(first_ms)) * 1e-3),
+                     "bit_identical_to_the_unbudgeted_launch": bool(same)})
+    out["budgets"] = rows
+    ctx.set_stream(None)
+    bp._sync()
+    return out
+
+
 # ================================================================== the ESDF-lookup kernel on its own
 def esdf_report(R):
     """add_sampled_cost + add_sampled_grad_CT (expert_planner.py:392-466) for batch 0 at the initial guess, coefficients
@@ -506,6 +573,8 @@ def extend(R, out, mode_runs, cpu_out, arr):
     one = R.world == 1 and not R.use_dist
     if one and a.config == "cfg2" and R.init is None and R.n_scenes == 1 and not a.no_retries:
         out["accepted_after_retries"] = retries_report(R, mode_runs[a.dtype])
+    if one and a.config == "cfg2" and R.init is None and R.n_scenes == 1 and a.layout in ("brick", "linear") and R.store == "f32":
+        out["single_batch_budget"] = single_batch_budget_report(R, mode_runs[a.dtype])
     if R.n_scenes == 1:
         out["esdf_kernel"] = esdf_report(R)
     if one and a.config == "cfg2":

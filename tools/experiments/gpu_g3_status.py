@@ -18,7 +18,7 @@ for path in sorted(glob.glob(os.path.join(REPO, "tests", "golden", "g3_trace_*.n
     pl = npa.MinJerkPlanner(npa.PlannerConfig())
     err = tp._run_entry(pl, d, m)
     last = int(d["n_runs"]) - 1
-    exact = last < 0 or pl.last_nfev == int(d[f"r{last}_nfev"])
+    exact = last < 0 or (pl.last_nfev == int(d[f"r{last}_nfev"]) and pl.iter_num == int(d["iter_num"]))
     n += 1; ex += exact
     xr = rel_err(pl.int_wpts, d["final_int_wpts"]) if hasattr(pl, "int_wpts") else float("nan")
     print(f"{os.path.basename(path):34s} exact {int(exact)} nfev {getattr(pl, 'last_nfev', -1):4d} ref {int(d[f'r{last}_nfev']) if last >= 0 else -1:4d} "
