@@ -86,6 +86,9 @@ def parse(argv=None):
     ap.add_argument("--no-modes", action="store_true", help="time only the --dtype mode (cfg2 on one GPU times all three)")
     ap.add_argument("--no-report", action="store_true",
                     help="the timed region and the compact line only: nothing of tools/bench_report.py runs")
+    ap.add_argument("--report-sections", default="all",
+                    help="comma list of tools/bench_report.py sections to run: retries, budget, esdf, cfg1, parity (default all); "
+                         "profile runs ask for `esdf` alone so that the counters of a launch shape belong to one kind of launch")
     ap.add_argument("--details", default=None,
                     help="where the full report goes (default gpurun_out/bench_details.json, /tmp when that is not writable)")
     ap.add_argument("--esdf-order", default="spatial", choices=["spatial", "index"],

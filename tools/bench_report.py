@@ -571,17 +571,18 @@ def extend(R, out, mode_runs, cpu_out, arr):
     """run every section that applies to this run and attach it to the full report"""
     a = R.a
     one = R.world == 1 and not R.use_dist
-    if one and a.config == "cfg2" and R.init is None and R.n_scenes == 1 and not a.no_retries:
+    want = lambda name: a.report_sections == "all" or name in a.report_sections.split(",")
+    if want("retries") and one and a.config == "cfg2" and R.init is None and R.n_scenes == 1 and not a.no_retries:
         out["accepted_after_retries"] = retries_report(R, mode_runs[a.dtype])
-    if one and a.config == "cfg2" and R.init is None and R.n_scenes == 1 and a.layout in ("brick", "linear") and R.store == "f32":
+    if want("budget") and one and a.config == "cfg2" and R.init is None and R.n_scenes == 1 and a.layout in ("brick", "linear") and R.store == "f32":
         out["single_batch_budget"] = single_batch_budget_report(R, mode_runs[a.dtype])
-    if R.n_scenes == 1:
+    if want("esdf") and R.n_scenes == 1:
         out["esdf_kernel"] = esdf_report(R)
-    if one and a.config == "cfg2":
+    if want("cfg1") and one and a.config == "cfg2":
         out["cfg1"] = cfg1_report(R)
         if cpu_out and "cfg1" in cpu_out:
             out["cfg1"].update(cpu_out["cfg1"])
-    if cpu_out is not None:
+    if want("parity") and cpu_out is not None:
         out["parity"] = parity_report(R, out, mode_runs, cpu_out, arr)
 
 

@@ -64,7 +64,8 @@ def main():
     extra = [a for a in args if a != "--trace-only"]
     os.makedirs(out, exist_ok=True)
     os.environ["TMPDIR"] = "/tmp"
-    bench = ["python3", "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-modes", "--no-retries"] + extra
+    bench = ["python3", "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-modes", "--no-retries",
+             "--report-sections", "esdf"] + extra
     d = os.path.join(out, "trace")
     rc = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + bench,
              os.path.join(out, "trace.log"), 420)
@@ -73,6 +74,7 @@ def main():
         shutil.copy(stats[0], os.path.join(out, "kernel_stats.csv"))
     # the same trace split by launch shape (rocprofv3's own stats merge every launch of a kernel name)
     traces = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    symbols = {}          # launch shape -> the kernel's full (demangled) name as rocprofv3 reports it
     if traces:
         by = {}
         with open(traces[0]) as f:
@@ -84,6 +86,7 @@ def main():
                 wg = max(int(row["Workgroup_Size_X"]) if "Workgroup_Size_X" in row else int(row.get("Workgroup_Size", 64)), 1)
                 gs = int(row["Grid_Size_X"]) if "Grid_Size_X" in row else int(row.get("Grid_Size", 0))
                 by.setdefault(f"{k}@{gs // wg}", []).append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+                symbols.setdefault(f"{k}@{gs // wg}", name)
         with open(os.path.join(out, "kernel_stats_by_grid.csv"), "w") as f:
             f.write("kernel@workgroups,calls,avg_ns,min_ns,max_ns,total_ns\n")
             for k, v in sorted(by.items()):
@@ -124,6 +127,7 @@ def main():
            "units": {"FETCH_SIZE": "KB per dispatch (raw counter; the 8-byte gathers are an uncalibrated access shape, "
                                    "no gfx950 correction applied)", "WRITE_SIZE": "KB per dispatch",
                      "SQ_*": "summed over the dispatch"},
+           "kernel_symbols": symbols,
            "kernels": {k: {c: {"mean_per_dispatch": v[0] / v[1], "dispatches": v[1]} for c, v in cs.items()}
                        for k, cs in agg.items()}}
     with open(os.path.join(out, "pmc.json"), "w") as f:
