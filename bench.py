@@ -596,6 +596,24 @@ class Rank:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
+    def kernel_symbol(self, name):
+        """the instantiation this run launches for kernel family `name`, as rocprofv3 spells it (demangled, up to the argument
+        list): what a committed counter profile's `kernel_symbols` entry must say for its figures to be this run's
+        (tools/bench_report.py pmc_profile).  None for the families the bench has no traffic figure for."""
+        a, M, D = self.a, self.M, self.D
+        lay = {"linear": 0, "yz4": 1, "cell8": 2, "brick": 3}[a.layout]
+        elem = "float" if self.store == "f32" else "__half"
+        real = "double" if a.dtype == "f64" else "float"
+        num = "float" if a.dtype == "f32x" else "double"
+        lookup = f"neo::Lookup3D<{real}, {elem}, {lay}>"
+        if name == "sample_kernel":
+            return f"void neo::sample_kernel<{D}, {real}, neo::Map3D, {lookup} >"
+        if name == "optimize_kernel":
+            ns = min(max((self.n + 63) // 64, 1), 4)
+            lg = f"neo::WaveLanesPD<{D}>" if D * M <= 64 else "neo::WaveLanes"
+            return f"void neo::optimize_kernel<{D}, {ns}, {real}, neo::Map3D, {lookup}, 2, {lg}, {num}, false>"
+        return None
+
     def kernel_time(self, which):
         """(launches, total ms) of a kernel family since neo_profile_reset: HIP events on the stream each launch ran on"""
         launches, kms = ctypes.c_int64(), ctypes.c_double()

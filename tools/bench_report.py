@@ -74,7 +74,7 @@ def pmc_profile(a, kernel_key, symbol=None):
             if kernel_key not in ks:
                 continue
             syms = prof.get("kernel_symbols") or {}
-            if symbol and kernel_key in syms and _norm_symbol(syms[kernel_key]) != _norm_symbol(symbol):
+            if symbol and kernel_key in syms and not _norm_symbol(syms[kernel_key]).startswith(_norm_symbol(symbol)):
                 continue
             return ({c: v["mean_per_dispatch"] for c, v in ks[kernel_key].items() if "mean_per_dispatch" in v},
                     os.path.relpath(path, REPO))
