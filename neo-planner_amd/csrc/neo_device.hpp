@@ -106,7 +106,11 @@ struct Map3D {
   // map record they arrive in scalar registers.
   float f_inv, f_off[3], f_hi[3];
   int nbx, nby;  // corner-brick layout: blocks along x and y (set by the upload for layout 3)
+  double d_inv;  // 1 / res for the fp64 lookups (round 5: three fp64 divisions a sample -- ~10 instructions each with
+                 // v_rcp_f64 and its refinement -- became multiplications; the trilinear mode is defined by the oracle,
+                 // which divides: cell coordinates differ by an ulp at most, distances by ~1e-13 relative)
   __host__ __device__ void derive() {
+    d_inv = 1.0 / res;
     f_inv = (float)(1.0 / res);
     f_off[0] = (float)(-ox / res - 0.5);
     f_off[1] = (float)(-oy / res - 0.5);
@@ -492,7 +496,7 @@ struct Lookup3D {
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      Real u = (Real)(((double)pos[k] - org[k]) / m.res);  // as oracle Grid3DESDF._cell
+      Real u = (Real)(((double)pos[k] - org[k]) * m.d_inv);  // oracle Grid3DESDF._cell divides by res: an ulp apart at most
       if (!(u >= Real(0) && u < (Real)n[k])) a.inside = false;
       u -= Real(0.5);
       const int i = min(max((int)floor(u), 0), n[k] - 2);
@@ -648,7 +652,7 @@ struct Lookup3D {
     for (int d = 0; d < D; ++d) g[d] = Real(0);
     if (!a.inside) return Real(10000);
     const Real fx = a.fr[0], fy = a.fr[1], fz = a.fr[2];
-    const Real inv_res = (Real)(1.0 / m.res);
+    const Real inv_res = sizeof(Real) == 4 ? (Real)m.f_inv : (Real)m.d_inv;
     const Real c000 = (Real)q.c[0][0][0], c100 = (Real)q.c[0][0][1], c010 = (Real)q.c[0][1][0], c110 = (Real)q.c[0][1][1];
     const Real c001 = (Real)q.c[1][0][0], c101 = (Real)q.c[1][0][1], c011 = (Real)q.c[1][1][0], c111 = (Real)q.c[1][1][1];
     const Real dx00 = c100 - c000, dx10 = c110 - c010, dx01 = c101 - c001, dx11 = c111 - c011;
