@@ -93,7 +93,6 @@ struct DevBackend {
   bool fold_rows = true;  // xs has all kStage doubles (false: only NS * 64, the fold stays in registers)
   bool fold_acc = false;  // xs holds [M][fold_acc_stride(D)] per-piece accumulators instead of the rows (minco_sample; the kernels that keep
                           // the cyclic reduction's multipliers in LDS: launch_opt)
-  double *sc;    // LDS [2m]: rho / alpha of the two-loop recursion
   LineSearch *lsp;  // LDS: line-search state (wave-uniform)
   double *cst;      // LDS [12]: cost terms of the last evaluation / current x / previous x
   // LDS [2][m][n]: the stored (s, y) pairs of this trajectory
@@ -471,7 +470,6 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
                                                       double *__restrict__ grad, double *__restrict__ coeffs,
                                                       int *__restrict__ status) {
   __shared__ __attribute__((aligned(16))) double xs[stage_doubles<D, NS, Real>()];
-  __shared__ double sc[2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm;
   __shared__ double cst[12];
   __shared__ Num bnd[6 * D];
@@ -486,7 +484,6 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
   be.xs = xs;
   if constexpr (sizeof(Num) == 4 && LG::W == kWave)   // (the staging doubles as the cyclic reduction's exchange table)
     if (pcr_xch_elems(M, LG::dl(D)) * (int)sizeof(Num) <= stage_doubles<D, NS, Real>() * 8) be.t.pcr_xch = reinterpret_cast<Num *>(xs);
-  be.sc = sc;
   be.lsp = &lsm;
   be.cst = cst;
   be.hist = nullptr;
@@ -540,7 +537,6 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
                                                           double *__restrict__ trace_xg, int trace_cap, int stage, int pcr_off,
                                                           double *state, int state_doubles, int budget, int resume) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
-  __shared__ double sc[2 * NEO_LBFGS_M];
   __shared__ LineSearch lsm;
   __shared__ double cst[12];
   __shared__ Num bnd[6 * D];
@@ -577,7 +573,6 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   }
   if constexpr (sizeof(Num) == 4 && LG::W == kWave)   // (the staging doubles as the cyclic reduction's exchange table)
     if (be.fold_rows && pcr_xch_elems(M, LG::dl(D)) * (int)sizeof(Num) <= stage * 8) be.t.pcr_xch = reinterpret_cast<Num *>(dyn_lds);
-  be.sc = sc;
   be.lsp = &lsm;
   be.cst = cst;
   be.m = NEO_LBFGS_M;

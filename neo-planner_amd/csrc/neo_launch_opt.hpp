@@ -62,7 +62,7 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
       case 2: NEO_OPT(2); return NEO_OK;
       default: return fail(c, NEO_ERR_INVALID, "budgeted launches: n <= 128 variables");
     }
-  }
+  } else
   switch (slots_for(a.M, D)) {
     case 1: NEO_OPT(1); break;
     case 2: NEO_OPT(2); break;

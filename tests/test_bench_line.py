@@ -68,3 +68,40 @@ def test_compact_line_of_a_bare_report():
     for k in CONTRACT:
         assert k in line
     assert "cpu_baseline" not in line and "value_parity_mode" not in line
+
+
+def test_traffic_figures_come_only_from_a_profile_of_this_workload_and_kernel():
+    """`roofline.traffic` is a counter figure from a COMMITTED rocprofv3 profile; it is reported only when
+    that profile's command names this run's workload and its recorded kernel symbol is the instantiation this run launches
+    (bench.Rank.kernel_symbol spells it as rocprofv3 does), and null otherwise"""
+    import types
+    import bench
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import bench_report
+    prof = json.load(open(os.path.join(REPO, "profiles", "r05_b_pmc.json")))
+
+    def rank(argv):
+        a = bench.parse(argv)
+        a.argv = list(argv)
+        R = types.SimpleNamespace(a=a, M=a.waypoints + 1, D=3, n=3 * a.waypoints + a.waypoints + 1, store="f32")
+        R.kernel_symbol = lambda name: bench.Rank.kernel_symbol(R, name)
+        return R
+    R = rank([])
+    for key in ("optimize_kernel@4096", "sample_kernel@4096", "sample_kernel@163840"):
+        sym = R.kernel_symbol(key.split("@")[0])
+        assert prof["kernel_symbols"][key].replace(" ", "").startswith(sym.replace(" ", "")), (key, sym)
+        t = bench_report.kernel_traffic(R, key)
+        assert t["traffic"] and t["source"].startswith("profiles/r0")
+    # another arithmetic mode, another layout, another size: no figure
+    for argv in (["--dtype", "f64"], ["--layout", "yz4"], ["--batch", "2048"], ["--config", "cfg4"]):
+        assert bench_report.kernel_traffic(rank(argv), "optimize_kernel@4096")["traffic"] is None, argv
+    # cfg5 has its own profile (three FLAT slots, lane = piece, fp16 bricks)
+    R5 = rank(["--config", "cfg5"])
+    R5.M, R5.n, R5.store = 41, 161, "f16"
+    t5 = bench_report.kernel_traffic(R5, "optimize_kernel@4096")
+    assert t5["traffic"] and "cfg5" in t5["source"], t5
+    # the same command line but another instantiation (a profile with symbols must agree with the run's)
+    R2 = rank([])
+    R2.kernel_symbol = lambda name: "void neo::optimize_kernel<3, 2, double"
+    t2 = bench_report.kernel_traffic(R2, "optimize_kernel@4096")
+    assert t2["source"] is None or "r05" not in t2["source"]
