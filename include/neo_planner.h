@@ -252,8 +252,9 @@ int neo_optimize_batch_from_dev(neo_ctx *ctx, int scene_id, const int32_t *scene
  * bit for bit the run of an unbudgeted launch (tests/test_gpu_budget.py).  The reference's own caps keep their meaning:
  * maxiter / maxfun of expert_planner.py:213-225 count over all launches of a run (NEO_TRAJ_MAXITER).
  *   state      DEVICE buffer of B * neo_optimize_state_bytes(M, D) bytes, the caller's, kept between the launches of a run
- *   subset     optional DEVICE array of n_subset trajectory indices (each < B): only these are launched -- the compacted
- *              re-launch of the stragglers; NULL = all B.  Arrays are always indexed by trajectory, never by position
+ *   subset     optional DEVICE array of n_subset trajectory indices: only these are launched -- the compacted re-launch of
+ *              the stragglers; NULL = all B.  Arrays are always indexed by trajectory, never by position; an index
+ *              outside 0 .. B - 1 is skipped
  *   resume     0: the launched trajectories start from x0; 1: those among them with status NEO_TRAJ_SUSPENDED continue
  *              from state, the others are left untouched
  * A suspended trajectory's x holds the point it evaluates next, costs4 the terms at its last iterate, nit / nfev its
@@ -317,8 +318,8 @@ int neo_pack_results_dev(neo_ctx *ctx, int B, int n, const double *x, const doub
  * in the caller's order, bit-identical): there the lever is locality -- workgroup i runs on XCD i mod 8, each XCD has its
  * own L2, and BatchPlanner.spatial_order deals requests that fly through the same part of the field to the same XCD.
  * `order` is a host (on_device = 0) or device (on_device = 1) array of B ints; it is COPIED into a context-owned buffer
- * (stream-ordered), so the caller may free it after the call (a device array: once the context's stream has passed the
- * copy).  NULL or B = 0 resets.  Independent of neo_optimize_dispatch_order. */
+ * before the call returns (the call synchronises the context's stream), so the caller may free it right away.  NULL or
+ * B = 0 resets.  Independent of neo_optimize_dispatch_order. */
 int neo_sampled_terms_dispatch_order(neo_ctx *ctx, const int32_t *order, int on_device, int B);
 int neo_profile_read(neo_ctx *ctx, int kernel, int64_t *launches, double *total_ms);
 int neo_profile_reset(neo_ctx *ctx);

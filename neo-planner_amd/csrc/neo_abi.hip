@@ -673,7 +673,6 @@ __global__ __launch_bounds__(kWave) void traj_state_kernel(int B, int M, DevPara
                                                             const double *__restrict__ tail, double hz, int K,
                                                             double *__restrict__ state, int *__restrict__ count) {
   __shared__ double xs[kSlots * kWave];
-  __shared__ double sc[2 * NEO_LBFGS_M];
   __shared__ double cs[kWave * 6 * D];
   __shared__ double tcum[kWave + 1];
   const int b = blockIdx.x;
@@ -686,7 +685,6 @@ __global__ __launch_bounds__(kWave) void traj_state_kernel(int B, int M, DevPara
   NoMap nm;
   DevBackend<D, kSlots, double, NoMap, NoLookup> be(p, nm);
   be.xs = xs;
-  be.sc = sc;
   be.hist = nullptr;
   be.m = NEO_LBFGS_M;
   be.coeff_out = nullptr;
@@ -1609,6 +1607,7 @@ int neo_optimize_batch_budget_dev(neo_ctx *c, int scene_id, int B, int M, int D,
   oa.resume = resume ? 1 : 0;
   oa.subset = subset;
   oa.n_subset = subset ? n_subset : 0;
+  oa.traj_total = B;
   rc = launch_opt_3d_budget(c, it->second.elem, it->second.m3.layout, oa);
   if (rc) return rc;
   HIPCHK(c, hipGetLastError());
@@ -1903,11 +1902,10 @@ int neo_sampled_terms_dispatch_order(neo_ctx *c, const int32_t *order, int on_de
     HIPCHK(c, hipMalloc((void **)&c->sample_order, (size_t)B * sizeof(int)));
     c->sample_order_cap = (size_t)B;
   }
-  // stream-ordered copy into the context's own buffer: the caller's array may go away after the call (a host array once
-  // the synchronisation below has returned, a device array once the stream has passed this point)
+  // copied into the context's own buffer before the call returns: the caller's array may go away right after it
   HIPCHK(c, hipMemcpyAsync(c->sample_order, order, (size_t)B * sizeof(int),
                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-  if (!on_device) HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   c->sample_order_B = B;
   return NEO_OK;
 }

@@ -150,6 +150,7 @@ struct OptArgs {
   int resume = 0;                // continue suspended runs instead of starting from x0
   const int *subset = nullptr;   // device array of n_subset trajectory indices: launch these only (workgroup i -> subset[i])
   int n_subset = 0;
+  int traj_total = 0;            // B of the arrays (subset entries are checked against it on the device)
 };
 
 struct SampleArgs {

@@ -535,7 +535,8 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
                                                           long long *__restrict__ nsamples,
                                                           const int *__restrict__ order, double *__restrict__ trace,
                                                           double *__restrict__ trace_xg, int trace_cap, int stage, int pcr_off,
-                                                          double *state, int state_doubles, int budget, int resume) {
+                                                          double *state, int state_doubles, int budget, int resume,
+                                                          int traj_total) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
   __shared__ LineSearch lsm;
   __shared__ double cst[12];
@@ -544,6 +545,8 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   // workgroups are dispatched in index order: `order` lets the caller start the runs it expects to
   // be long first (list scheduling: a long run that starts last sets the duration of the launch)
   const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
+  if constexpr (BUDGET)  // (a subset launch names its trajectories: an entry outside the arrays is skipped)
+    if (b < 0 || b >= traj_total) return;
   // the two-waves variant has half the registers: two samples per lane in flight instead of four (with the lean
   // Horner form, cfg2 with three batches in flight: 414 k -> 541 k traj/s; scratch 640 -> 336 B per lane)
   using BE = DevBackend<D, NS, Real, MapT, LookupT, (WAVES == 2 ? NEO_W2_U : NEO_FUSED_U), LG,
@@ -598,6 +601,8 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   // two-waves kernel.  Four FLAT slots (n > 128, cfg5): the compiler keeps the machine's vectors in private memory
   // (1 KB of scratch, 3x slower), so those instantiations run the straight-line form.
   bool suspended = false;
+  // (round 5, measured and dropped: wavefronts raising their own issue priority -- s_setprio -- as their evaluations pass
+  //  128 / 256 / 384: 1.444 - 1.451 M traj/s against 1.439 - 1.440 M, a single batch unchanged: HISTORY.md)
   if constexpr (NS <= NEO_SM_MAX_SLOTS) {
     LbfgsMachine<BE> mach(be, o);
     if constexpr (BUDGET) {

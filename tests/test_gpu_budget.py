@@ -71,8 +71,8 @@ def test_budget_api_edges():
     torch.cuda.synchronize()
     assert call(0, None, 0, 0) != 0                                   # a budget below one evaluation
     # a subset launch touches its trajectories only
-    sub = torch.tensor([3, 40, 7], dtype=torch.int32, device=dev)
-    assert call(5, sub, 3, 0) == 0
+    sub = torch.tensor([3, 40, 7, B + 5, -1], dtype=torch.int32, device=dev)      # (the last two are outside the arrays: skipped)
+    assert call(5, sub, 5, 0) == 0
     ctx.synchronize()
     s = st.cpu().numpy()
     assert set(np.flatnonzero(s != -1).tolist()) == {3, 7, 40}
