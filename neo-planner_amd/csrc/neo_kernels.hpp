@@ -54,6 +54,8 @@ __host__ __device__ constexpr int stage_doubles() {
   return (NS * kWave * 8 > fold ? NS * kWave * 8 : fold) / 8;
 }
 
+constexpr int kSlCacheInts = kWave / 4 + kWave + 4;  // DevBackend::sl_cache: a key byte and an assignment word a lane, three uniform ints
+
 // ------------------------------------------------------------------ device backend of the optimiser
 // SU: samples per lane in flight in the sample loop (minco_sample)
 // LG: lane layout of the PIECE-layout phases -- WaveLanes (lane = piece) or WaveLanesPD<D> (lane = (piece, dimension))
@@ -90,6 +92,11 @@ struct DevBackend {
   double *xs;    // LDS [kStage]: FLAT <-> PIECE staging; between scatter_x and the gradient gather the same memory
                  // holds the lane assignment's segment table and the rows of the per-piece fold (minco_sample)
   static constexpr int kStage = stage_doubles<D, NS, Real>();
+  // LDS [kSlCacheInts] or nullptr: the lane assignment of the last evaluation (a key byte and a word a lane + three wave-uniform ints).
+  // The assignment depends on the pieces' sample counts int(T / delta_t) alone, and along a run 58 % of consecutive
+  // iterates have the same counts in every piece (line-search trial points more often still): a hit costs a compare, a
+  // ballot and two LDS reads instead of the ~140 vector instructions of balanced_sample_lanes.  Same assignment, same bits.
+  int *sl_cache = nullptr;
   bool fold_rows = true;  // xs has all kStage doubles (false: only NS * 64, the fold stays in registers)
   bool fold_acc = false;  // xs holds [M][fold_acc_stride(D)] per-piece accumulators instead of the rows (minco_sample; the kernels that keep
                           // the cyclic reduction's multipliers in LDS: launch_opt)
@@ -313,7 +320,38 @@ struct DevBackend {
       if constexpr (LG::S > 1) ns_by_piece = __shfl(t.ns, min(LG::S * lane, kWave - 1), kWave);
       NEO_MARK("assign_begin");
       t.M = opaque_uniform(M_all);
-      const SampleLanes sl = balanced_sample_lanes(t.M, ns_by_piece, reinterpret_cast<int *>(xs));
+      SampleLanes sl;
+      bool cached = false;
+      const int ns_key = lane < t.M ? ns_by_piece : 0;  // (what balanced_sample_lanes sees of this lane)
+      if (sl_cache != nullptr) cached = __ballot(ns_key == (int)reinterpret_cast<const unsigned char *>(sl_cache)[lane]) == ~0ull;
+      if (cached) {
+        const unsigned pk = (unsigned)sl_cache[kWave / 4 + lane];
+        sl.piece = pk & 63;
+        sl.r = (pk >> 6) & 63;
+        sl.L = (pk >> 12) & 127;
+        sl.act = ((pk >> 19) & 1) != 0;
+        sl.first = (pk >> 20) & 63;
+        sl.Lp = pk >> 26;  // (<= 32 here: Lp = 64 means a single piece, which has no entry -- see the store)
+        sl.rounds = __builtin_amdgcn_readfirstlane(sl_cache[kWave / 4 + kWave]);
+        sl.lmax = __builtin_amdgcn_readfirstlane(sl_cache[kWave / 4 + kWave + 1]);
+        sl.total = __builtin_amdgcn_readfirstlane(sl_cache[kWave / 4 + kWave + 2]);
+      } else {
+        sl = balanced_sample_lanes(t.M, ns_by_piece, reinterpret_cast<int *>(xs));
+        if (sl_cache != nullptr) {
+          // one byte a lane for the key (sample counts stay below T_max / delta_t; 255 = never equal), one word for the
+          // assignment; a piece with more than 63 lanes (M = 1) does not fit the word's six bits: not cached
+          const bool fits = sl.lmax < 64 && ns_key < 255;
+          reinterpret_cast<unsigned char *>(sl_cache)[lane] = (unsigned char)(__ballot(!fits) == 0 ? ns_key : 255);
+          sl_cache[kWave / 4 + lane] = (int)((unsigned)sl.piece | ((unsigned)sl.r << 6) | ((unsigned)sl.L << 12) |
+                                             ((sl.act ? 1u : 0u) << 19) | ((unsigned)sl.first << 20) | ((unsigned)sl.Lp << 26));
+          if (lane == 0) {
+            sl_cache[kWave / 4 + kWave] = sl.rounds;
+            sl_cache[kWave / 4 + kWave + 1] = sl.lmax;
+            sl_cache[kWave / 4 + kWave + 2] = sl.total;
+          }
+          lds_wave_sync();
+        }
+      }
       last_ns = sl.total;  // (the lane assignment has summed the sample counts already)
       samples += (long long)last_ns;
       NEO_MARK("assign_done");
@@ -541,6 +579,9 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   __shared__ LineSearch lsm;
   __shared__ double cst[12];
   __shared__ Num bnd[6 * D];
+  // the all-fp32 three-waves-per-SIMD kernels have LDS to spare for the lane-assignment cache (launch_opt keeps room)
+  constexpr bool kSlCache = sizeof(Num) == 4 && NS <= 2;
+  __shared__ __attribute__((aligned(8))) int slc[kSlCache ? kSlCacheInts : 2];
   if ((int)blockIdx.x >= B) return;
   // workgroups are dispatched in index order: `order` lets the caller start the runs it expects to
   // be long first (list scheduling: a long run that starts last sets the duration of the launch)
@@ -580,6 +621,10 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   be.cst = cst;
   be.m = NEO_LBFGS_M;
   be.coeff_out = nullptr;
+  if constexpr (kSlCache) {
+    if (lane_id() < kWave / 4) slc[lane_id()] = -1;  // (key bytes 255: the first evaluation misses)
+    be.sl_cache = slc;
+  }
   be.trace = trace ? trace + (size_t)b * trace_cap * 4 : nullptr;
   be.trace_cap = (trace != nullptr || trace_xg != nullptr) ? trace_cap : 0;
   be.trace_xg = trace_xg ? trace_xg + (size_t)b * trace_cap * 2 * (D * (M - 1) + M) : nullptr;

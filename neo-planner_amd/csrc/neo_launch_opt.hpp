@@ -16,7 +16,10 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
   // staging in front of the pairs: the full size (with the rows of the per-piece fold) unless that costs the two-waves
   // variant occupancy -- eight wavefronts per CU want 160 KB / 8 each, less ~0.5 KB of static LDS.  The one-wave
   // variant follows the same rule so that both sum the partials in the same order (bit-identical results).
-  const size_t lds_share8 = (size_t)160 * 1024 / 8 - 512, lds_share12 = (size_t)160 * 1024 / (4 * NEO_X_OCC) - 512;
+  // (static LDS beside the dynamic part: line-search state, cost terms, boundary states ~0.35 KB; the all-fp32 kernels'
+  //  lane-assignment cache kSlCacheInts * 4 = 0.8 KB more)
+  const size_t lds_share8 = (size_t)160 * 1024 / 8 - 512,
+               lds_share12 = (size_t)160 * 1024 / (4 * NEO_X_OCC) - 512 - kSlCacheInts * sizeof(int);
 #define NEO_OPT_LG(NS, LG)                                                                                    \
   do {                                                                                                        \
     const size_t pairs = pair_elems * ((pairs_in_f32<Real, NS, WAVES>() || sizeof(Num) == 4) ? sizeof(float) : sizeof(double)); \
