@@ -579,8 +579,8 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
   __shared__ LineSearch lsm;
   __shared__ double cst[12];
   __shared__ Num bnd[6 * D];
-  // the all-fp32 three-waves-per-SIMD kernels have LDS to spare for the lane-assignment cache (launch_opt keeps room)
-  constexpr bool kSlCache = sizeof(Num) == 4 && NS <= 2;
+  // the all-fp32 kernels keep the last lane assignment (DevBackend::sl_cache; launch_opt counts its 336 bytes)
+  constexpr bool kSlCache = sizeof(Num) == 4;
   __shared__ __attribute__((aligned(8))) int slc[kSlCache ? kSlCacheInts : 2];
   if ((int)blockIdx.x >= B) return;
   // workgroups are dispatched in index order: `order` lets the caller start the runs it expects to

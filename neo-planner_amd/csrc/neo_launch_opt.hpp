@@ -16,10 +16,14 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
   // staging in front of the pairs: the full size (with the rows of the per-piece fold) unless that costs the two-waves
   // variant occupancy -- eight wavefronts per CU want 160 KB / 8 each, less ~0.5 KB of static LDS.  The one-wave
   // variant follows the same rule so that both sum the partials in the same order (bit-identical results).
-  // (static LDS beside the dynamic part: line-search state, cost terms, boundary states ~0.35 KB; the all-fp32 kernels'
-  //  lane-assignment cache kSlCacheInts * 4 = 0.8 KB more)
-  const size_t lds_share8 = (size_t)160 * 1024 / 8 - 512,
-               lds_share12 = (size_t)160 * 1024 / (4 * NEO_X_OCC) - 512 - kSlCacheInts * sizeof(int);
+  // (static LDS beside the dynamic part: line-search state, cost terms, boundary states; the all-fp32 kernels'
+  //  lane-assignment cache kSlCacheInts * 4 = 336 bytes more)
+  // The chip hands out LDS in granules of 1 280 bytes (measured in round 5: a workgroup of 13 152 bytes runs eleven to a
+  // CU, one of 12 704 twelve): the share of a wavefront is 160 KB / waves rounded DOWN to that.
+  const size_t cache = sizeof(Num) == 4 ? kSlCacheInts * sizeof(int) : 0;
+  const size_t statics = 400;  // line-search state 160 + cost terms 96 + boundary states 72 / 144 (fp32 / fp64), padded
+  const size_t lds_share8 = (size_t)160 * 1024 / 8 / 1280 * 1280 - statics - cache,
+               lds_share12 = (size_t)160 * 1024 / (4 * NEO_X_OCC) / 1280 * 1280 - statics - cache;
 #define NEO_OPT_LG(NS, LG)                                                                                    \
   do {                                                                                                        \
     const size_t pairs = pair_elems * ((pairs_in_f32<Real, NS, WAVES>() || sizeof(Num) == 4) ? sizeof(float) : sizeof(double)); \
