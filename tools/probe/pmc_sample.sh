@@ -1,10 +1,10 @@
 #!/bin/bash
 # A/B of the ESDF-lookup kernel's bodies on one box (tools/gpu_sample_only.py): the in-tree library against the comparison
-# builds under tools/probe/_build (NEO_BUILD_DEFS=-DNEO_SAMPLE_NO_CTAB / -DNEO_SAMPLE_SHARED_TAILS), timing first, then
+# build under tools/probe/_build (NEO_BUILD_DEFS=-DNEO_SAMPLE_SHARED_TAILS NEO_BUILD_OUT=.../libneo_shared.so), timing first, then
 # counters per wavefront of the 4096 launch.   bash tools/probe/pmc_sample.sh [timing]
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-LIBS="in-tree $PWD/tools/probe/_build/libneo_noctab.so $PWD/tools/probe/_build/libneo_shared.so"
+LIBS="in-tree $PWD/tools/probe/_build/libneo_shared.so"    # (round 5 also compared a coefficient-table variant: HISTORY.md)
 for i in 1 2; do for lib in $LIBS; do
   if [ $lib = in-tree ]; then unset NEO_PLANNER_LIB; else export NEO_PLANNER_LIB=$lib; fi
   python3 tools/gpu_sample_only.py
