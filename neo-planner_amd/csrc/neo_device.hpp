@@ -280,6 +280,36 @@ __device__ __forceinline__ void wave_sum4(double a, double b, double c, double d
   td = rdlane(z, 63);
 }
 
+// the same for four fp32 values: 2 + 1 register swaps, 3 adds, one row-wise DPP scan, 4 v_readlane -- the price of about one
+// and a half wave_sum(float) for four sums on ONE dependent chain (the paired two-loop recursion batches its dots).
+// Fixed association order: half-waves first, then odd / even rows, then the 16 lanes of a row left to right.
+__device__ __forceinline__ void wave_sum4(float a, float b, float c, float d, float &ta, float &tb, float &tc, float &td) {
+  auto swap32 = [](float &x, float &y) {  // lanes 32..63 of x <-> lanes 0..31 of y
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]);
+    y = __uint_as_float(r[1]);
+  };
+  auto swap16 = [](float &x, float &y) {  // odd rows of x <-> even rows of y
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]);
+    y = __uint_as_float(r[1]);
+  };
+  swap32(a, c);
+  float x = a + c;  // lanes 0..31: a folded to 32 values, lanes 32..63: c
+  swap32(b, d);
+  float y = b + d;
+  swap16(x, y);
+  float z = x + y;  // row 0: a, row 1: b, row 2: c, row 3: d (16 partials each)
+  z += dpp_f<0x111>(z);
+  z += dpp_f<0x112>(z);
+  z += dpp_f<0x114>(z);
+  z += dpp_f<0x118>(z);
+  ta = rdlane(z, 15);
+  tb = rdlane(z, 31);
+  tc = rdlane(z, 47);
+  td = rdlane(z, 63);
+}
+
 // inclusive prefix sum / prefix maximum over the lanes of the wavefront (non-negative ints; the same DPP sequence as
 // wave_sum, which is that scan read at lane 63)
 __device__ __forceinline__ int wave_scan_add(int v) {

@@ -207,6 +207,77 @@ struct DevBackend {
     for (int k = 0; k < NS; ++k) s += a.v[k] * b.v[k];
     return (double)(rdlane(sreg, slot) * wave_sum(s));
   }
+  // ---- the two-loop recursion two pairs at a time (all-fp32 mode; round 5).  The textbook recursion is 2 * col DEPENDENT
+  // steps "read (s, y), dot, wave-wide sum, axpy": a_k = rho_k s_k . q_k needs q_k = q_{k+1} - a_{k+1} y_{k+1}.  Written out for
+  // two steps, a_{k-1} = rho_{k-1} (s_{k-1} . q_k - a_k s_{k-1} . y_k): the three dots s_k . q, s_{k-1} . q, s_{k-1} . y_k do not
+  // depend on each other, go through ONE batched reduction (wave_sum4) and give both coefficients; likewise the second
+  // loop with y_k . r, y_{k+1} . r, y_{k+1} . s_k.  col dependent reductions instead of 2 * col, ~35 vector instructions a
+  // pair of steps instead of ~90.  Same mathematics, another rounding (the fp64 modes keep the textbook form: their
+  // iterates are pinned to SciPy's, tests/test_lbfgs_host.py).
+  static constexpr bool kOwnDirection = sizeof(Num) == 4;
+  __device__ __forceinline__ void direction(const Vec &g, Vec &d, int col, int head, int mm, double theta) {
+    if (col == 0) {
+      neg(d, g);
+      return;
+    }
+    auto slot_of = [&](int k) { return head + k < mm ? head + k : head + k - mm; };
+    auto dot3 = [&](const Vec &a0, const Vec &b0, const Vec &a1, const Vec &b1, const Vec &a2, const Vec &b2, Num &t0, Num &t1,
+                    Num &t2) {
+      Num p0 = Num(0), p1 = Num(0), p2 = Num(0);
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        p0 += a0.v[k] * b0.v[k];
+        p1 += a1.v[k] * b1.v[k];
+        p2 += a2.v[k] * b2.v[k];
+      }
+      Num unused;
+      wave_sum4((float)p0, (float)p1, (float)p2, 0.0f, t0, t1, t2, unused);
+    };
+    copy(d, g);  // d plays q of the recursion
+    Vec sA, yA, sB, yB;
+    int k = col - 1;
+    for (; k >= 1; k -= 2) {
+      const int A = slot_of(k), B = slot_of(k - 1);
+      hist_get_sy(A, sA, yA);
+      hist_get_sy(B, sB, yB);
+      Num t0, t1, t2;
+      dot3(sA, d, sB, d, sB, yA, t0, t1, t2);
+      const Num aA = rdlane(sreg, A) * t0;
+      const Num aB = rdlane(sreg, B) * (t1 - aA * t2);
+      sput(mm + A, (double)aA);
+      sput(mm + B, (double)aB);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) d.v[q] = (d.v[q] - aA * yA.v[q]) - aB * yB.v[q];
+    }
+    if (k == 0) {
+      const int A = slot_of(0);
+      hist_get_sy(A, sA, yA);
+      const Num aA = (Num)rho_dot(A, sA, d);
+      sput(mm + A, (double)aA);
+      axpy(-(double)aA, yA, d);
+    }
+    scale(d, 1.0 / theta);
+    k = 0;
+    for (; k + 1 < col; k += 2) {
+      const int A = slot_of(k), B = slot_of(k + 1);
+      hist_get_sy(A, sA, yA);
+      hist_get_sy(B, sB, yB);
+      Num t0, t1, t2;
+      dot3(yA, d, yB, d, yB, sA, t0, t1, t2);
+      const Num cA = rdlane(sreg, mm + A) - rdlane(sreg, A) * t0;              // alpha_k - beta_k
+      const Num cB = rdlane(sreg, mm + B) - rdlane(sreg, B) * (t1 + cA * t2);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) d.v[q] = (d.v[q] + cA * sA.v[q]) + cB * sB.v[q];
+    }
+    if (k < col) {
+      const int A = slot_of(k);
+      hist_get_sy(A, sA, yA);
+      const double b = rho_dot(A, yA, d);
+      axpy(sdiff(mm + A, b), sA, d);
+    }
+    scale(d, -1.0);
+  }
+
   // (line-search state and cost terms in LDS: in registers they spill, measured 14.0 against 15.5 ms at cfg2)
   __device__ __forceinline__ LineSearch &ls() { return *lsp; }
   __device__ __forceinline__ double *cost_store() { return cst; }

@@ -7,14 +7,26 @@
 //  work -- was built and measured in round 2: 24.3 us per evaluation against 21.7 us at cfg2, slower on the MI355X.  It
 //  was a build option until round 3 and is gone from the tree; DESIGN.md section 5 keeps the numbers.)
 #pragma once
+#include <type_traits>
 
 namespace neo {
+
+// a backend may bring its own form of the recursion (`static constexpr bool kOwnDirection = true` and
+// `direction(g, d, col, head, m, theta)`): the all-fp32 device backend walks the pairs two at a time (neo_kernels.hpp)
+template <class Backend, class = void>
+struct has_own_direction { static constexpr bool value = false; };
+template <class Backend>
+struct has_own_direction<Backend, std::enable_if_t<Backend::kOwnDirection>> { static constexpr bool value = true; };
 
 // d = -H g.  `scratch` vectors are the caller's (tmp, tmp2 of the run).
 template <class Backend>
 NEO_HD void lbfgs_direction(Backend &be, const typename Backend::Vec &g, typename Backend::Vec &d,
                             typename Backend::Vec &tmp, typename Backend::Vec &tmp2, int col, int head, int m,
                             double theta) {
+  if constexpr (has_own_direction<Backend>::value) {
+    be.direction(g, d, col, head, m, theta);
+    return;
+  }
   if (col == 0) {
     be.neg(d, g);
     return;

@@ -714,6 +714,7 @@ def test_all_fp32_multiplier_reuse_for_every_piece_count_and_both_maps():
             assert abs(r_on["nfev"].mean() - r_off["nfev"].mean()) <= 0.25 * r_off["nfev"].mean() + 3, (D, M)
             both = (r_on["status"] <= 1) & (r_off["status"] <= 1)
             if both.sum() >= 20:
-                med = np.median(r_off["final_cost"][both])
-                # (a hundred chaotic runs whose costs span three orders of magnitude: the median is a coarse figure)
-                assert abs(np.median(r_on["final_cost"][both]) - med) <= 0.3 * abs(med) + 1e-6, (D, M)
+                # (a hundred chaotic runs whose costs span three orders of magnitude in two clusters -- collision-free or not:
+                #  the median jumps between the clusters with a handful of runs; the geometric mean moves with their share)
+                lg_on, lg_off = np.log10(r_on["final_cost"][both]), np.log10(r_off["final_cost"][both])
+                assert abs(lg_on.mean() - lg_off.mean()) <= 0.4, (D, M, lg_on.mean(), lg_off.mean())

@@ -74,11 +74,11 @@ def test_g6_shares_within_1e_4_of_the_reference_beside_the_reference_against_its
     # fp64: parts from the reference no more often than the reference from itself under another BLAS kernel set
     assert dev["f64"]["finals_within_1e_4"] >= ref["self_agreement_min"] - slack
     assert dev["f64"]["x_rel_median"] < 1e-9 and dev["f64"]["same_exception"] >= 0.95
-    # measured on the MI355X (profiles/r04_h_reference_fixture_parity.json, 251 runs): finals within 1e-4 of the reference's on
-    # 73.3 % (f32) and 51.0 % (f32x) -- the reference against itself: 89.6 %; cost within 1e-2 on 90.8 % / 75.7 %.  The
+    # measured on the MI355X (round 5, 251 runs; profiles/r05_*_bench_details.json): finals within 1e-4 of the reference's on
+    # 73.7 % (f32) and 54.0 % (f32x) -- the reference against itself: 89.6 %; cost within 1e-2 on 91.2 % / 79.6 %.  The
     # assertions are those shares minus two standard deviations of a share of n runs (a kernel change that re-rounds an
     # fp32 sum moves individual runs across the 1e-4 line; it must not move the share).
-    for mode, within, c2 in (("f32", 0.733, 0.908), ("f32x", 0.510, 0.757)):
+    for mode, within, c2 in (("f32", 0.737, 0.912), ("f32x", 0.540, 0.796)):
         m = dev[mode]
         two_sigma = lambda p_: 2.0 * np.sqrt(p_ * (1.0 - p_) / n)
         assert m["finals_within_1e_4"] >= within - two_sigma(within), (mode, m)
@@ -98,5 +98,9 @@ def test_g6_shares_within_1e_4_of_the_reference_beside_the_reference_against_its
         # exits: every run ends by L-BFGS-B's own tests; the fp32 modes end fewer line searches ABNORMALly than the
         # reference (f32x: 3 against 32 of 251 -- a search that has contracted below fp32 resolution repeats a point and
         # is closed by dcsrch's rounding-error warning, which L-BFGS-B treats as a completed search)
-        assert set(m["exits"]) <= {"CONVERGED_F", "CONVERGED_GRAD", "ABNORMAL"}, (mode, m["exits"])
+        # (NUMERIC_RANGE = a duration variable ran off to where exp(-tau) overflows: the reference raises OverflowError there and
+        #  its retry loop re-seeds; 0.6 - 1.3 % of cfg2 runs end so in EVERY mode, fp64 included; on these 251 requests the
+        #  reference and the fp64 mode never do, the all-fp32 mode once since round 5's paired two-loop recursion)
+        assert set(m["exits"]) <= {"CONVERGED_F", "CONVERGED_GRAD", "ABNORMAL", "NUMERIC_RANGE"}, (mode, m["exits"])
+        assert m["exits"].get("NUMERIC_RANGE", 0) <= 0.01 * n, (mode, m["exits"])
         assert m["exits"].get("ABNORMAL", 0) <= ref["exits"].get("ABNORMAL", 0) + 8, (mode, m["exits"], ref["exits"])

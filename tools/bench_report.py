@@ -539,7 +539,8 @@ def parity_report(R, out, mode_runs, cpu_out, arr):
         g3_runs = rfp.g3_summary(rfp.g3_report())
         keep = ("n", "finals_within_1e_4", "finals_within_1e_2", "cost_within_1e_4", "cost_within_1e_2", "same_nfev",
                 "x_rel_median", "cost_rel_median", "mean_nfev", "same_exception", "exceptions", "exits",
-                "median_final_cost", "reference_median_final_cost")
+                "median_final_cost", "reference_median_final_cost", "cost_ratio_quantiles", "cost_ratio_log_mean",
+                "frac_cost_above_reference_by_1e_3", "frac_cost_below_reference_by_1e_3")
         par["vs_reference_fixtures"] = {
             "what": g6["what"],
             "g6_finals_within_1e_4_of_the_reference": {m_: v_["finals_within_1e_4"] for m_, v_ in g6["device_vs_reference"].items()},
