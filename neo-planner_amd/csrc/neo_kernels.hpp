@@ -46,6 +46,15 @@
 
 namespace neo {
 
+// the type of the optimiser's scalars and of the line-search state: fp32 where everything else is (Num = float) and the
+// run is the state machine (the straight-line form of the four-slot kernels keeps fp64 scalars)
+template <typename Num, int NS>
+#ifdef NEO_F64_SCALARS  // comparison builds: the fp64 scalars of rounds 1 - 4 everywhere
+using opt_scalar_t = double;
+#else
+using opt_scalar_t = std::conditional_t<sizeof(Num) == 4 && (NS <= NEO_SM_MAX_SLOTS), float, double>;
+#endif
+
 // doubles of LDS staging a wavefront needs: NS * 64 for the FLAT <-> PIECE exchange, 64 rows of [D][8] Reals for the
 // per-piece fold of the sampled partials (the two uses never overlap)
 template <int D, int NS, typename Real>
@@ -100,7 +109,11 @@ struct DevBackend {
   bool fold_rows = true;  // xs has all kStage doubles (false: only NS * 64, the fold stays in registers)
   bool fold_acc = false;  // xs holds [M][fold_acc_stride(D)] per-piece accumulators instead of the rows (minco_sample; the kernels that keep
                           // the cyclic reduction's multipliers in LDS: launch_opt)
-  LineSearch *lsp;  // LDS: line-search state (wave-uniform)
+  // the optimiser's scalars (f, step, g . d, theta) and the line-search state: fp32 in the all-fp32 kernels that run the
+  // state machine (round 5: dcsrch / dcstep were ~150 wave-uniform fp64 instructions, eight divisions and a square root
+  // among them, on the dependent chain of every evaluation), fp64 otherwise
+  using Scalar = opt_scalar_t<Num, NS>;
+  LineSearchT<Scalar> *lsp;  // LDS: line-search state (wave-uniform)
   double *cst;      // LDS [12]: cost terms of the last evaluation / current x / previous x
   // LDS [2][m][n]: the stored (s, y) pairs of this trajectory
   using Hist = std::conditional_t<PAIRS32, float, double>;
@@ -131,6 +144,7 @@ struct DevBackend {
   // a wave-uniform scalar back into scalar registers (two v_readfirstlane): the optimiser's scalar state then costs
   // no vector registers
   __device__ __forceinline__ double uni(double v) const { return uniform(v); }
+  __device__ __forceinline__ float uni(float v) const { return uniform(v); }
   __device__ __forceinline__ double amax(const Vec &a) const {
     Num s = Num(0);
 #pragma unroll
@@ -215,7 +229,7 @@ struct DevBackend {
   // pair of steps instead of ~90.  Same mathematics, another rounding (the fp64 modes keep the textbook form: their
   // iterates are pinned to SciPy's, tests/test_lbfgs_host.py).
   static constexpr bool kOwnDirection = sizeof(Num) == 4;
-  __device__ __forceinline__ void direction(const Vec &g, Vec &d, int col, int head, int mm, double theta) {
+  __device__ __forceinline__ void direction(const Vec &g, Vec &d, int col, int head, int mm, Num theta) {
     if (col == 0) {
       neg(d, g);
       return;
@@ -256,7 +270,7 @@ struct DevBackend {
       sput(mm + A, (double)aA);
       axpy(-(double)aA, yA, d);
     }
-    scale(d, 1.0 / theta);
+    scale(d, (double)(Num(1) / theta));
     k = 0;
     for (; k + 1 < col; k += 2) {
       const int A = slot_of(k), B = slot_of(k + 1);
@@ -279,7 +293,7 @@ struct DevBackend {
   }
 
   // (line-search state and cost terms in LDS: in registers they spill, measured 14.0 against 15.5 ms at cfg2)
-  __device__ __forceinline__ LineSearch &ls() { return *lsp; }
+  __device__ __forceinline__ LineSearchT<Scalar> &ls() { return *lsp; }
   __device__ __forceinline__ double *cost_store() { return cst; }
 
   // diagnostics (neo_optimize_trace / neo_optimize_trace_xg): one record per counted evaluation -- (f, step, samples,
@@ -486,14 +500,17 @@ __device__ __forceinline__ void save_run(BE &be, const Mach &mc, double *st) {
     const int iv[9] = {mc.phase, mc.status, mc.nfev, mc.nit, mc.iter, mc.col, mc.head, mc.task, mc.ifun};
 #pragma unroll
     for (int k = 0; k < 9; ++k) st[k] = (double)iv[k];
-    const double dv[7] = {mc.f, mc.fold, mc.stp, mc.gd, mc.gdold, mc.theta, mc.stp_evaluated};
+    const double dv[7] = {(double)mc.f, (double)mc.fold, (double)mc.stp, (double)mc.gd, (double)mc.gdold, (double)mc.theta,
+                          (double)mc.stp_evaluated};
 #pragma unroll
     for (int k = 0; k < 7; ++k) st[9 + k] = dv[k];
     st[16] = (double)be.samples;
     st[17] = (double)be.last_ns;
-    const LineSearch &L = *be.lsp;
-    const double lv[20] = {L.ftol, L.gtol, L.xtol, L.stpmin, L.stpmax, (double)L.brackt, (double)L.stage, L.ginit, L.gtest, L.gx,
-                           L.gy, L.finit, L.fx, L.fy, L.stx, L.sty, L.stmin, L.stmax, L.width, L.width1};
+    const auto &L = *be.lsp;
+    const double lv[20] = {(double)L.ftol, (double)L.gtol, (double)L.xtol, (double)L.stpmin, (double)L.stpmax, (double)L.brackt,
+                           (double)L.stage, (double)L.ginit, (double)L.gtest, (double)L.gx, (double)L.gy, (double)L.finit,
+                           (double)L.fx, (double)L.fy, (double)L.stx, (double)L.sty, (double)L.stmin, (double)L.stmax,
+                           (double)L.width, (double)L.width1};
 #pragma unroll
     for (int k = 0; k < 20; ++k) st[20 + k] = lv[k];
 #pragma unroll
@@ -522,16 +539,18 @@ __device__ __forceinline__ void load_run(BE &be, Mach &mc, const double *st) {
   auto iu = [&](int k) { return (int)uniform(st[k]); };
   mc.phase = iu(0); mc.status = iu(1); mc.nfev = iu(2); mc.nit = iu(3); mc.iter = iu(4);
   mc.col = iu(5); mc.head = iu(6); mc.task = iu(7); mc.ifun = iu(8);
-  mc.f = uniform(st[9]); mc.fold = uniform(st[10]); mc.stp = uniform(st[11]); mc.gd = uniform(st[12]);
-  mc.gdold = uniform(st[13]); mc.theta = uniform(st[14]); mc.stp_evaluated = uniform(st[15]);
+  using S = typename Mach::S;  // (every fp32 scalar went to the state as a double: exact both ways)
+  mc.f = (S)uniform(st[9]); mc.fold = (S)uniform(st[10]); mc.stp = (S)uniform(st[11]); mc.gd = (S)uniform(st[12]);
+  mc.gdold = (S)uniform(st[13]); mc.theta = (S)uniform(st[14]); mc.stp_evaluated = (S)uniform(st[15]);
   be.samples = (long long)uniform(st[16]);
   be.last_ns = iu(17);
   if (lane == 0) {
-    LineSearch &L = *be.lsp;
-    L.ftol = st[20]; L.gtol = st[21]; L.xtol = st[22]; L.stpmin = st[23]; L.stpmax = st[24];
+    auto &L = *be.lsp;
+    L.ftol = (S)st[20]; L.gtol = (S)st[21]; L.xtol = (S)st[22]; L.stpmin = (S)st[23]; L.stpmax = (S)st[24];
     L.brackt = (int)st[25]; L.stage = (int)st[26];
-    L.ginit = st[27]; L.gtest = st[28]; L.gx = st[29]; L.gy = st[30]; L.finit = st[31]; L.fx = st[32]; L.fy = st[33];
-    L.stx = st[34]; L.sty = st[35]; L.stmin = st[36]; L.stmax = st[37]; L.width = st[38]; L.width1 = st[39];
+    L.ginit = (S)st[27]; L.gtest = (S)st[28]; L.gx = (S)st[29]; L.gy = (S)st[30]; L.finit = (S)st[31]; L.fx = (S)st[32];
+    L.fy = (S)st[33]; L.stx = (S)st[34]; L.sty = (S)st[35]; L.stmin = (S)st[36]; L.stmax = (S)st[37]; L.width = (S)st[38];
+    L.width1 = (S)st[39];
 #pragma unroll
     for (int k = 0; k < 12; ++k) be.cst[k] = st[40 + k];
   }
@@ -579,7 +598,7 @@ __global__ __launch_bounds__(kWave) void eval_kernel(int B, int M, DevParams prm
                                                       double *__restrict__ grad, double *__restrict__ coeffs,
                                                       int *__restrict__ status) {
   __shared__ __attribute__((aligned(16))) double xs[stage_doubles<D, NS, Real>()];
-  __shared__ LineSearch lsm;
+  __shared__ LineSearchT<opt_scalar_t<Num, NS>> lsm;
   __shared__ double cst[12];
   __shared__ Num bnd[6 * D];
   // all-fp32 mode, lane = (piece, dimension): the cyclic reduction's multipliers stay in LDS for the adjoint pass
@@ -647,7 +666,7 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
                                                           double *state, int state_doubles, int budget, int resume,
                                                           int traj_total) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
-  __shared__ LineSearch lsm;
+  __shared__ LineSearchT<opt_scalar_t<Num, NS>> lsm;
   __shared__ double cst[12];
   __shared__ Num bnd[6 * D];
   // the all-fp32 kernels keep the last lane assignment (DevBackend::sl_cache; launch_opt counts its 336 bytes)
@@ -737,7 +756,9 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
           suspended = true;
           break;
         }
-        const int est = be.eval(mach.x, mach.f, mach.g, mach.costs());
+        double fe;
+        const int est = be.eval(mach.x, fe, mach.g, mach.costs());
+        mach.f = (typename BE::Scalar)fe;
         mach.advance(est);
         ++evals;
       }
@@ -745,7 +766,9 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
       mach.x = xv;
       mach.begin();
       while (mach.need_eval()) {
-        const int est = be.eval(mach.x, mach.f, mach.g, mach.costs());
+        double fe;
+        const int est = be.eval(mach.x, fe, mach.g, mach.costs());
+        mach.f = (typename BE::Scalar)fe;
         mach.advance(est);
       }
     }

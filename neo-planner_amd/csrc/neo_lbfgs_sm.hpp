@@ -25,16 +25,24 @@
 
 namespace neo {
 
+// the type of the run's scalars (f, the step, g . d, theta, the line-search state): double unless the backend names
+// another -- the all-fp32 device kernels run them in fp32 (Backend::Scalar = float, neo_kernels.hpp)
+template <class B, class = void>
+struct backend_scalar { using type = double; };
+template <class B>
+struct backend_scalar<B, std::void_t<typename B::Scalar>> { using type = typename B::Scalar; };
+
 template <class Backend>
 struct LbfgsMachine {
   using Vec = typename Backend::Vec;
+  using S = typename backend_scalar<Backend>::type;
   enum : int { PH_FIRST = 0, PH_LS = 1, PH_DONE = 2 };
   enum : int { DO_START_ITER = 0, DO_LS_CONT = 1, DO_SUCCESS = 2, DO_FAILED = 3, DO_RETURN = 4 };
 
   Backend &be;
   LbfgsOpts o;
   Vec x, g, t, r, d, tmp, tmp2;
-  double f = 0.0, fold = 0.0, stp = 0.0, gd = 0.0, gdold = 0.0, theta = 1.0, stp_evaluated = -1.0;
+  S f = 0, fold = 0, stp = 0, gd = 0, gdold = 0, theta = 1, stp_evaluated = -1;
   int nfev = 0, nit = 0, iter = 0, col = 0, head = 0, task = LS_START, ifun = 0;
   int phase = PH_FIRST, status = -1;
 
@@ -49,7 +57,7 @@ struct LbfgsMachine {
     phase = PH_FIRST;
     status = -1;
     nfev = nit = iter = col = head = 0;
-    theta = 1.0;
+    theta = 1;
   }
 
   NEO_HD void finish(int st) {
@@ -71,31 +79,31 @@ struct LbfgsMachine {
   // after be.eval(x, f, g, costs()) returned `est`
   NEO_HD void advance(int est) {
     NEO_MARK("advance_begin");
-    const double epsmch = 2.220446049250313e-16;
-    const double big = 1.0e10;
+    const S epsmch = S(2.220446049250313e-16);  // (the fp64 value in the all-fp32 runs too: the same pairs skipped)
+    const S big = S(1.0e10);
     int next;
     if (phase == PH_FIRST) {
       nfev++;
-      be.note_eval(nfev, 0, 0.0, f, x, g);
+      be.note_eval(nfev, 0, 0.0, (double)f, x, g);
       for (int k = 0; k < 4; ++k) cur()[k] = costs()[k];
       if (est != 0) return finish(est);
-      if (!(f - f == 0.0)) return finish(TERM_NONFINITE);
+      if (!(f - f == S(0))) return finish(TERM_NONFINITE);
       if (be.amax(g) <= o.gtol) return finish(TERM_CONVERGED_GRAD);
       phase = PH_LS;
       next = DO_START_ITER;
     } else {
       // an evaluation inside the line search
       nfev++;
-      be.note_eval(nfev, iter, stp, f, x, g);
+      be.note_eval(nfev, iter, (double)stp, (double)f, x, g);
       if (est != 0) {
         for (int k = 0; k < 4; ++k) cur()[k] = costs()[k];
         return finish(est);
       }
-      if (!(f - f == 0.0)) {
+      if (!(f - f == S(0))) {
         for (int k = 0; k < 4; ++k) cur()[k] = costs()[k];
         return finish(TERM_NONFINITE);
       }
-      gd = be.dot(g, d);
+      gd = (S)be.dot(g, d);
       task = LS_FG;
       next = DO_LS_CONT;
     }
@@ -114,22 +122,22 @@ struct LbfgsMachine {
         fold = f;
         for (int k = 0; k < 4; ++k) old()[k] = cur()[k];
         // (lnsrlb forms |d| every iteration but, without bounds, uses it only for the first step)
-        stp = 1.0;
-        if (iter == 0) stp = be.uni(fmin(1.0 / sqrt(be.dot(d, d)), big));
-        gd = be.dot(g, d);
+        stp = 1;
+        if (iter == 0) stp = be.uni(fmin(S(1) / sqrt((S)be.dot(d, d)), big));
+        gd = (S)be.dot(g, d);
         gdold = gd;
-        if (gd >= 0.0) {
+        if (gd >= S(0)) {
           next = DO_FAILED;  // "ascent direction in projection": info = -4
         } else {
-          LineSearch &L = be.ls();
-          L.ftol = 1.0e-3;
-          L.gtol = 0.9;
-          L.xtol = 0.1;
-          L.stpmin = 0.0;
+          auto &L = be.ls();
+          L.ftol = S(1.0e-3);
+          L.gtol = S(0.9);
+          L.xtol = S(0.1);
+          L.stpmin = S(0);
           L.stpmax = big;
           task = LS_START;
           ifun = 0;
-          stp_evaluated = -1.0;
+          stp_evaluated = -1;
           next = DO_LS_CONT;
         }
       } else if (next == DO_LS_CONT) {
@@ -166,7 +174,7 @@ struct LbfgsMachine {
         if (col == 0) return finish(TERM_ABNORMAL);
         col = 0;
         head = 0;
-        theta = 1.0;
+        theta = 1;
         next = DO_START_ITER;  // RESTART_FROM_LNSRCH: same iteration, steepest descent, stp = 1
       } else {  // DO_SUCCESS: NEW_X
         NEO_MARK("newx_begin");
@@ -175,14 +183,14 @@ struct LbfgsMachine {
         for (int k = 0; k < 4; ++k) cur()[k] = costs()[k];
         if (be.amax(g) <= o.gtol) return finish(TERM_CONVERGED_GRAD);
         {
-          const double ddum = fmax(fmax(fabs(fold), fabs(f)), 1.0);
-          if ((fold - f) <= o.ftol * ddum) return finish(TERM_CONVERGED_F);
+          const S ddum = fmax(fmax(fabs(fold), fabs(f)), S(1));
+          if ((fold - f) <= (S)o.ftol * ddum) return finish(TERM_CONVERGED_F);
         }
         if (nit >= o.maxiter || nfev > o.maxfun) return finish(TERM_MAXITER);
         // ---- update the limited-memory pairs (mainlb + matupd)
         be.lincomb(r, g, -1.0, r);  // r = g - g_old = y
-        double dr, ddum;
-        if (stp == 1.0) {
+        S dr, ddum;
+        if (stp == S(1)) {
           dr = gd - gdold;
           ddum = -gdold;
         } else {
@@ -192,7 +200,7 @@ struct LbfgsMachine {
         }
         next = DO_START_ITER;
         if (dr <= epsmch * ddum) continue;  // skip the update, keep the old memory
-        const double rr = be.dot(r, r);
+        const S rr = (S)be.dot(r, r);
         int slot;
         if (col < o.m) {
           slot = (head + col) % o.m;
@@ -202,7 +210,7 @@ struct LbfgsMachine {
           head = (head + 1) % o.m;
         }
         be.hist_put(slot, d, r);
-        be.sput(slot, 1.0 / dr);
+        be.sput(slot, S(1) / dr);
         theta = be.uni(rr / dr);
         NEO_MARK("newx_end");
       }

@@ -24,32 +24,38 @@ namespace neo {
 
 enum LsTask : int { LS_START = 0, LS_FG = 1, LS_CONVERGENCE = 2, LS_WARNING = 3, LS_ERROR = 4 };
 
-struct LineSearch {
+// T: the arithmetic of the search's scalars -- double everywhere but in the all-fp32 device kernels (round 5: there f and g . d
+// arrive as fp32 values and the fp64 divisions and square root of dcstep sat on every evaluation's dependent chain)
+template <typename T>
+struct LineSearchT {
   // parameters (lnsrlb: ftol = 1e-3, gtol = 0.9, xtol = 0.1, stpmin = 0)
-  double ftol, gtol, xtol, stpmin, stpmax;
+  T ftol, gtol, xtol, stpmin, stpmax;
   // saved state between calls
   int brackt, stage;
-  double ginit, gtest, gx, gy, finit, fx, fy, stx, sty, stmin, stmax, width, width1;
+  T ginit, gtest, gx, gy, finit, fx, fy, stx, sty, stmin, stmax, width, width1;
 };
 
-NEO_HD double ls_max3(double a, double b, double c) { return fmax(fmax(a, b), c); }
+template <typename T>
+NEO_HD T ls_max3(T a, T b, T c) { return fmax(fmax(a, b), c); }
 
 // safeguarded cubic/quadratic step; updates the interval [stx, sty] and stp
-struct StepInterval {
-  double stx, fx, dx, sty, fy, dy, stp;
+template <typename T>
+struct StepIntervalT {
+  T stx, fx, dx, sty, fy, dy, stp;
   int brackt;
 };
 
 // (the interval goes in and out BY VALUE: with reference parameters the device compiler kept it in a private-memory
 //  array -- the only scratch use of the optimiser kernels)
-NEO_HD StepInterval dcstep(const StepInterval in, double fp, double dp, double stpmin, double stpmax) {
-  double stx = in.stx, fx = in.fx, dx = in.dx, sty = in.sty, fy = in.fy, dy = in.dy, stp = in.stp;
+template <typename T>
+NEO_HD StepIntervalT<T> dcstep(const StepIntervalT<T> in, T fp, T dp, T stpmin, T stpmax) {
+  T stx = in.stx, fx = in.fx, dx = in.dx, sty = in.sty, fy = in.fy, dy = in.dy, stp = in.stp;
   int brackt = in.brackt;
-  double gamma, p, q, r, s, stpc, stpf, stpq, theta;
-  const double sgnd = dp * (dx / fabs(dx));
+  T gamma, p, q, r, s, stpc, stpf, stpq, theta;
+  const T sgnd = dp * (dx / fabs(dx));
   if (fp > fx) {
     // case 1: higher function value -> minimum bracketed
-    theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    theta = T(3.0) * (fx - fp) / (stp - stx) + dx + dp;
     s = ls_max3(fabs(theta), fabs(dx), fabs(dp));
     gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
     if (stp < stx) gamma = -gamma;
@@ -57,15 +63,15 @@ NEO_HD StepInterval dcstep(const StepInterval in, double fp, double dp, double s
     q = ((gamma - dx) + gamma) + dp;
     r = p / q;
     stpc = stx + r * (stp - stx);
-    stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
+    stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / T(2.0)) * (stp - stx);
     if (fabs(stpc - stx) < fabs(stpq - stx))
       stpf = stpc;
     else
-      stpf = stpc + (stpq - stpc) / 2.0;
+      stpf = stpc + (stpq - stpc) / T(2.0);
     brackt = 1;
-  } else if (sgnd < 0.0) {
+  } else if (sgnd < T(0.0)) {
     // case 2: lower function value, derivatives of opposite sign
-    theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    theta = T(3.0) * (fx - fp) / (stp - stx) + dx + dp;
     s = ls_max3(fabs(theta), fabs(dx), fabs(dp));
     gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
     if (stp > stx) gamma = -gamma;
@@ -81,14 +87,14 @@ NEO_HD StepInterval dcstep(const StepInterval in, double fp, double dp, double s
     brackt = 1;
   } else if (fabs(dp) < fabs(dx)) {
     // case 3: lower function value, same sign, derivative magnitude decreases
-    theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    theta = T(3.0) * (fx - fp) / (stp - stx) + dx + dp;
     s = ls_max3(fabs(theta), fabs(dx), fabs(dp));
-    gamma = s * sqrt(fmax(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+    gamma = s * sqrt(fmax(T(0.0), (theta / s) * (theta / s) - (dx / s) * (dp / s)));
     if (stp > stx) gamma = -gamma;
     p = (gamma - dp) + theta;
     q = (gamma + (dx - dp)) + gamma;
     r = p / q;
-    if (r < 0.0 && gamma != 0.0)
+    if (r < T(0.0) && gamma != T(0.0))
       stpc = stp + r * (stx - stp);
     else if (stp > stx)
       stpc = stpmax;
@@ -101,9 +107,9 @@ NEO_HD StepInterval dcstep(const StepInterval in, double fp, double dp, double s
       else
         stpf = stpq;
       if (stp > stx)
-        stpf = fmin(stp + 0.66 * (sty - stp), stpf);
+        stpf = fmin(stp + T(0.66) * (sty - stp), stpf);
       else
-        stpf = fmax(stp + 0.66 * (sty - stp), stpf);
+        stpf = fmax(stp + T(0.66) * (sty - stp), stpf);
     } else {
       if (fabs(stpc - stp) > fabs(stpq - stp))
         stpf = stpc;
@@ -115,7 +121,7 @@ NEO_HD StepInterval dcstep(const StepInterval in, double fp, double dp, double s
   } else {
     // case 4: lower function value, same sign, derivative does not decrease
     if (brackt) {
-      theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
+      theta = T(3.0) * (fp - fy) / (sty - stp) + dy + dp;
       s = ls_max3(fabs(theta), fabs(dy), fabs(dp));
       gamma = s * sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
       if (stp > sty) gamma = -gamma;
@@ -136,7 +142,7 @@ NEO_HD StepInterval dcstep(const StepInterval in, double fp, double dp, double s
     fy = fp;
     dy = dp;
   } else {
-    if (sgnd < 0.0) {
+    if (sgnd < T(0.0)) {
       sty = stx;
       fy = fx;
       dy = dx;
@@ -146,7 +152,7 @@ NEO_HD StepInterval dcstep(const StepInterval in, double fp, double dp, double s
     dx = dp;
   }
   stp = stpf;
-  StepInterval out;
+  StepIntervalT<T> out;
   out.stx = stx;
   out.fx = fx;
   out.dx = dx;
@@ -160,29 +166,30 @@ NEO_HD StepInterval dcstep(const StepInterval in, double fp, double dp, double s
 
 // one reverse-communication call.  task in: LS_START or LS_FG (f, g evaluated at stp);
 // task out: LS_FG (evaluate at the new stp), LS_CONVERGENCE, LS_WARNING or LS_ERROR.
-NEO_HD int dcsrch(LineSearch &L, double f, double g, double &stp, int task) {
-  const double xtrapl = 1.1, xtrapu = 4.0;
+template <typename T>
+NEO_HD int dcsrch(LineSearchT<T> &L, T f, T g, T &stp, int task) {
+  const T xtrapl = T(1.1), xtrapu = T(4.0);
   if (task == LS_START) {
-    if (stp < L.stpmin || stp > L.stpmax || g >= 0.0) return LS_ERROR;
+    if (stp < L.stpmin || stp > L.stpmax || g >= T(0.0)) return LS_ERROR;
     L.brackt = 0;
     L.stage = 1;
     L.finit = f;
     L.ginit = g;
     L.gtest = L.ftol * L.ginit;
     L.width = L.stpmax - L.stpmin;
-    L.width1 = L.width / 0.5;
-    L.stx = 0.0;
+    L.width1 = L.width / T(0.5);
+    L.stx = T(0.0);
     L.fx = L.finit;
     L.gx = L.ginit;
-    L.sty = 0.0;
+    L.sty = T(0.0);
     L.fy = L.finit;
     L.gy = L.ginit;
-    L.stmin = 0.0;
+    L.stmin = T(0.0);
     L.stmax = stp + xtrapu * stp;
     return LS_FG;
   }
-  const double ftest = L.finit + stp * L.gtest;
-  if (L.stage == 1 && f <= ftest && g >= 0.0) L.stage = 2;
+  const T ftest = L.finit + stp * L.gtest;
+  if (L.stage == 1 && f <= ftest && g >= T(0.0)) L.stage = 2;
 
   int out = LS_FG;
   // later tests overwrite earlier ones, convergence overwrites warnings
@@ -198,8 +205,8 @@ NEO_HD int dcsrch(LineSearch &L, double f, double g, double &stp, int task) {
   // the interval in a private-memory array selected by pointer); the arithmetic of each case is unchanged.
   {
     const bool modified = L.stage == 1 && f <= L.fx && f > ftest;
-    double stx = L.stx, sty = L.sty, fx = L.fx, fy = L.fy, gx = L.gx, gy = L.gy;
-    double fp = f, gp = g;
+    T stx = L.stx, sty = L.sty, fx = L.fx, fy = L.fy, gx = L.gx, gy = L.gy;
+    T fp = f, gp = g;
     int brackt = L.brackt;
     if (modified) {
       fp = f - stp * L.gtest;
@@ -209,7 +216,7 @@ NEO_HD int dcsrch(LineSearch &L, double f, double g, double &stp, int task) {
       gx = L.gx - L.gtest;
       gy = L.gy - L.gtest;
     }
-    StepInterval iv;
+    StepIntervalT<T> iv;
     iv.stx = stx; iv.fx = fx; iv.dx = gx; iv.sty = sty; iv.fy = fy; iv.dy = gy; iv.stp = stp; iv.brackt = brackt;
     iv = dcstep(iv, fp, gp, L.stmin, L.stmax);
     stx = iv.stx; fx = iv.fx; gx = iv.dx; sty = iv.sty; fy = iv.fy; gy = iv.dy; stp = iv.stp; brackt = iv.brackt;
@@ -228,7 +235,7 @@ NEO_HD int dcsrch(LineSearch &L, double f, double g, double &stp, int task) {
     L.brackt = brackt;
   }
   if (L.brackt) {
-    if (fabs(L.sty - L.stx) >= 0.66 * L.width1) stp = L.stx + 0.5 * (L.sty - L.stx);
+    if (fabs(L.sty - L.stx) >= T(0.66) * L.width1) stp = L.stx + T(0.5) * (L.sty - L.stx);
     L.width1 = L.width;
     L.width = fabs(L.sty - L.stx);
   }
@@ -246,5 +253,7 @@ NEO_HD int dcsrch(LineSearch &L, double f, double g, double &stp, int task) {
     stp = L.stx;
   return LS_FG;
 }
+
+using LineSearch = LineSearchT<double>;  // (the fp64 modes, the host harness)
 
 }  // namespace neo
