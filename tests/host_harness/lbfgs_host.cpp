@@ -199,4 +199,19 @@ int dcsrch_host(double *state, double f, double g, double *stp, int task, double
   }
   return neo::dcsrch(*L, f, g, *stp, task);
 }
+
+// the same search on fp32 scalars (LineSearchT<float>: what the all-fp32 device kernels instantiate)
+int dcsrch_host_f32(float *state, float f, float g, float *stp, int task, float ftol, float gtol, float xtol,
+                    float stpmin, float stpmax) {
+  static_assert(sizeof(neo::LineSearchT<float>) <= 20 * sizeof(float), "state blob too small");
+  neo::LineSearchT<float> *L = reinterpret_cast<neo::LineSearchT<float> *>(state);
+  if (task == neo::LS_START) {
+    L->ftol = ftol;
+    L->gtol = gtol;
+    L->xtol = xtol;
+    L->stpmin = stpmin;
+    L->stpmax = stpmax;
+  }
+  return neo::dcsrch(*L, f, g, *stp, task);
+}
 }

@@ -115,6 +115,53 @@ def test_dcsrch_matches_scipy(lib):
     assert checked > 100
 
 
+def test_dcsrch_on_fp32_scalars_follows_the_fp64_search(lib):
+    """LineSearchT<float> (the all-fp32 device kernels): the same search, rounded to fp32 -- on smooth 1-D functions its
+    trial steps are those of the fp64 instantiation to fp32 accuracy and it stops with the same verdict."""
+    f32 = ctypes.c_float
+    lib.dcsrch_host_f32.restype = ctypes.c_int
+    lib.dcsrch_host_f32.argtypes = [ctypes.POINTER(f32), f32, f32, ctypes.POINTER(f32), ctypes.c_int] + [f32] * 5
+    rng = np.random.default_rng(11)
+    same, checked = 0, 0
+    for trial in range(300):
+        a, b, c = rng.normal(0, 1, 3)
+
+        def phi(s):
+            return (a * a + 0.1) * (s - 1.3 * abs(b)) ** 2 + 0.3 * np.sin(2 * c * s)
+
+        def dphi(s):
+            return 2 * (a * a + 0.1) * (s - 1.3 * abs(b)) + 0.6 * c * np.cos(2 * c * s)
+
+        if dphi(0.0) >= -1e-3:
+            continue
+        stp0 = float(rng.choice([1.0, 0.3]))
+        st64 = (ctypes.c_double * 20)()
+        s64 = ctypes.c_double(stp0)
+        t64 = lib.dcsrch_host(st64, phi(0.0), dphi(0.0), ctypes.byref(s64), 0, 1e-3, 0.9, 0.1, 0.0, 1e10)
+        st32 = (f32 * 20)()
+        s32 = f32(stp0)
+        t32 = lib.dcsrch_host_f32(st32, phi(0.0), dphi(0.0), ctypes.byref(s32), 0, 1e-3, 0.9, 0.1, 0.0, 1e10)
+        steps64, steps32 = [], []
+        k = 0
+        while t64 == 1 and k < 25:
+            steps64.append(s64.value)
+            t64 = lib.dcsrch_host(st64, phi(s64.value), dphi(s64.value), ctypes.byref(s64), 1, 1e-3, 0.9, 0.1, 0.0, 1e10)
+            k += 1
+        k = 0
+        while t32 == 1 and k < 25:
+            steps32.append(s32.value)
+            t32 = lib.dcsrch_host_f32(st32, phi(s32.value), dphi(s32.value), ctypes.byref(s32), 1, 1e-3, 0.9, 0.1, 0.0, 1e10)
+            k += 1
+        checked += 1
+        assert t32 in (2, 3)                       # the fp32 search always ends: convergence or a warning
+        assert steps32[0] == np.float32(steps64[0])  # (the first trial step is the caller's)
+        if len(steps32) == len(steps64) and t32 == t64 and np.allclose(steps32, steps64, rtol=2e-4, atol=0):
+            same += 1
+    assert checked > 100
+    # (a search that stops on a tie of the sufficient-decrease test may take one trial more or less in fp32)
+    assert same >= 0.95 * checked, (same, checked)
+
+
 def _oracle_objective(d, init_wpts, init_ts):
     occ = d["occ"]
     m = onp.GridESDF(occ, float(d["res"]), occ.shape[1], occ.shape[0], d["origin"])
