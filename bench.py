@@ -327,7 +327,7 @@ def compact_line(out, details_path=None):
     if "f64" in modes:
         # the mode that computes in the reference's own arithmetic and meets its 1e-4 as often as the reference meets itself
         line["value_parity_mode"] = modes["f64"].get("value")
-    line.update(_pick(out, ("accepted_traj_per_s", "accepted_frac", "single_batch_ms", "single_batch_traj_per_s")))
+    line.update(_pick(out, ("accepted_traj_per_s", "accepted_frac", "single_batch_ms", "single_batch_traj_per_s", "single_batch_ms_range")))
     sb = out.get("single_batch_budget")
     if sb and sb.get("budgets"):
         b0 = sb["budgets"][0]
@@ -644,17 +644,23 @@ class Rank:
         launches, kms = self.kernel_time(self._lib.NEO_KERNEL_OPTIMIZE)
         # one launch ALONE on the chip (outside the timed region): what a caller with a single request batch gets -- with
         # `--streams` launches in flight each one lasts longer than it would by itself
-        solo = None
+        # A launch alone lasts as long as its LONGEST run (one wavefront, ~600 evaluations of a mean of 135), and which run
+        # that is changes with the last bit of the arithmetic: the figure is the mean over the step's first eight request
+        # batches, each launched by itself (round 5; batch 0 alone moved 6.05 -> 6.99 ms with a change that made every
+        # evaluation faster), the range beside it.
+        solo, solo_range = None, None
         if self.rank == 0 and not self.use_dist:
-            ctx.check(ctx.lib.neo_profile_reset(ctx.h))
-            ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
-            for _ in range(3):
-                self.launch(self.batches[0], bpm)
+            each = []
+            for bt in self.batches[:8]:
+                ctx.check(ctx.lib.neo_profile_reset(ctx.h))
+                ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
+                self.launch(bt, bpm)
                 self.fence()
-            ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
+                ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
+                l_s, m_s = self.kernel_time(self._lib.NEO_KERNEL_OPTIMIZE)
+                each.append(m_s / max(l_s, 1))
             ctx.set_stream(None)
-            l_s, m_s = self.kernel_time(self._lib.NEO_KERNEL_OPTIMIZE)
-            solo = m_s / max(l_s, 1)
+            solo, solo_range = sum(each) / len(each), [min(each), max(each)]
         nfev_all = torch.stack([bt["nfev"] for bt in self.batches]).cpu().numpy().astype(np.int64)
         nsamp_all = torch.stack([bt["nsamp"] for bt in self.batches]).cpu().numpy()
         status_all = torch.stack([bt["status"] for bt in self.batches]).cpu().numpy()
@@ -664,7 +670,7 @@ class Rank:
         # algorithmic bytes of ONE launch, mean over the step's batches: S*C*e per evaluation + 2*n*4 + 20
         bytes_launch = (float(nsamp_all.sum()) * 8 * self.esz + float(nfev_all.sum()) * (2 * self.n * 4 + 20)) / self.n_sets
         b0_ = self.batches[0]
-        return dict(mode=mode, elapsed=el, kernel_ms=kms / max(launches, 1), launches=launches, nfev_all=nfev_all, solo_ms=solo,
+        return dict(mode=mode, elapsed=el, kernel_ms=kms / max(launches, 1), launches=launches, nfev_all=nfev_all, solo_ms=solo, solo_ms_range=solo_range,
                     nsamp_all=nsamp_all, status_all=status_all, accepted_frac=float(accepted.mean()),
                     bytes_launch=bytes_launch, mean_nit=float(b0_["nit"].float().mean().item()),
                     b0=dict(x=b0_["x"].clone(), last=b0_["last"].clone(), nfev=b0_["nfev"].clone()))
@@ -804,6 +810,7 @@ def main():
             # what a caller with ONE request batch gets: a single launch of B trajectories alone on the chip (`value` keeps
             # `--streams` launches in flight and is the throughput figure)
             "single_batch_ms": solo_ms, "single_batch_traj_per_s": (B / (solo_ms * 1e-3)) if solo_ms else None,
+            "single_batch_ms_range": main_run.get("solo_ms_range"),   # (mean and range over the first eight batches)
             "config": {"workload": f"{a.config}: {n_sets} x {B} trajectories x {M - 1} waypoints per step per GPU, "
                                    f"{R.n_scenes} x {a.grid}^3 {R.store} ESDF per GPU (trilinear, " +
                                    ("planar requests" if a.planar else f"pillars + {CANOPY} canopy boxes") +

@@ -119,7 +119,8 @@ typedef struct neo_params {
  * and results agree with the default kernel to fp32 rounding, not bit for bit. */
 #define NEO_FLAG_LANE_GROUPS 128
 /* all-fp32 evaluation (fp32 sampling; 3-D fields and the 2-D reference map): the coefficient solve, the adjoint pass and the optimiser's vectors
- * and stored pairs in fp32 too, two wavefronts per SIMD.  Per evaluation the cost and gradient then agree with the
+ * and stored pairs in fp32 too -- for n <= 128 variables also the optimiser's scalars and the line search --, three
+ * wavefronts per SIMD for n <= 128, two beyond.  Per evaluation the cost and gradient then agree with the
  * fp64 solve to ~1e-5 instead of 2e-6; the optimiser's statistics (evaluations, final costs) are those of the default
  * mode.  Opt-in throughput mode. */
 #define NEO_FLAG_F32_SOLVE 2048
