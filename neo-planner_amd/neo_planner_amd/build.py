@@ -1,7 +1,9 @@
 """Builds libneo_planner_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
 The library is several translation units -- the C ABI plus one unit per kernel family (neo_disp_*.hip) -- compiled
-in parallel and linked into one shared object; objects are cached under csrc/build/ by source time stamps."""
+in parallel and linked into one shared object.  Objects are cached under csrc/build/ by CONTENT: an object's name carries a
+hash of its command line, its source and every header; the library's stamp file the hash of all of them.  Time stamps
+play no part (a checkout that restores a file, or a copy of the tree that does not keep them, rebuilds nothing)."""
 import concurrent.futures
 import hashlib
 import os
@@ -18,7 +20,7 @@ SOURCES = ["neo_abi.hip", "neo_disp_eval.hip", "neo_disp_sample.hip", "neo_disp_
            "neo_disp_opt3d_f64.hip", "neo_disp_opt3d_w2.hip", "neo_disp_opt3d_x.hip", "neo_disp_group.hip", "neo_disp_opt3d_b.hip"]
 HEADERS = ["neo_device.hpp", "neo_kernels.hpp", "neo_host.hpp", "neo_launch_opt.hpp", "neo_lbfgs.hpp",
            "neo_linesearch.hpp", "neo_lbfgs_sm.hpp", "neo_lbfgs_dir.hpp", "neo_group_kernel.hpp"]
-STAMP = LIB + ".stamp"    # key of the command lines the library was built with (travels with the library)
+STAMP = LIB + ".stamp"    # hash of command lines + sources + headers the library was built from (travels with the library)
 
 
 def _hipcc():
@@ -50,12 +52,22 @@ def _flags():
         os.environ.get("NEO_BUILD_DEFS", "").split()
 
 
-def _newest_header():
+def _headers():
     deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "neo_planner.h")]
-    if "NEO_SAMPLE_EXPERIMENTS" in os.environ.get("NEO_BUILD_DEFS", ""):     # neo_disp_sample.hip then includes these
-        probe = os.path.join(os.path.dirname(os.path.dirname(PKG)), "tools", "probe")
+    defs = os.environ.get("NEO_BUILD_DEFS", "")
+    probe = os.path.join(os.path.dirname(os.path.dirname(PKG)), "tools", "probe")
+    if "NEO_SAMPLE_EXPERIMENTS" in defs:     # neo_disp_sample.hip then includes these
         deps += [os.path.join(probe, h) for h in ("neo_sample_chunk.hpp", "neo_sample_wg.hpp")]
-    return max(os.path.getmtime(d) for d in deps)
+    if "NEO_SAMPLE_SHARED_TAILS" in defs:    # neo_kernels.hpp then includes this one
+        deps.append(os.path.join(probe, "neo_sample_shared.hpp"))
+    return deps
+
+
+def _headers_hash():
+    h = hashlib.sha256()
+    for d in _headers():
+        h.update(os.path.basename(d).encode() + b"\0" + open(d, "rb").read() + b"\0")
+    return h.hexdigest()
 
 
 # per-unit compiler options: the all-fp32 optimiser kernels are allocated for three wavefronts per SIMD (168 registers);
@@ -87,13 +99,16 @@ def _compile(src, obj, verbose):
     os.replace(obj + ".tmp", obj)
 
 
-def _key(src=None):
-    """hash of everything besides the sources that decides what the compiler produces: this file (options, per-unit
-    options, source list) and the experiment definitions -- an object or library built with other options is not
-    reused"""
+def _key(src=None, headers_hash=None):
+    """hash of everything that decides what the compiler produces: this file (options, per-unit options, source list), the
+    experiment definitions, the headers and the source(s) -- of unit `src`, or of the whole library (src None).  An object
+    or library built from anything else is not reused (options; round 5: contents instead of time stamps)"""
     h = hashlib.sha256()
     h.update(open(os.path.abspath(__file__), "rb").read())
     h.update(" ".join(_flags() + (_unit_flags(src) if src else [])).encode())
+    h.update((headers_hash or _headers_hash()).encode())
+    for s in ([src] if src else SOURCES):
+        h.update(s.encode() + b"\0" + open(os.path.join(CSRC, s), "rb").read() + b"\0")
     return h.hexdigest()[:12]
 
 
@@ -104,17 +119,17 @@ def build(force=False, verbose=False, jobs=None):
         # an experiment build must never replace the in-tree product library: _lib.load() would silently use it
         raise RuntimeError("NEO_BUILD_DEFS is for experiment builds: set NEO_BUILD_OUT=<path of the experiment library> as well "
                            "(and NEO_PLANNER_LIB=<that path> when running it)")
-    src_t = max([_newest_header()] + [os.path.getmtime(os.path.join(CSRC, s)) for s in SOURCES])
+    hh = _headers_hash()
+    lib_key = _key(None, hh)
     stamp = open(STAMP).read().strip() if os.path.exists(STAMP) else ""
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= src_t and stamp == _key():
-        return LIB          # (the GPU box receives the built library without the object cache)
+    if not force and os.path.exists(LIB) and stamp == lib_key:
+        return LIB          # (the GPU box receives the built library and its stamp without the object cache)
     os.makedirs(OBJDIR, exist_ok=True)
-    hdr_t = _newest_header()
     todo, objs = [], []
     for s in SOURCES:
-        obj = os.path.join(OBJDIR, s.replace(".hip", "." + _key(s) + ".o"))
+        obj = os.path.join(OBJDIR, s.replace(".hip", "." + _key(s, hh) + ".o"))
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(os.path.join(CSRC, s))):
+        if force or not os.path.exists(obj):
             todo.append((s, obj))
     jobs = jobs or int(os.environ.get("NEO_BUILD_JOBS", "0")) or min(len(todo) or 1, os.cpu_count() or 1, 8)
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(jobs, 1)) as ex:
@@ -126,7 +141,7 @@ def build(force=False, verbose=False, jobs=None):
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
     with open(STAMP, "w") as f:
-        f.write(_key() + "\n")
+        f.write(lib_key + "\n")
     return LIB
 
 
