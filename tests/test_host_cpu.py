@@ -117,3 +117,30 @@ def test_one_source_for_the_lane_group_kernel():
         assert dev.count(f" {fn}(") == 1, fn                      # defined once ...
         assert f"{fn}<" in grp and "GroupLanes<W>" in grp         # ... and instantiated for the groups
     assert "struct WaveLanes" in dev and "struct GroupLanes" in dev
+
+
+def test_build_cache_is_keyed_by_content_not_by_time_stamps(tmp_path, monkeypatch):
+    """neo_planner_amd/build.py: the library is up to date when its stamp equals the hash of command lines, sources and
+    headers -- touching a file changes nothing, changing a header or an option changes every key (no hipcc run here)"""
+    import shutil
+    from neo_planner_amd import build as b
+    if os.path.exists(b.STAMP) and os.path.exists(b.LIB):
+        assert open(b.STAMP).read().strip() == b._key()        # the in-tree library is the one these sources build
+    k_lib, k_unit = b._key(), b._key("neo_disp_sample.hip")
+    hdr = os.path.join(b.CSRC, "neo_linesearch.hpp")
+    st = os.stat(hdr)
+    os.utime(hdr, (st.st_atime, st.st_mtime + 1000))           # a newer time stamp ...
+    try:
+        assert b._key() == k_lib and b._key("neo_disp_sample.hip") == k_unit   # ... is no change
+    finally:
+        os.utime(hdr, (st.st_atime, st.st_mtime))
+    copy = tmp_path / "neo_linesearch.hpp"
+    shutil.copy(hdr, copy)
+    with open(copy, "a") as f:
+        f.write("// edited\n")
+    real = b._headers
+    monkeypatch.setattr(b, "_headers", lambda: [str(copy) if os.path.basename(d) == "neo_linesearch.hpp" else d for d in real()])
+    assert b._key() != k_lib and b._key("neo_disp_sample.hip") != k_unit       # a changed header: every key changes
+    monkeypatch.setattr(b, "_headers", real)
+    monkeypatch.setenv("NEO_FP_CONTRACT", "fast")
+    assert b._key() != k_lib                                                    # and so does a changed option
