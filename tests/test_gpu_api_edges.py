@@ -718,3 +718,32 @@ def test_all_fp32_multiplier_reuse_for_every_piece_count_and_both_maps():
                 #  the median jumps between the clusters with a handful of runs; the geometric mean moves with their share)
                 lg_on, lg_off = np.log10(r_on["final_cost"][both]), np.log10(r_off["final_cost"][both])
                 assert abs(lg_on.mean() - lg_off.mean()) <= 0.4, (D, M, lg_on.mean(), lg_off.mean())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f64", "f32", "f32x"])
+def test_a_non_finite_start_point_ends_its_own_run_only(mode):
+    """a NaN in one request's start point: that run ends at its first evaluation with NEO_TRAJ_NONFINITE (the objective is
+    NaN: L-BFGS-B has nothing to line-search on; NEO_TRAJ_NUMERIC_RANGE in the all-fp32 mode), x left as given; every other run of the batch is the run it is without
+    that request, bit for bit -- in all three arithmetic modes (the all-fp32 one carries f, the step and the line-search
+    state in fp32 since round 5)."""
+    grid = 96
+    res = 30.0 / grid
+    occ = synth.occupancy_3d(2, n=grid, res=res, canopy=10)
+    g3 = npa.ESDF3D.from_occupancy(occ, res, synth.DOMAIN_ORIGIN, store="f32", layout="brick")
+    M, B = 21, 96
+    h, t, w, ts = synth.replan_requests(7, B, M - 1, D=3, **synth.VOLUME)
+    bp = npa.BatchPlanner(sample_dtype=mode)
+    x0 = bp.pack_x(w, ts)
+    good = bp.optimize(g3, x0, h, t)
+    bad = x0.copy()
+    bad[17, 5] = np.nan
+    out = bp.optimize(g3, bad, h, t)
+    # NEO_TRAJ_NONFINITE; the all-fp32 evaluation reports NEO_TRAJ_NUMERIC_RANGE: there a jerk outside the fp32 range shows
+    # as inf or NaN and either raises the range flag (neo_device.hpp minco_backward), before the objective is looked at
+    assert out["status"][17] == (4 if mode == "f32x" else 5)
+    assert out["nfev"][17] == 1 and out["nit"][17] == 0
+    keep = np.arange(B) != 17
+    assert np.array_equal(out["x"][keep], good["x"][keep])
+    assert np.array_equal(out["nfev"][keep], good["nfev"][keep]) and np.array_equal(out["status"][keep], good["status"][keep])
+    assert np.array_equal(out["costs"][keep], good["costs"][keep])
