@@ -344,7 +344,8 @@ def compact_line(out, details_path=None):
     line["roofline"]["traffic_source"] = rf.get("traffic_source")
     es = out.get("esdf_kernel")
     if es:
-        e = _pick(es, ("kernel", "bound", "achieved", "peak", "unit", "frac", "kernel_us", "trajectories", "traffic",
+        e = _pick(es, ("kernel", "bound", "achieved", "peak", "unit", "frac", "kernel_us", "kernel_us_one_launch_per_event_pair",
+                       "frac_one_launch_per_event_pair", "operand_buffers", "trajectories", "traffic",
                        "traffic_over_algorithmic", "traffic_source", "lookups_per_fetched_line", "l2_hit_rate",
                        "orders_give_the_same_bits"))
         ws = es.get("whole_step_launch")

@@ -213,6 +213,14 @@ int neo_sampled_terms_batch(neo_ctx *ctx, int scene_id, int B, int M, int D, con
                             const double *ts, double *costs2, double *grad_C, double *grad_T);
 int neo_sampled_terms_batch_dev(neo_ctx *ctx, int scene_id, int B, int M, int D, const double *coeffs,
                                 const double *ts, double *costs2, double *grad_C, double *grad_T);
+/* the same with fp32 coefficient and partials buffers (round 6; sample_dtype NEO_F32 only, NEO_ERR_INVALID otherwise):
+ * half the operand bytes of the fp32 sampling path and no conversions in the kernel.  coeffs[B][6M][D] and
+ * grad_C[B][6M][D], grad_T[B][M] are floats; ts and costs2 stay doubles (int(T / delta_t) of :401 is taken in fp64).
+ * _dev: coeffs and grad_C must be 8-byte aligned. */
+int neo_sampled_terms_batch_f32(neo_ctx *ctx, int scene_id, int B, int M, int D, const float *coeffs,
+                                const double *ts, double *costs2, float *grad_C, float *grad_T);
+int neo_sampled_terms_batch_f32_dev(neo_ctx *ctx, int scene_id, int B, int M, int D, const float *coeffs,
+                                    const double *ts, double *costs2, float *grad_C, float *grad_T);
 
 /* ---- optimiser (expert_planner.py:205-237: plan_once) ----------------------
  * Runs L-BFGS-B(maxcor 10, no bounds) from x to termination for every trajectory,

@@ -1461,57 +1461,80 @@ int neo_cost_grad_batch(neo_ctx *c, int scene_id, int B, int M, int D, const dou
   return NEO_OK;
 }
 
-int neo_sampled_terms_batch_dev(neo_ctx *c, int scene_id, int B, int M, int D, const double *coeffs,
-                                const double *ts, double *costs2, double *grad_C, double *grad_T) {
+// IO32: coeffs / grad_C / grad_T are floats (the _f32 entry points; fp32 sampling only)
+static int sampled_terms_dev(neo_ctx *c, int scene_id, int B, int M, int D, const void *coeffs, const double *ts, double *costs2,
+                             void *grad_C, void *grad_T, bool io32) {
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
   if (!coeffs || !ts || !costs2 || !grad_C || !grad_T) return fail_locked(c, NEO_ERR_INVALID, "null buffer");
-  if (((uintptr_t)coeffs | (uintptr_t)grad_C) & 15)
-    return fail_locked(c, NEO_ERR_INVALID, "coeffs and grad_C must be 16-byte aligned");
+  if (((uintptr_t)coeffs | (uintptr_t)grad_C) & (io32 ? 7 : 15))
+    return fail_locked(c, NEO_ERR_INVALID, io32 ? "coeffs and grad_C must be 8-byte aligned" : "coeffs and grad_C must be 16-byte aligned");
   std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   auto it = c->maps.find(scene_id);
   if (it == c->maps.end()) return fail(c, NEO_ERR_NO_MAP, "no ESDF for this scene");
   if (B == 0) return NEO_OK;
   ProfScope ps(c, NEO_KERNEL_ESDF_SAMPLE);
-  const SampleArgs sa{B, M, coeffs, ts, costs2, grad_C, grad_T};
+  SampleArgs sa{B, M, coeffs, ts, costs2, grad_C, grad_T};
+  sa.io32 = io32;
   rc = dispatch_sample(c, it->second, D, sa);
   if (rc) return rc;
   HIPCHK(c, hipGetLastError());
   return NEO_OK;
 }
 
-int neo_sampled_terms_batch(neo_ctx *c, int scene_id, int B, int M, int D, const double *coeffs, const double *ts,
-                            double *costs2, double *grad_C, double *grad_T) {
+int neo_sampled_terms_batch_dev(neo_ctx *c, int scene_id, int B, int M, int D, const double *coeffs,
+                                const double *ts, double *costs2, double *grad_C, double *grad_T) {
+  return sampled_terms_dev(c, scene_id, B, M, D, coeffs, ts, costs2, grad_C, grad_T, false);
+}
+
+int neo_sampled_terms_batch_f32_dev(neo_ctx *c, int scene_id, int B, int M, int D, const float *coeffs,
+                                    const double *ts, double *costs2, float *grad_C, float *grad_T) {
+  return sampled_terms_dev(c, scene_id, B, M, D, coeffs, ts, costs2, grad_C, grad_T, true);
+}
+
+static int sampled_terms_host(neo_ctx *c, int scene_id, int B, int M, int D, const void *coeffs, const double *ts, double *costs2,
+                              void *grad_C, void *grad_T, bool io32) {
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
   if (!coeffs || !ts || !costs2 || !grad_C || !grad_T) return fail_locked(c, NEO_ERR_INVALID, "null buffer");
   if (B == 0) return NEO_OK;
   std::lock_guard<std::recursive_mutex> whole_call(c->mu);  // scratch buffers stay ours until the copies back are done
-  const size_t bs = (size_t)B, nc = (size_t)6 * M * D;
-  double *dco, *dts, *dc2, *dgc, *dgt;
+  const size_t bs = (size_t)B, nc = (size_t)6 * M * D, es = io32 ? sizeof(float) : sizeof(double);
+  void *dco, *dgc, *dgt;
+  double *dts, *dc2;
   {
     std::lock_guard<std::recursive_mutex> g(c->mu);
     hipSetDevice(c->device);
     rc = ensure_scratch(c, bs * (2 * nc + 2 * M + 2) * sizeof(double) + 6 * 256);
     if (rc) return rc;
     Carver cv(c->scratch);
-    dco = cv.take<double>(bs * nc);
+    dco = cv.take<double>(bs * nc);  // (sized for doubles either way)
     dts = cv.take<double>(bs * M);
     dc2 = cv.take<double>(bs * 2);
     dgc = cv.take<double>(bs * nc);
     dgt = cv.take<double>(bs * M);
-    HIPCHK(c, hipMemcpyAsync(dco, coeffs, bs * nc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dco, coeffs, bs * nc * es, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(dts, ts, bs * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
   }
-  rc = neo_sampled_terms_batch_dev(c, scene_id, B, M, D, dco, dts, dc2, dgc, dgt);
+  rc = sampled_terms_dev(c, scene_id, B, M, D, dco, dts, dc2, dgc, dgt, io32);
   if (rc) return rc;
   std::lock_guard<std::recursive_mutex> g(c->mu);
   HIPCHK(c, hipMemcpyAsync(costs2, dc2, bs * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(grad_C, dgc, bs * nc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(grad_T, dgt, bs * M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(grad_C, dgc, bs * nc * es, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(grad_T, dgt, bs * M * es, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return NEO_OK;
+}
+
+int neo_sampled_terms_batch(neo_ctx *c, int scene_id, int B, int M, int D, const double *coeffs, const double *ts,
+                            double *costs2, double *grad_C, double *grad_T) {
+  return sampled_terms_host(c, scene_id, B, M, D, coeffs, ts, costs2, grad_C, grad_T, false);
+}
+
+int neo_sampled_terms_batch_f32(neo_ctx *c, int scene_id, int B, int M, int D, const float *coeffs, const double *ts,
+                                double *costs2, float *grad_C, float *grad_T) {
+  return sampled_terms_host(c, scene_id, B, M, D, coeffs, ts, costs2, grad_C, grad_T, true);
 }
 
 // the L-BFGS pairs (2 * maxcor * n doubles per trajectory) live in LDS: no HBM workspace

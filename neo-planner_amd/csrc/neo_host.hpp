@@ -155,8 +155,11 @@ struct OptArgs {
 
 struct SampleArgs {
   int B, M;
-  const double *coeffs, *ts;
-  double *costs2, *grad_C, *grad_T;
+  const void *coeffs;  // [B][6M][D] doubles, or floats when io32
+  const double *ts;
+  double *costs2;
+  void *grad_C, *grad_T;  // doubles, or floats when io32
+  bool io32 = false;      // neo_sampled_terms_batch_f32_dev (fp32 sampling only)
 };
 
 // FLAT slots of the optimiser vectors: n <= 64, 128, 192 or 256 variables

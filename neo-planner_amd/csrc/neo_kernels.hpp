@@ -816,19 +816,27 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
 #define NEO_SAMPLE_U 1
 #endif
 #ifndef NEO_SAMPLE_OCC
-#define NEO_SAMPLE_OCC 4  // waves per SIMD the fp32 instantiations are allocated for
+// waves per SIMD the fp32 instantiations are allocated for.  Round 6: five (94 registers suffice): the launch over a whole
+// step's 163 840 requests 921 -> 731 us (more gathers in flight per CU); the 4096 launch, whose wavefronts are all
+// resident at four per SIMD anyway, is unchanged (23.9 us either way, same box)
+#define NEO_SAMPLE_OCC 5
 #endif
 // the body of sample_kernel (one wavefront per trajectory, lanes per piece) as a function: also the fallback path of
 // sample_chunk_kernel (neo_sample_chunk.hpp)
 // (round 5, measured and not adopted -- HISTORY.md: the coefficients loaded in the PIECE layout next to the durations and
 //  handed to the sample lanes through an LDS table, to take the coefficient load off the chain "durations -> lane
 //  assignment -> coefficients": 28.3 us against 27.9 us per 4096 launch; shared tail lanes, 10 rounds instead of 13 at a
-//  fresh guess: 31.1 us, tools/probe/neo_sample_shared.hpp)
-template <int D, typename Real, class MapT, class LookupT>
+//  fresh guess: 31.1 us, tools/probe/neo_sample_shared.hpp.  Round 6, same verdict -- HISTORY.md round 6 (1): the samples as ONE
+//  sequence dealt round-robin to the lanes with a candidate list, tools/probe/seq/; floor / clamp / brick address as single
+//  instructions through inline assembly: 8 % FEWER vector instructions and 10 % slower, 26.3 against 23.8 us)
+// IO: element type of the coefficient / partials buffers (double: neo_sampled_terms_batch[_dev]; float: the _f32 entry
+// points of the fp32 sampling path, round 6: half the operand bytes and no conversions)
+template <int D, typename Real, class MapT, class LookupT, typename IO = double>
 __device__ __forceinline__ void sample_wave_per_piece(int b, int M, const DevParams &prm, const MapT &map,
-                                                      const double *__restrict__ coeffs, const double *__restrict__ ts,
-                                                      double *__restrict__ costs2, double *__restrict__ grad_C,
-                                                      double *__restrict__ grad_T, int *seg, Real *rows) {
+                                                      const IO *__restrict__ coeffs, const double *__restrict__ ts,
+                                                      double *__restrict__ costs2, IO *__restrict__ grad_C,
+                                                      IO *__restrict__ grad_T, int *seg, Real *rows) {
+  typedef IO IOPair __attribute__((ext_vector_type(2)));
   const int lane = lane_id();
   // lanes in proportion to the pieces' sample counts, as in the fused kernels
   const double Tp = lane < M ? ts[(size_t)b * M + lane] : 1.0;
@@ -840,11 +848,11 @@ __device__ __forceinline__ void sample_wave_per_piece(int b, int M, const DevPar
   const int ns = act ? (int)(T / prm.delta_t) : 0;
   Real c[6][D], gC[6][D], gT;
   {
-    // the 6*D doubles of a piece are contiguous and 16-byte aligned (6*D is even)
-    const double2 *src = reinterpret_cast<const double2 *>(coeffs + ((size_t)b * 6 * M + 6 * (act ? piece : 0)) * D);
+    // the 6*D elements of a piece are contiguous and pair-aligned (6*D is even)
+    const IOPair *src = reinterpret_cast<const IOPair *>(coeffs + ((size_t)b * 6 * M + 6 * (act ? piece : 0)) * D);
 #pragma unroll
     for (int q = 0; q < 3 * D; ++q) {
-      const double2 v = src[q];
+      const IOPair v = src[q];
       const int e0 = 2 * q, e1 = 2 * q + 1;
       c[e0 / D][e0 % D] = act ? (Real)v.x : Real(0);
       c[e1 / D][e1 % D] = act ? (Real)v.y : Real(0);
@@ -854,22 +862,22 @@ __device__ __forceinline__ void sample_wave_per_piece(int b, int M, const DevPar
   LookupT lk(map);
   minco_sample<Real, D, LookupT, NEO_SAMPLE_U, true>(M, sl, ns, c, prm, lk, gC, gT, cf, ck, sizeof(Real) == 4 ? rows : nullptr);
   if (act && r == 0) {
-    double2 *dst = reinterpret_cast<double2 *>(grad_C + ((size_t)b * 6 * M + 6 * piece) * D);
+    IOPair *dst = reinterpret_cast<IOPair *>(grad_C + ((size_t)b * 6 * M + 6 * piece) * D);
 #pragma unroll
     for (int q = 0; q < 3 * D; ++q) {
       const int e0 = 2 * q, e1 = 2 * q + 1;
-      dst[q] = make_double2((double)gC[e0 / D][e0 % D], (double)gC[e1 / D][e1 % D]);
+      dst[q] = IOPair{(IO)gC[e0 / D][e0 % D], (IO)gC[e1 / D][e1 % D]};
     }
-    grad_T[(size_t)b * M + piece] = (double)gT;
+    grad_T[(size_t)b * M + piece] = (IO)gT;
   }
   if (lane < M && ns_p == 0) {
     // a piece shorter than delta_t has no sample and no sample lane: its partials are zeros (the planner's durations
     // never are -- T > T_min = 5 delta_t --, a caller of neo_sampled_terms_batch may pass any; found by
     // tests/test_gpu_parity.py::test_sampled_terms_on_ragged_durations: the rows were left as the caller's buffer had them)
-    double2 *dst = reinterpret_cast<double2 *>(grad_C + ((size_t)b * 6 * M + 6 * lane) * D);
+    IOPair *dst = reinterpret_cast<IOPair *>(grad_C + ((size_t)b * 6 * M + 6 * lane) * D);
 #pragma unroll
-    for (int q = 0; q < 3 * D; ++q) dst[q] = make_double2(0.0, 0.0);
-    grad_T[(size_t)b * M + lane] = 0.0;
+    for (int q = 0; q < 3 * D; ++q) dst[q] = IOPair{IO(0), IO(0)};
+    grad_T[(size_t)b * M + lane] = IO(0);
   }
   if (lane == 0) {
     costs2[(size_t)b * 2 + 0] = cf;
@@ -877,17 +885,13 @@ __device__ __forceinline__ void sample_wave_per_piece(int b, int M, const DevPar
   }
 }
 
-#ifdef NEO_SAMPLE_SHARED_TAILS  // experiment builds only (tools/probe/neo_sample_shared.hpp: measured, not adopted)
-#include "../../tools/probe/neo_sample_shared.hpp"
-#endif
-
-template <int D, typename Real, class MapT, class LookupT>
+template <int D, typename Real, class MapT, class LookupT, typename IO = double>
 __global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? NEO_SAMPLE_OCC : 2) void sample_kernel(int B, int M, DevParams prm, MapT map,
-                                                                                  const double *__restrict__ coeffs,
+                                                                                  const IO *__restrict__ coeffs,
                                                                                   const double *__restrict__ ts,
                                                                                   double *__restrict__ costs2,
-                                                                                  double *__restrict__ grad_C,
-                                                                                  double *__restrict__ grad_T,
+                                                                                  IO *__restrict__ grad_C,
+                                                                                  IO *__restrict__ grad_T,
                                                                                   const int *__restrict__ order) {
   if ((int)blockIdx.x >= B) return;
   // workgroup i runs on XCD i mod 8 (round-robin dispatch) and each XCD has its own 4 MB L2: `order` lets the caller
@@ -897,14 +901,7 @@ __global__ __launch_bounds__(kWave, sizeof(Real) == 4 ? NEO_SAMPLE_OCC : 2) void
   __shared__ int seg[kWave];
   // rows of the per-piece fold (fp32 sampling, minco_sample)
   __shared__ __attribute__((aligned(16))) Real rows[sizeof(Real) == 4 ? kWave * 8 * D : 4];
-#ifdef NEO_SAMPLE_SHARED_TAILS
-  if constexpr (sizeof(Real) == 4) {
-    extern __shared__ __attribute__((aligned(16))) float sample_tab[];
-    sample_wave_shared<D, MapT, LookupT>(b, M, prm, map, coeffs, ts, costs2, grad_C, grad_T, seg, sample_tab);
-    return;
-  }
-#endif
-  sample_wave_per_piece<D, Real, MapT, LookupT>(b, M, prm, map, coeffs, ts, costs2, grad_C, grad_T, seg, rows);
+  sample_wave_per_piece<D, Real, MapT, LookupT, IO>(b, M, prm, map, coeffs, ts, costs2, grad_C, grad_T, seg, rows);
 }
 
 }  // namespace neo

@@ -52,20 +52,21 @@ def _flags():
         os.environ.get("NEO_BUILD_DEFS", "").split()
 
 
-def _headers():
-    deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "neo_planner.h")]
-    defs = os.environ.get("NEO_BUILD_DEFS", "")
-    probe = os.path.join(os.path.dirname(os.path.dirname(PKG)), "tools", "probe")
-    if "NEO_SAMPLE_EXPERIMENTS" in defs:     # neo_disp_sample.hip then includes these
-        deps += [os.path.join(probe, h) for h in ("neo_sample_chunk.hpp", "neo_sample_wg.hpp")]
-    if "NEO_SAMPLE_SHARED_TAILS" in defs:    # neo_kernels.hpp then includes this one
-        deps.append(os.path.join(probe, "neo_sample_shared.hpp"))
-    return deps
+# headers only one unit includes: a change there recompiles that unit alone
+UNIT_HEADERS = {}
 
 
-def _headers_hash():
+def _headers(src=None):
+    """the headers every unit sees (src None) or the ones only `src` includes.  (The experiment bodies of rounds 3 - 5 are
+    patches under tools/probe/ -- sample_experiment_hooks.patch re-adds their hooks -- and no longer part of any build.)"""
+    if src is not None:
+        return [os.path.join(CSRC, h) for h in UNIT_HEADERS.get(src, [])]
+    return [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "neo_planner.h")]
+
+
+def _headers_hash(src=None):
     h = hashlib.sha256()
-    for d in _headers():
+    for d in _headers(src):
         h.update(os.path.basename(d).encode() + b"\0" + open(d, "rb").read() + b"\0")
     return h.hexdigest()
 
@@ -109,6 +110,7 @@ def _key(src=None, headers_hash=None):
     h.update((headers_hash or _headers_hash()).encode())
     for s in ([src] if src else SOURCES):
         h.update(s.encode() + b"\0" + open(os.path.join(CSRC, s), "rb").read() + b"\0")
+        h.update(_headers_hash(s).encode())
     return h.hexdigest()[:12]
 
 

@@ -460,20 +460,28 @@ class BatchPlanner:
                                           _lib.ptr(st)))
         return dict(cost=cost, costs=costs, grad=grad, coeffs=coeffs, status=st)
 
-    def sampled_terms(self, map, coeffs, ts, order=None):
+    def sampled_terms(self, map, coeffs, ts, order=None, io32=False):
         """add_sampled_cost + add_sampled_grad_CT (:392-466) for B trajectories: coeffs (B, 6M, D), ts (B, M).
         `order`: optional permutation (B,) the ESDF-lookup kernel dispatches its workgroups in (`spatial_order`); the
-        results stay in the caller's order, bit-identical"""
+        results stay in the caller's order, bit-identical.  `io32`: hand the coefficients over and take the partials back
+        as float32 (neo_sampled_terms_batch_f32; fp32 sampling only)"""
         self._sync()
         c = self.ctx
-        coeffs = _lib.as_f64(coeffs); ts = _lib.as_f64(ts)
+        ts = _lib.as_f64(ts)
         B, M = ts.shape
-        D = coeffs.shape[2]
+        D = np.shape(coeffs)[2]
         perm = None if order is None else np.ascontiguousarray(order, dtype=np.int32)
         c.check(c.lib.neo_sampled_terms_dispatch_order(c.h, _lib.ptr(perm), 0, 0 if perm is None else B))
-        costs2 = np.zeros((B, 2)); gC = np.zeros((B, 6 * M, D)); gT = np.zeros((B, M))
-        c.check(c.lib.neo_sampled_terms_batch(c.h, map.scene_id, B, M, D, _lib.ptr(coeffs), _lib.ptr(ts),
-                                              _lib.ptr(costs2), _lib.ptr(gC), _lib.ptr(gT)))
+        costs2 = np.zeros((B, 2))
+        if io32:
+            coeffs = np.ascontiguousarray(coeffs, dtype=np.float32)
+            gC = np.zeros((B, 6 * M, D), np.float32); gT = np.zeros((B, M), np.float32)
+            fn = c.lib.neo_sampled_terms_batch_f32
+        else:
+            coeffs = _lib.as_f64(coeffs)
+            gC = np.zeros((B, 6 * M, D)); gT = np.zeros((B, M))
+            fn = c.lib.neo_sampled_terms_batch
+        c.check(fn(c.h, map.scene_id, B, M, D, _lib.ptr(coeffs), _lib.ptr(ts), _lib.ptr(costs2), _lib.ptr(gC), _lib.ptr(gT)))
         return dict(costs2=costs2, grad_C=gC, grad_T=gT)
 
     def optimize(self, map, x0, head, tail, scene_ids=None, order=True):

@@ -373,6 +373,15 @@ def test_sampled_terms_on_ragged_durations(M):
             sc = max(np.abs(a[k][t]).max(), 1e-3 * np.abs(a[k]).max())
             assert np.abs(b[k][t] - a[k][t]).max() <= 1e-3 * sc, (k, t, ns[t])
     assert np.all(b["costs2"][28] == 0) and np.all(b["grad_C"][28] == 0) and np.all(b["grad_T"][28] == 0)
+    # round 6: fp32 coefficient / partials buffers (neo_sampled_terms_batch_f32): the kernel rounds fp64 coefficients to fp32
+    # on entry and its fp32 partials to fp64 on exit, so the fp32 buffers carry the same bits
+    c32 = bp32.sampled_terms(g3, coeffs, ts, io32=True)
+    assert c32["grad_C"].dtype == np.float32 and c32["grad_T"].dtype == np.float32
+    assert np.array_equal(c32["costs2"], b["costs2"])
+    assert np.array_equal(c32["grad_C"], b["grad_C"].astype(np.float32)) and np.array_equal(c32["grad_C"].astype(np.float64), b["grad_C"])
+    assert np.array_equal(c32["grad_T"].astype(np.float64), b["grad_T"])
+    with pytest.raises(Exception):      # fp64 sampling has no fp32-buffer form
+        bp64.sampled_terms(g3, coeffs, ts, io32=True)
     # pieces without samples have no partials
     gC = b["grad_C"].reshape(B, M, 6, D)
     assert np.all(gC[ns == 0] == 0) and np.all(b["grad_T"][ns == 0] == 0)

@@ -139,7 +139,7 @@ def test_build_cache_is_keyed_by_content_not_by_time_stamps(tmp_path, monkeypatc
     with open(copy, "a") as f:
         f.write("// edited\n")
     real = b._headers
-    monkeypatch.setattr(b, "_headers", lambda: [str(copy) if os.path.basename(d) == "neo_linesearch.hpp" else d for d in real()])
+    monkeypatch.setattr(b, "_headers", lambda src=None: [str(copy) if os.path.basename(d) == "neo_linesearch.hpp" else d for d in real(src)])
     assert b._key() != k_lib and b._key("neo_disp_sample.hip") != k_unit       # a changed header: every key changes
     monkeypatch.setattr(b, "_headers", real)
     monkeypatch.setenv("NEO_FP_CONTRACT", "fast")

@@ -325,7 +325,8 @@ def esdf_report(R):
     by_8d2 = n_samples * 8.0 * esz + B * (2 * n * 4 + 20)
     # ... or with what this stand-alone kernel really moves besides the field: fp64 coefficients in, their
     # partials out, durations in / partials out, 2 cost terms
-    by_ops = n_samples * 8.0 * esz + B * (2 * 6 * M * D * 8 + 2 * M * 8 + 16)
+    io_b = 4 if bp.sample_dtype == "f32" else 8    # (round 6: fp32 operand buffers on the fp32 sampling path)
+    by_ops = n_samples * 8.0 * esz + B * (2 * 6 * M * D * io_b + M * 8 + M * io_b + 16)
     # footprint of the field: distinct 128-byte lines the launch's lookups touch (linear voxel order)
     cf = coeffs.cpu().numpy().reshape(B, M, 6, D)
     jmax = int(ns_piece.max())
@@ -357,14 +358,24 @@ def esdf_report(R):
         by_a = ns_a * 8.0 * esz + Ba * (2 * n * 4 + 20)
     d_ts = torch.from_numpy(np.ascontiguousarray(ts)).to(dev)
 
+    # round 6: the fp32 sampling path takes fp32 coefficient / partials buffers (neo_sampled_terms_batch_f32_dev)
+    io32 = bp.sample_dtype == "f32"
+    io_dt = torch.float32 if io32 else torch.float64
+    sample_fn = ctx.lib.neo_sampled_terms_batch_f32_dev if io32 else ctx.lib.neo_sampled_terms_batch_dev
+    K_BACK_TO_BACK = 20
+
     def time_sample(scene, nb, co, dts, order_np, reps):
-        """mean launch duration (HIP events on the kernel's stream) of sample_kernel over nb trajectories"""
+        """launch durations of sample_kernel over nb trajectories from HIP events on the kernel's stream: the mean over K
+        launches back to back between ONE event pair (`us`: what the kernel costs in a stream of work, and what rocprofv3's
+        kernel trace agrees with) and one launch per event pair (the context's profile scope; up to round 5 the only figure:
+        ~2 us of event overhead at the 4096 launch)"""
+        co = co.to(io_dt)
         c2 = torch.zeros(nb, 2, dtype=torch.float64, device=dev)
-        gC = torch.zeros(nb, 6 * M, D, dtype=torch.float64, device=dev)
-        gT = torch.zeros(nb, M, dtype=torch.float64, device=dev)
+        gC = torch.zeros(nb, 6 * M, D, dtype=io_dt, device=dev)
+        gT = torch.zeros(nb, M, dtype=io_dt, device=dev)
         od = torch.from_numpy(order_np).to(dev) if order_np is not None else None
         ctx.check(ctx.lib.neo_sampled_terms_dispatch_order(ctx.h, pp(od) if od is not None else None, 1, nb))
-        run = lambda: ctx.check(ctx.lib.neo_sampled_terms_batch_dev(ctx.h, scene, nb, M, D, pp(co), pp(dts), pp(c2), pp(gC), pp(gT)))
+        run = lambda: ctx.check(sample_fn(ctx.h, scene, nb, M, D, pp(co), pp(dts), pp(c2), pp(gC), pp(gT)))
         for _ in range(3):
             run()
         torch.cuda.synchronize()
@@ -375,16 +386,27 @@ def esdf_report(R):
         torch.cuda.synchronize()
         ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
         nl, ms = R.kernel_time(_lib.NEO_KERNEL_ESDF_SAMPLE)
+        stream = torch.cuda.current_stream()
+        groups = max(reps // K_BACK_TO_BACK, 1)
+        us_k = 0.0
+        for _ in range(groups):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(K_BACK_TO_BACK):
+                run()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            us_k += 1e3 * e0.elapsed_time(e1) / K_BACK_TO_BACK
         ctx.check(ctx.lib.neo_sampled_terms_dispatch_order(ctx.h, None, 0, 0))
-        return 1e3 * ms / max(nl, 1), nl, (c2, gC, gT)
+        return us_k / groups, nl + groups * K_BACK_TO_BACK, (c2, gC, gT), 1e3 * ms / max(nl, 1)
 
     def block(scene, layout_name, default_wl):
         """the ESDF-lookup kernel on one field: the 4096-trajectory launch and the launch over every request batch of a
         step, in the chosen dispatch order, the other order timed beside it (same bits either way: checked)"""
         orders = {"index": None, "spatial": npa.BatchPlanner.spatial_order(head, tail)}
         other = "index" if a.esdf_order == "spatial" else "spatial"
-        us, nl, out_main = time_sample(scene, B, coeffs, d_ts, orders[a.esdf_order], 50)
-        us_o, _, out_o = time_sample(scene, B, coeffs, d_ts, orders[other], 20)
+        us, nl, out_main, us_single = time_sample(scene, B, coeffs, d_ts, orders[a.esdf_order], 60)
+        us_o, _, out_o, _ = time_sample(scene, B, coeffs, d_ts, orders[other], 20)
         same = all(torch.equal(x_, y_) for x_, y_ in zip(out_main, out_o))
         tr = kernel_traffic(R, f"sample_kernel@{B}") if default_wl else {"traffic": None, "source": None, "rule": None, "pm": {}}
         pm_s = tr["pm"]
@@ -393,7 +415,11 @@ def esdf_report(R):
              "unit": "GB/s", "frac": by_8d2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
              "frac_8d2": by_8d2 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
              "frac_with_operands": by_ops / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-             "kernel_us": us, "launches": nl, f"kernel_us_{other}_order": us_o, "orders_give_the_same_bits": bool(same),
+             "kernel_us": us, "launches": nl, "timing": f"HIP events on the kernel's stream, mean over groups of {K_BACK_TO_BACK} launches back to back",
+             "kernel_us_one_launch_per_event_pair": us_single,
+             "frac_one_launch_per_event_pair": by_8d2 / (us_single * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+             "operand_buffers": "f32" if io32 else "f64",
+             f"kernel_us_{other}_order": us_o, "orders_give_the_same_bits": bool(same),
              "samples_per_launch": n_samples,
              "algorithmic_bytes_per_launch": by_8d2, "bytes_per_launch_with_operands": by_ops,
              "lookups_per_s": n_samples / (us * 1e-6),
@@ -414,8 +440,8 @@ def esdf_report(R):
         # wavefronts than the chip holds at once the launch is bound by throughput, not by the run time of one wavefront
         if whole:
             orders_a = {"index": None, "spatial": npa.BatchPlanner.spatial_order(head_a, tail_a)}
-            us_a, nl_a, _ = time_sample(scene, Ba, coeffs_a, d_ts_a, orders_a[a.esdf_order], 20)
-            us_ao, _, _ = time_sample(scene, Ba, coeffs_a, d_ts_a, orders_a[other], 8)
+            us_a, nl_a, _, _ = time_sample(scene, Ba, coeffs_a, d_ts_a, orders_a[a.esdf_order], 20)
+            us_ao, _, _, _ = time_sample(scene, Ba, coeffs_a, d_ts_a, orders_a[other], 8)
             w_ = {"trajectories": Ba, "kernel_us": us_a, "launches": nl_a, f"kernel_us_{other}_order": us_ao,
                   "dispatch_order": a.esdf_order, "samples_per_launch": ns_a, "algorithmic_bytes_per_launch": by_a,
                   "achieved": by_a / (us_a * 1e-6) / 1e9, "frac_8d2": by_a / (us_a * 1e-6) / 1e9 / HBM_PEAK_GBPS}
