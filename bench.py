@@ -327,7 +327,10 @@ def compact_line(out, details_path=None):
     if "f64" in modes:
         # the mode that computes in the reference's own arithmetic and meets its 1e-4 as often as the reference meets itself
         line["value_parity_mode"] = modes["f64"].get("value")
-    line.update(_pick(out, ("accepted_traj_per_s", "accepted_frac", "single_batch_ms", "single_batch_traj_per_s", "single_batch_ms_range")))
+    line.update(_pick(out, ("accepted_traj_per_s", "accepted_frac", "host_visible_traj_per_s", "single_batch_ms", "single_batch_traj_per_s",
+                            "single_batch_ms_range")))
+    if out.get("flags_or"):
+        line["flags_or"] = out["flags_or"]
     sb = out.get("single_batch_budget")
     if sb and sb.get("budgets"):
         b0 = sb["budgets"][0]
@@ -507,10 +510,13 @@ class Rank:
             st_ = self.streams[r % self.n_lanes]
             with torch.cuda.stream(st_):
                 x0 = torch.from_numpy(self.bp.pack_x(wp_, ts_)).to(dev)
-                order = None if a.no_order else torch.from_numpy(self.bp.expected_effort_order(h_, t_, ts_)).to(dev)
+                # (round 6: the dispatch order -- runs expected to be long first -- is computed on the device from the batch's own
+                #  buffers at every launch, inside the timed region: `effort_order_dev`; up to round 5 a host argsort at set-up)
                 self.batches.append(dict(
                     st=st_, x0=x0, x=torch.empty_like(x0), head=torch.from_numpy(h_).to(dev), tail=torch.from_numpy(t_).to(dev),
-                    order=order, nsamp=torch.zeros(B, dtype=torch.int64, device=dev),
+                    order=None, nsamp=torch.zeros(B, dtype=torch.int64, device=dev),
+                    # pinned host mirrors of what a caller reads back (`host_visible_traj_per_s`: time_mode(d2h=True))
+                    h_x=torch.empty(B, n, dtype=torch.float64).pin_memory(), h_status=torch.empty(B, dtype=torch.int32).pin_memory(),
                     costs=torch.zeros(B, 4, dtype=torch.float64, device=dev), last=torch.zeros(B, 4, dtype=torch.float64, device=dev),
                     nit=torch.zeros(B, dtype=torch.int32, device=dev), nfev=torch.zeros(B, dtype=torch.int32, device=dev),
                     status=torch.zeros(B, dtype=torch.int32, device=dev),
@@ -567,19 +573,34 @@ class Rank:
         x0_[:, :D * (M - 1)] = wp_.reshape(B, -1)
         x0_[:, D * (M - 1):] = tau_
 
-    def launch(self, bt, bpm):
+    def effort_order_dev(self, bt):
+        """BatchPlanner.expected_effort_order on the device, from the batch's resident x0 / head / tail: time slack of the
+        guess, sum(ts) v_max / distance, largest first (list scheduling: a long run that starts last is the launch's tail)"""
+        torch, cfg = self.torch, self.bp.cfg
+        nq = self.D * (self.M - 1)
+        ts = (cfg.T_max - cfg.T_min) * torch.sigmoid(bt["x0"][:, nq:]) + cfg.T_min
+        dist = (bt["tail"][:, 0] - bt["head"][:, 0]).norm(dim=1).clamp_min(1e-9)
+        return torch.argsort(-(ts.sum(dim=1) * cfg.v_max / dist), stable=True).to(torch.int32)
+
+    def launch(self, bt, bpm, d2h=False):
         torch, ctx, B = self.torch, self.ctx, self.B
         ctx.set_stream(bt["st"].cuda_stream)
         ctx.check(ctx.lib.neo_optimize_sample_counter(ctx.h, ctypes.c_void_p(bt["nsamp"].data_ptr())))
-        ctx.check(ctx.lib.neo_optimize_dispatch_order(
-            ctx.h, ctypes.c_void_p(bt["order"].data_ptr()) if bt["order"] is not None else None, B))
         with torch.cuda.stream(bt["st"]):
             if self.init is not None:
                 with torch.no_grad():
                     self.warm_start(bt["x0"])
+            if not self.a.no_order:
+                bt["order"] = self.effort_order_dev(bt)    # (kept alive in the batch: the launch reads it asynchronously)
+        ctx.check(ctx.lib.neo_optimize_dispatch_order(
+            ctx.h, ctypes.c_void_p(bt["order"].data_ptr()) if bt["order"] is not None else None, B))
+        with torch.cuda.stream(bt["st"]):
             # start points are read from x0, results written to x: no copy per launch (neo_optimize_batch_from_dev)
             bpm.optimize_dev(self.g3, bt["x"], bt["head"], bt["tail"], bt["costs"], bt["last"], bt["nit"], bt["nfev"],
                              bt["status"], slots=self.slots, x0=bt["x0"])
+            if d2h:
+                bt["h_x"].copy_(bt["x"], non_blocking=True)
+                bt["h_status"].copy_(bt["status"], non_blocking=True)
             if self.use_dist:
                 # results to every rank: final x, total cost, 4 cost terms (SURVEY.md 8.e1).  The gather runs
                 # behind the batch on the process group's own stream; this batch's stream does not wait for it
@@ -621,27 +642,31 @@ class Rank:
         self.ctx.check(self.ctx.lib.neo_profile_read(self.ctx.h, which, ctypes.byref(launches), ctypes.byref(kms)))
         return int(launches.value), float(kms.value)
 
-    def time_mode(self, mode):
+    def time_mode(self, mode, d2h=False):
         """W warm-up steps, then exactly K timed steps of the hot path in arithmetic mode `mode`, fenced by a barrier
-        and a device synchronisation on both sides; returns the timing and what the launches of the last step left"""
+        and a device synchronisation on both sides; returns the timing and what the launches of the last step left.
+        d2h: every launch is followed by the copy of its final points and statuses to pinned host memory (what a host-side
+        caller sees; returns only the elapsed time)"""
         torch, ctx, a = self.torch, self.ctx, self.a
         bpm = self.bp if mode == a.dtype else self.planner_for(mode)
         bpm._sync()
         self.fence()
         for k in range(a.warmup):
             for bt in self.batches:
-                self.launch(bt, bpm)
+                self.launch(bt, bpm, d2h)
         self.fence()
         ctx.check(ctx.lib.neo_profile_reset(ctx.h))
         ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
         t0 = time.perf_counter()
         for k in range(a.steps):
             for bt in self.batches:
-                self.launch(bt, bpm)
+                self.launch(bt, bpm, d2h)
         self.fence()
         el = time.perf_counter() - t0
         ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
         ctx.set_stream(None)
+        if d2h:
+            return dict(mode=mode, elapsed=el)
         launches, kms = self.kernel_time(self._lib.NEO_KERNEL_OPTIMIZE)
         # one launch ALONE on the chip (outside the timed region): what a caller with a single request batch gets -- with
         # `--streams` launches in flight each one lasts longer than it would by itself
@@ -767,6 +792,8 @@ def main():
     t_gpu0 = time.time()
     main_run = R.time_mode(a.dtype)
     elapsed = main_run["elapsed"]
+    # the same steps with the D2H copy of every batch's final points and statuses behind its launch (one GPU, full reports)
+    host_visible = R.time_mode(a.dtype, d2h=True)["elapsed"] if (world == 1 and rank == 0 and not a.no_report) else None
     rank_rate = B * n_sets * a.steps / elapsed
     rccl_ranks, per_rank, gather_ok = None, None, None
     if use_dist:
@@ -808,6 +835,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "accepted_traj_per_s": value * main_run["accepted_frac"], "accepted_frac": main_run["accepted_frac"],
+            # inputs resident in HBM, results copied to pinned host memory behind every launch (x: B x n doubles, status)
+            "host_visible_traj_per_s": (B * n_sets * a.steps / host_visible) if host_visible else None,
+            # kernel-experiment flags ORed into neo_params.flags of the timed runs (environment NEO_BENCH_FLAGS_OR); normally 0
+            "flags_or": int(os.environ.get("NEO_BENCH_FLAGS_OR", "0")),
+            "dispatch_order": "none" if a.no_order else "expected effort, computed on the device inside the timed region",
             # what a caller with ONE request batch gets: a single launch of B trajectories alone on the chip (`value` keeps
             # `--streams` launches in flight and is the throughput figure)
             "single_batch_ms": solo_ms, "single_batch_traj_per_s": (B / (solo_ms * 1e-3)) if solo_ms else None,
@@ -816,7 +848,8 @@ def main():
                                    f"{R.n_scenes} x {a.grid}^3 {R.store} ESDF per GPU (trilinear, " +
                                    ("planar requests" if a.planar else f"pillars + {CANOPY} canopy boxes") +
                                    "), each optimised to L-BFGS-B termination"
-                                   + ("; x0 from the initializer net (random weights)" if R.init is not None else ""),
+                                   + ("; x0 = a straight line + 0.05 x the output of a RANDOM-WEIGHT initializer head (one dense "
+                                      "head launch per batch in the timed region; not a trained warm start)" if R.init is not None else ""),
                        "batch_per_launch": B, "batches_per_step": n_sets, "trajectories_per_step_per_gpu": B * n_sets,
                        "pieces": M, "dims": D, "variables": n, "esdf_voxels": a.grid ** 3, "layout": a.layout,
                        "lbfgsb": "maxcor 10, maxls 20, tol 1e-4 (expert_planner.py:213-225)",
@@ -885,6 +918,15 @@ def dry_run(a, rank, world, n):
     dist_.init_process_group(backend, rank=rank, world_size=world)
     B = 64
     x = torch.full((B, n), float(rank), dtype=torch.float64)
+    scenes = None
+    if a.config == "cfg4":
+        # BASELINE configs[3]: 256 scenes over the node, `a.scenes` = 256 // max(world, 8) per rank, rank r holding the scenes
+        # r * scenes .. (r + 1) * scenes - 1 (Rank.__init__ seeds them so); every row carries its scene's number in column 1,
+        # and the rank-major gather must come back scene-major
+        scenes, rows = a.scenes, 2
+        B = scenes * rows
+        x = torch.full((B, n), float(rank), dtype=torch.float64)
+        x[:, 1] = (rank * scenes + torch.arange(scenes, dtype=torch.float64)).repeat_interleave(rows)
     costs = torch.ones(B, 4, dtype=torch.float64) * (rank + 1)
     w = torch.tensor([1.0, 1.0, 1.0, 10000.0], dtype=torch.float64)
     dist_.barrier()
@@ -895,11 +937,16 @@ def dry_run(a, rank, world, n):
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist_.all_reduce(el, op=dist_.ReduceOp.MAX)
     ok = all(float(g[r * B, 0]) == float(r) and abs(float(g[r * B, n]) - (r + 1) * 10003.0) < 1e-3 for r in range(world))
+    extra = {}
+    if scenes is not None:
+        want = torch.arange(world * scenes, dtype=torch.float32).repeat_interleave(2)
+        extra = {"config": "cfg4", "scenes_per_rank": scenes, "scenes_total": world * scenes,
+                 "scene_major_ok": bool(torch.equal(g[:, 1], want))}
     if rank == 0:
         print(json.dumps({"metric": "trajectories/sec (batched replan)", "value": None, "unit": "traj/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * float(el) / max(a.steps, 1),
                           "dry_run": True, "ranks": dist_.get_world_size(), "gather_ok": bool(ok),
-                          "dist_backend": backend}), flush=True)
+                          "dist_backend": backend, **extra}), flush=True)
     dist_.barrier()
     dist_.destroy_process_group()
 

@@ -28,6 +28,14 @@ def test_self_launch_two_ranks_end_to_end():
     assert out["steps"] == 4 and out["value"] is None and out["dry_run"] is True
 
 
+def test_self_launch_eight_ranks_cfg4_scene_split():
+    """the 8-rank launch of BASELINE configs[3] as far as CPUs allow -- eight processes rendezvous (gloo),
+    each holds 256 / 8 = 32 scenes, and the rank-major gather of their result rows comes back scene-major"""
+    out = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run", "--config", "cfg4"])
+    assert out["n_gpus"] == 8 and out["ranks"] == 8 and out["gather_ok"] is True and out["dry_run"] is True
+    assert out["scenes_per_rank"] == 32 and out["scenes_total"] == 256 and out["scene_major_ok"] is True
+
+
 def test_torchrun_style_environment_is_respected():
     """when the driver launches the ranks (python -m torch.distributed.run ...) bench.py must not launch again"""
     import socket
