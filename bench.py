@@ -95,7 +95,12 @@ def parse(argv=None):
                     help="dispatch order of the stand-alone ESDF-lookup kernel: XCD-aware spatial order "
                          "(BatchPlanner.spatial_order) or index order; the other one is timed beside it")
     ap.add_argument("--planar", action="store_true", help="round-1 workload: every request in the plane z = 2 m, no canopy")
-    ap.add_argument("--no-order", action="store_true", help="dispatch trajectories in index order")
+    ap.add_argument("--no-order", action="store_true", help="dispatch trajectories in index order everywhere")
+    ap.add_argument("--order", default="none", choices=["none", "effort"],
+                    help="dispatch order of the PIPELINED steps: index order, or expected effort computed on the device inside the "
+                         "timed region (neo_effort_order_dev).  With four launches in flight the order is worth less than its three "
+                         "small launches cost (round 6, one box: 1.498 M traj/s without, 1.489 M with); launches that run alone "
+                         "(single_batch_*) always use it")
     ap.add_argument("--lane-groups", action="store_true",
                     help="small problems (cfg3): eight trajectories per wavefront (NEO_FLAG_LANE_GROUPS)")
     ap.add_argument("--streams", type=int, default=4,
@@ -514,7 +519,8 @@ class Rank:
                 #  buffers at every launch, inside the timed region: `effort_order_dev`; up to round 5 a host argsort at set-up)
                 self.batches.append(dict(
                     st=st_, x0=x0, x=torch.empty_like(x0), head=torch.from_numpy(h_).to(dev), tail=torch.from_numpy(t_).to(dev),
-                    order=None, nsamp=torch.zeros(B, dtype=torch.int64, device=dev),
+                    order=torch.zeros(B, dtype=torch.int32, device=dev),
+                    okeys=torch.zeros(2 * B, dtype=torch.float64, device=dev), nsamp=torch.zeros(B, dtype=torch.int64, device=dev),
                     # pinned host mirrors of what a caller reads back (`host_visible_traj_per_s`: time_mode(d2h=True))
                     h_x=torch.empty(B, n, dtype=torch.float64).pin_memory(), h_status=torch.empty(B, dtype=torch.int32).pin_memory(),
                     costs=torch.zeros(B, 4, dtype=torch.float64, device=dev), last=torch.zeros(B, 4, dtype=torch.float64, device=dev),
@@ -575,25 +581,27 @@ class Rank:
 
     def effort_order_dev(self, bt):
         """BatchPlanner.expected_effort_order on the device, from the batch's resident x0 / head / tail: time slack of the
-        guess, sum(ts) v_max / distance, largest first (list scheduling: a long run that starts last is the launch's tail)"""
-        torch, cfg = self.torch, self.bp.cfg
-        nq = self.D * (self.M - 1)
-        ts = (cfg.T_max - cfg.T_min) * torch.sigmoid(bt["x0"][:, nq:]) + cfg.T_min
-        dist = (bt["tail"][:, 0] - bt["head"][:, 0]).norm(dim=1).clamp_min(1e-9)
-        return torch.argsort(-(ts.sum(dim=1) * cfg.v_max / dist), stable=True).to(torch.int32)
+        guess, sum(ts) v_max / distance, largest first (list scheduling: a long run that starts last is the launch's tail).
+        neo_effort_order_dev: three small launches on the batch's stream (a first version with torch -- sigmoid, norm, a stable
+        argsort: ~20 launches a batch -- cost the step 7 %)"""
+        ctx, pp = self.ctx, (lambda t: ctypes.c_void_p(t.data_ptr()))
+        ctx.check(ctx.lib.neo_effort_order_dev(ctx.h, self.B, self.M, self.D, pp(bt["x0"]), pp(bt["head"]), pp(bt["tail"]),
+                                               pp(bt["okeys"]), pp(bt["order"])))
 
-    def launch(self, bt, bpm, d2h=False):
+    def launch(self, bt, bpm, d2h=False, ordered=None):
+        """ordered: dispatch the batch's workgroups in expected-effort order, computed on the device ahead of the launch
+        (None: `--order`'s choice for the pipelined steps)"""
         torch, ctx, B = self.torch, self.ctx, self.B
+        ordered = (self.a.order == "effort") if ordered is None else (ordered and not self.a.no_order)
         ctx.set_stream(bt["st"].cuda_stream)
         ctx.check(ctx.lib.neo_optimize_sample_counter(ctx.h, ctypes.c_void_p(bt["nsamp"].data_ptr())))
         with torch.cuda.stream(bt["st"]):
             if self.init is not None:
                 with torch.no_grad():
                     self.warm_start(bt["x0"])
-            if not self.a.no_order:
-                bt["order"] = self.effort_order_dev(bt)    # (kept alive in the batch: the launch reads it asynchronously)
-        ctx.check(ctx.lib.neo_optimize_dispatch_order(
-            ctx.h, ctypes.c_void_p(bt["order"].data_ptr()) if bt["order"] is not None else None, B))
+        if ordered:
+            self.effort_order_dev(bt)        # (on the batch's stream, ahead of the launch that reads bt["order"])
+        ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, ctypes.c_void_p(bt["order"].data_ptr()) if ordered else None, B))
         with torch.cuda.stream(bt["st"]):
             # start points are read from x0, results written to x: no copy per launch (neo_optimize_batch_from_dev)
             bpm.optimize_dev(self.g3, bt["x"], bt["head"], bt["tail"], bt["costs"], bt["last"], bt["nit"], bt["nfev"],
@@ -680,7 +688,7 @@ class Rank:
             for bt in self.batches[:8]:
                 ctx.check(ctx.lib.neo_profile_reset(ctx.h))
                 ctx.check(ctx.lib.neo_profile_enable(ctx.h, 1))
-                self.launch(bt, bpm)
+                self.launch(bt, bpm, ordered=True)      # (a launch alone: long runs first, or the longest one is its tail)
                 self.fence()
                 ctx.check(ctx.lib.neo_profile_enable(ctx.h, 0))
                 l_s, m_s = self.kernel_time(self._lib.NEO_KERNEL_OPTIMIZE)
@@ -839,7 +847,9 @@ def main():
             "host_visible_traj_per_s": (B * n_sets * a.steps / host_visible) if host_visible else None,
             # kernel-experiment flags ORed into neo_params.flags of the timed runs (environment NEO_BENCH_FLAGS_OR); normally 0
             "flags_or": int(os.environ.get("NEO_BENCH_FLAGS_OR", "0")),
-            "dispatch_order": "none" if a.no_order else "expected effort, computed on the device inside the timed region",
+            "dispatch_order": {"pipelined_steps": "index order" if (a.no_order or a.order == "none")
+                               else "expected effort, computed on the device inside the timed region (neo_effort_order_dev)",
+                               "launches_alone": "index order" if a.no_order else "expected effort, computed on the device ahead of the launch"},
             # what a caller with ONE request batch gets: a single launch of B trajectories alone on the chip (`value` keeps
             # `--streams` launches in flight and is the throughput figure)
             "single_batch_ms": solo_ms, "single_batch_traj_per_s": (B / (solo_ms * 1e-3)) if solo_ms else None,

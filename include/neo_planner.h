@@ -315,6 +315,13 @@ int neo_optimize_trace_xg(neo_ctx *ctx, double *dev_xg, int cap);
  * trajectories on this context until another order (or NULL) is set: keep it allocated until those launches have
  * completed.  Only the optimiser kernels read it. */
 int neo_optimize_dispatch_order(neo_ctx *ctx, const int32_t *dev_order, int B);
+/* the expected-effort order computed ON THE DEVICE from a batch's resident start points (round 6): key = time slack of the
+ * guess, sum(T) v_max / |goal - start|, largest first, ties by index -- what neo_planner_amd.BatchPlanner.expected_effort_order
+ * computes on the host.  Three small launches on the context's stream; `scratch` (16 B bytes, 8-byte aligned: the B keys as
+ * doubles, then B ranks) and order[B] are the caller's device buffers (several batches in flight on several streams: one pair
+ * per batch).  Hand `order` to neo_optimize_dispatch_order. */
+int neo_effort_order_dev(neo_ctx *ctx, int B, int M, int D, const double *x0, const double *head, const double *tail,
+                         void *scratch, int32_t *order);
 /* the same from a HOST permutation (copied into a context-owned device buffer); NULL or B = 0 resets.
  * Either way the permutation only applies to launches of exactly B trajectories. */
 int neo_optimize_dispatch_order_host(neo_ctx *ctx, const int32_t *host_order, int B);

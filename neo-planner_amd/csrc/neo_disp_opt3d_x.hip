@@ -6,7 +6,7 @@ namespace neo {
 
 int launch_opt_3d_x(neo_ctx *c, int elem, int layout, const OptArgs &a) {
 #ifdef NEO_SLIM_BUILD  // kernel experiments (tools/probe/kstats.sh): only the cfg2 instantiation
-  return launch_opt<3, float, Map3D, Lookup3D<float, float, 0>, 2, float>(c, a);
+  return launch_opt<3, float, Map3D, Lookup3D<float, float, 3>, 2, float>(c, a);  // (brick: the bench default since round 4)
 #else
 #ifdef NEO_X_ONE_WAVE  // experiment builds: a one-wavefront-per-SIMD allocation of the all-fp32 kernel (four samples a lane in
                       // flight) for NEO_FLAG_ONE_WAVE_PER_SIMD on fp32 brick fields -- the latency of a lone wavefront

@@ -33,7 +33,7 @@ EXPORTS = [
     "neo_optimize_dispatch_order_host", "neo_ctx_set_stream", "neo_optimize_trace",
     "neo_optimize_batch_from_dev", "neo_optimize_trace_xg", "neo_sampled_terms_dispatch_order",
     "neo_esdf_build_config", "neo_pack_results_dev", "neo_optimize_state_bytes", "neo_optimize_batch_budget_dev",
-    "neo_sampled_terms_batch_f32", "neo_sampled_terms_batch_f32_dev",
+    "neo_sampled_terms_batch_f32", "neo_sampled_terms_batch_f32_dev", "neo_effort_order_dev",
 ]
 
 
@@ -113,6 +113,7 @@ def load():
     L.neo_sampled_terms_batch_dev.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 5
     L.neo_sampled_terms_batch_f32.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 5
     L.neo_sampled_terms_batch_f32_dev.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 5
+    L.neo_effort_order_dev.argtypes = [c_p, c_i, c_i, c_i] + [c_p] * 5
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int or name in ("neo_abi_version",):

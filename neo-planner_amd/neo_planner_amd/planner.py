@@ -632,6 +632,22 @@ class BatchPlanner:
         slack = ts.sum(axis=1) * self.cfg.v_max / np.maximum(dist, 1e-9)
         return np.argsort(-slack, kind="stable").astype(np.int32)
 
+    def expected_effort_order_dev(self, x0, head, tail):
+        """the same order computed on the device from RESIDENT torch tensors x0 (B, n), head / tail (B, 3, D) -- two launches
+        on the context's stream (neo_effort_order_dev); returns (order int32 [B], keys float64 [B]) device tensors"""
+        import ctypes
+        import torch
+        self._sync()
+        c = self.ctx
+        B, n = x0.shape
+        D = head.shape[2]
+        M = (n + D) // (D + 1)
+        scratch = torch.empty(2 * B, dtype=torch.float64, device=x0.device)     # keys, then the ranks
+        order = torch.empty(B, dtype=torch.int32, device=x0.device)
+        pp = lambda t: ctypes.c_void_p(t.data_ptr())
+        c.check(c.lib.neo_effort_order_dev(c.h, B, M, D, pp(x0), pp(head), pp(tail), pp(scratch), pp(order)))
+        return order, scratch[:B]
+
     @staticmethod
     def spatial_order(head, tail, xcds=8, cell=1.0, key=None, chunk=None):
         """XCD-aware spatial dispatch order for the ESDF-lookup kernel (neo_sampled_terms_dispatch_order): requests are keyed by

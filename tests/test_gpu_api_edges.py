@@ -747,3 +747,34 @@ def test_a_non_finite_start_point_ends_its_own_run_only(mode):
     assert np.array_equal(out["x"][keep], good["x"][keep])
     assert np.array_equal(out["nfev"][keep], good["nfev"][keep]) and np.array_equal(out["status"][keep], good["status"][keep])
     assert np.array_equal(out["costs"][keep], good["costs"][keep])
+
+
+def test_effort_order_on_the_device_is_the_host_order():
+    """neo_effort_order_dev (round 6): the expected-effort dispatch order from resident buffers -- a permutation, keys
+    non-increasing along it with ties in index order, and BatchPlanner.expected_effort_order's permutation wherever the host's
+    keys are not within rounding of a neighbour's; B not a multiple of the tile, equal keys, a NaN start point"""
+    import torch
+    dev = torch.device("cuda", 0)
+    for B, M, D in ((4096, 21, 3), (1000, 21, 3), (257, 3, 2), (3, 41, 3)):
+        head, tail, wp, ts = synth.replan_requests(5, B, M - 1, D=D, **(synth.VOLUME if D == 3 else {}))
+        ts[B // 2:B // 2 + 2] = ts[0]; head[B // 2:B // 2 + 2] = head[0]; tail[B // 2:B // 2 + 2] = tail[0]      # equal keys
+        bp = npa.BatchPlanner(sample_dtype="f32")
+        x0 = bp.pack_x(wp, ts)
+        if B > 100:
+            x0[7, -1] = np.nan
+        order, keys = bp.expected_effort_order_dev(torch.from_numpy(x0).to(dev), torch.from_numpy(head).to(dev),
+                                                   torch.from_numpy(tail).to(dev))
+        torch.cuda.synchronize()
+        order = order.cpu().numpy(); keys = keys.cpu().numpy()
+        assert np.array_equal(np.sort(order), np.arange(B))
+        ko = keys[order]
+        assert np.all(ko[:-1] >= ko[1:])
+        same = ko[:-1] == ko[1:]
+        assert np.all(order[:-1][same] < order[1:][same])
+        dist = np.linalg.norm(tail[:, 0] - head[:, 0], axis=1)
+        T = bp.unpack_x(x0, M, D)[1]
+        slack = T.sum(axis=1) * bp.cfg.v_max / np.maximum(dist, 1e-9)
+        ok = np.isfinite(slack)
+        assert np.allclose(keys[ok], slack[ok], rtol=1e-13, atol=0)
+        if B > 100:
+            assert keys[7] == 0.0 and order[-1] == 7 or keys[order[-1]] == 0.0

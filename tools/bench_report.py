@@ -250,7 +250,8 @@ def single_batch_budget_report(R, main_run):
     x = torch.empty_like(bt["x0"]); costs = torch.zeros_like(bt["costs"]); last = torch.zeros_like(bt["last"])
     nit = torch.zeros_like(bt["nit"]); nfev = torch.zeros_like(bt["nfev"]); st = torch.zeros_like(bt["status"])
     ctx.set_stream(R.tstream.cuda_stream)
-    ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, ctypes.c_void_p(bt["order"].data_ptr()) if bt["order"] is not None else None, B))
+    # (batch 0's expected-effort order: left in bt["order"] by the launch that timed the batch alone, Rank.time_mode)
+    ctx.check(ctx.lib.neo_optimize_dispatch_order(ctx.h, ctypes.c_void_p(bt["order"].data_ptr()) if not R.a.no_order else None, B))
     out = {"what": "batch 0 (4096 requests) alone on the chip: one unbudgeted launch against launches of at most `budget` "
                    "evaluations per trajectory with the stragglers re-launched compacted (BatchPlanner.optimize_budgeted_dev); "
                    "wall clock incl. the status round trips; done_after_first_launch = share of the batch finished when the "
