@@ -342,6 +342,12 @@ def compact_line(out, details_path=None):
         line["single_batch_budget"] = dict(_pick(b0, ("budget", "first_launch_ms", "all_done_ms", "done_after_first_launch",
                                                         "bit_identical_to_the_unbudgeted_launch")),
                                            unbudgeted_ms=sb.get("unbudgeted_ms"))
+    pg = (sb or {}).get("progress") or {}
+    if "ms_until_share_finished" in pg:
+        # one plain launch with a progress counter: when 80 % / all of the batch are finished, when the 80 % are on the host
+        line["single_batch_progress"] = {"ms_80pct": pg["ms_until_share_finished"].get("0.8"), "ms_all": pg["ms_until_share_finished"].get("1.0"),
+                                         "usable_on_host_ms": pg.get("usable_on_host_ms"), "usable_share": pg.get("usable_share_on_host"),
+                                         "finals": pg.get("finished_results_were_final")}
     retries = out.get("accepted_after_retries")
     if retries:
         line["accepted_after_retries_traj_per_s"] = retries.get("accepted_after_retries_traj_per_s")
@@ -395,7 +401,8 @@ def compact_line(out, details_path=None):
     line = _r(line)
     s = json.dumps(line, separators=(",", ":"))
     # belt and braces: drop optional blocks, last first, until the line fits
-    for k in ("cfg1", "esdf_build", "cpu_native", "single_batch_budget", "per_rank_traj_per_s", "accepted_after_retries_traj_per_s"):
+    for k in ("cfg1", "esdf_build", "cpu_native", "single_batch_budget", "single_batch_progress", "per_rank_traj_per_s",
+              "accepted_after_retries_traj_per_s"):
         if len(s) <= LINE_LIMIT:
             break
         line.pop(k, None)

@@ -295,6 +295,16 @@ int neo_profile_enable(neo_ctx *ctx, int on);
 /* optional DEVICE array [B] that the next neo_optimize_batch_dev launches fill with the number of
  * quadrature samples (ESDF lookups) each trajectory evaluated; NULL switches it off. */
 int neo_optimize_sample_counter(neo_ctx *ctx, int64_t *dev_counts);
+/* results as they finish (round 6).  One launch lasts as long as its LONGEST run (cfg2: 527 evaluations against a mean of
+ * 135) while 80 % of its trajectories are complete after ~2/3 of that time.  `counter` is a device-accessible int32 (device
+ * memory, or pinned host memory the device can add to) that the caller zeroes; every later neo_optimize_batch_dev /
+ * _from_dev launch on this context then adds 1 to it -- a system-scope release, after the trajectory's x, cost terms,
+ * counts and status are stored -- for each trajectory it completes.  A host that sees the counter reach k may copy the result
+ * arrays on another stream: the k finished trajectories are final (preset status[] to -1 to tell them apart, and copy status[]
+ * FIRST: a trajectory marked finished in that copy is final in every array copied after it), bit for bit what the
+ * completed launch leaves.  NULL switches it off.  Plain launches of optimize_kernel only (not the
+ * lane-group kernel, not budgeted launches -- which exist to END a launch early instead). */
+int neo_optimize_progress_counter(neo_ctx *ctx, int32_t *counter);
 /* diagnostics: optional DEVICE array [B][cap][4] that the next neo_optimize_batch[_dev] launches fill with one record
  * per counted evaluation of every trajectory -- (f, line-search step, quadrature samples, iteration) -- so that a run
  * can be laid beside the CPU optimiser's evaluation by evaluation (tools/classify_divergence.py); NULL switches it off.

@@ -1814,6 +1814,13 @@ int neo_eval_traj_batch(neo_ctx *c, int B, int M, int D, const double *x, const 
   return NEO_OK;
 }
 
+int neo_optimize_progress_counter(neo_ctx *c, int32_t *counter) {
+  if (!c) return NEO_ERR_INVALID;
+  std::lock_guard<std::recursive_mutex> g(c->mu);
+  c->progress = counter;
+  return NEO_OK;
+}
+
 int neo_optimize_sample_counter(neo_ctx *c, int64_t *dev_counts) {
   if (!c) return NEO_ERR_INVALID;
   std::lock_guard<std::recursive_mutex> g(c->mu);

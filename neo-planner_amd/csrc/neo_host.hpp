@@ -61,6 +61,7 @@ struct neo_ctx {
   bool profile = false;
   neo::ProfileSlot prof[NEO_KERNEL_COUNT];
   long long *sample_counter = nullptr;  // optional device array [B] (neo_optimize_sample_counter)
+  int *progress = nullptr;              // optional device-accessible counter of finished trajectories (neo_optimize_progress_counter)
   const int *dispatch_order = nullptr;  // optional device permutation [B] (neo_optimize_dispatch_order)
   int order_B = 0;                      // batch size the permutation was given for (ignored for any other B)
   double *trace = nullptr;              // optional device array [B][trace_cap][4] (neo_optimize_trace)

@@ -689,6 +689,8 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
       status[b] = NEO_TRAJ_BAD_SCENE;
       nit[b] = 0;
       nfev[b] = 0;
+      if constexpr (!BUDGET)  // (the progress counter counts every trajectory of the launch: below)
+        if (state != nullptr) __hip_atomic_fetch_add(reinterpret_cast<int *>(state), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     return;
   }
@@ -803,6 +805,14 @@ __global__ __launch_bounds__(kWave, (WAVES == 2 ? (sizeof(Num) == 4 && NS <= 2 ?
     nfev[b] = res.nfev;
     status[b] = st;
     if (nsamples) nsamples[b] = be.samples;
+  }
+  // Progress counter (neo_optimize_progress_counter, round 6; plain launches only -- their `state` argument carries it): one
+  // system-scope release add per finished trajectory, after every lane's result stores.  A host that polls the counter
+  // knows how many trajectories are complete while the launch's long runs are still going, and may read x / status of those
+  // (status[b] != NEO_TRAJ_RUNNING, preset by the caller) through a copy on another stream.
+  if constexpr (!BUDGET) {
+    if (state != nullptr && lane == 0)
+      __hip_atomic_fetch_add(reinterpret_cast<int *>(state), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

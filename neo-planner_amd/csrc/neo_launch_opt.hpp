@@ -48,7 +48,9 @@ int launch_opt(neo_ctx *c, const OptArgs &a) {
                        dyn, c->stream, n_launch, a.M, c->dev,                                                 \
                        static_cast<const MapT *>(a.table), a.slots, a.nmaps, a.x0 ? a.x0 : a.x, a.x, a.head, a.tail, a.costs4,   \
                        a.costs4_last, a.nit, a.nfev, a.status, c->sample_counter,                             \
-                       launch_order, c->trace, c->trace_xg, c->trace_cap, stage, pcr_off, a.state, a.state_doubles,  \
+                       launch_order, c->trace, c->trace_xg, c->trace_cap, stage, pcr_off,                     \
+                       BUDGET ? a.state : reinterpret_cast<double *>(c->progress) /* (plain launches: the progress counter) */, \
+                       a.state_doubles,                                                                       \
                        a.budget, a.resume, a.traj_total);                                                     \
   } while (0)
   // lane = (piece, dimension) whenever D * M fits the wavefront (cfg2: 63 lanes busy in the PIECE-layout phases

@@ -692,15 +692,19 @@ class BatchPlanner:
         out[out < 0] = rest
         return out.astype(np.int32)
 
-    def optimize_dev(self, map, x, head, tail, costs, costs_last, nit, nfev, status, slots=None, x0=None):
+    def optimize_dev(self, map, x, head, tail, costs, costs_last, nit, nfev, status, slots=None, x0=None, progress=None):
         """torch CUDA tensors (float64 / int32), asynchronous on the context's stream.
         `slots`: optional int32 device tensor of map-table slots (Context.lib.neo_scene_slot).
-        `x0`: optional start points (only read; results go to x) -- None: x is optimised in place."""
+        `x0`: optional start points (only read; results go to x) -- None: x is optimised in place.
+        `progress`: optional int32 device tensor (one element, zeroed by the caller) that counts the trajectories as they
+        finish (neo_optimize_progress_counter): poll it through a copy on another stream to use the finished results while
+        the launch's long runs are still going"""
         B, n = x.shape
         D = head.shape[2]
         M = (n + D) // (D + 1)
         c = self.ctx
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        c.check(c.lib.neo_optimize_progress_counter(c.h, p(progress)))
         c.check(c.lib.neo_optimize_batch_from_dev(c.h, map.scene_id, p(slots), B, M, D, p(x0 if x0 is not None else x),
                                                   p(x), p(head), p(tail), p(costs), p(costs_last), p(nit), p(nfev),
                                                   p(status)))

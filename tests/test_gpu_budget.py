@@ -89,3 +89,64 @@ def test_budget_api_edges():
     m2.occupancy_map_cb(synth.OccupancyGridMsg(synth.occupancy_2d(1)))
     assert ctx.lib.neo_optimize_batch_budget_dev(ctx.h, m2.scene_id, B, M, D, pp(x0), pp(x), pp(h), pp(tl), pp(costs), pp(last),
                                                  pp(nit), pp(nfev), pp(st), pp(state), 5, None, 0, 0) != 0
+
+
+@pytest.mark.parametrize("mode", ["f32x", "f64"])
+def test_progress_counter_finished_results_are_final_while_the_launch_runs(mode):
+    """neo_optimize_progress_counter (round 6): a plain launch counts its trajectories as they finish; what a host copies from
+    the result arrays on another stream once the counter says k are complete IS their final result -- x, cost terms, counts,
+    status bit for bit what the completed launch leaves -- and the launch computes the same bits with the counter as without"""
+    import torch
+    ctx, g3 = _scene("brick")
+    dev = torch.device("cuda", 0)
+    B, M, D = 3000, 21, 3
+    head, tail, wp, ts = synth.replan_requests(33, B, M - 1, D=3, **synth.VOLUME)
+    bp = npa.BatchPlanner(ctx=ctx, sample_dtype=mode)
+    bp._sync()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x0 = t(bp.pack_x(wp, ts)); hd = t(head); tl = t(tail)
+    n = x0.shape[1]
+
+    def bufs():
+        return dict(x=torch.empty_like(x0), costs=torch.zeros(B, 4, dtype=torch.float64, device=dev),
+                    last=torch.zeros(B, 4, dtype=torch.float64, device=dev), nit=torch.zeros(B, dtype=torch.int32, device=dev),
+                    nfev=torch.zeros(B, dtype=torch.int32, device=dev), status=torch.full((B,), -1, dtype=torch.int32, device=dev))
+    ref = bufs()
+    bp.optimize_dev(g3, ref["x"], hd, tl, ref["costs"], ref["last"], ref["nit"], ref["nfev"], ref["status"], x0=x0)
+    ctx.check(ctx.lib.neo_ctx_synchronize(ctx.h))
+    got = bufs()
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream()
+    h_cnt = torch.zeros(1, dtype=torch.int32).pin_memory()
+    snap = {k: torch.empty(v.shape, dtype=v.dtype).pin_memory() for k, v in got.items()}
+    torch.cuda.synchronize()
+    bp.optimize_dev(g3, got["x"], hd, tl, got["costs"], got["last"], got["nit"], got["nfev"], got["status"], x0=x0, progress=counter)
+    seen, snapped_at = [], None
+    with torch.cuda.stream(side):
+        for _ in range(200000):
+            h_cnt.copy_(counter, non_blocking=True)
+            side.synchronize()
+            k = int(h_cnt[0])
+            seen.append(k)
+            if snapped_at is None and k >= B // 2:
+                # status FIRST: a trajectory marked finished in that copy is final in every array copied after it (one that
+                # finishes between two copies shows in the later one only)
+                for name in ["status"] + [k_ for k_ in snap if k_ != "status"]:
+                    snap[name].copy_(got[name], non_blocking=True)
+                    side.synchronize()
+                snapped_at = k
+            if k >= B:
+                break
+    ctx.check(ctx.lib.neo_ctx_synchronize(ctx.h))
+    ctx.check(ctx.lib.neo_optimize_progress_counter(ctx.h, None))
+    assert seen[-1] == B and all(a <= b for a, b in zip(seen, seen[1:]))
+    for name in got:                       # the counter changes nothing
+        assert torch.equal(got[name], ref[name]), name
+    assert snapped_at is not None and B // 2 <= snapped_at <= B
+    done = snap["status"].numpy() != -1
+    assert int(done.sum()) >= snapped_at               # everything counted had landed (a few more may have by the time of the copy)
+    if snapped_at < B:
+        assert int(done.sum()) < B or seen[-1] == B    # (the snapshot was taken while the launch was still running, normally)
+    for name in got:
+        a, b = snap[name].numpy()[done], got[name].cpu().numpy()[done]
+        assert np.array_equal(a, b), (name, int((a != b).sum()))

@@ -299,6 +299,58 @@ def single_batch_budget_report(R, main_run):
                      "traj_per_s_done_after_first_launch": (B - (sizes[1] if len(sizes) > 1 else 0)) / (float(np.mean(first_ms)) * 1e-3),
                      "bit_identical_to_the_unbudgeted_launch": bool(same)})
     out["budgets"] = rows
+    # ---- round 6: results as they finish, from ONE plain launch (neo_optimize_progress_counter): the host polls a counter
+    # of finished trajectories through a side stream; when 80 % are in, it copies status and x of the whole batch -- the
+    # finished ones are final.  No suspension, no re-launch: the long runs go on undisturbed.
+    try:
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        h_cnt = torch.zeros(1, dtype=torch.int32).pin_memory()
+        h_st = torch.empty(B, dtype=torch.int32).pin_memory()
+        h_x = torch.empty(tuple(x.shape), dtype=torch.float64).pin_memory()
+        marks = (0.5, 0.8, 0.9, 0.99, 1.0)
+        times = {m_: [] for m_ in marks}
+        usable, ok_final = [], True
+        for rep in range(4):
+            counter.zero_(); st.fill_(-1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            bp.optimize_dev(R.g3, x, bt["head"], bt["tail"], costs, last, nit, nfev, st, x0=bt["x0"], progress=counter)
+            got_at = {}
+            snap_done = None
+            with torch.cuda.stream(side):
+                while True:
+                    h_cnt.copy_(counter, non_blocking=True)
+                    side.synchronize()
+                    k_ = int(h_cnt[0]); now = time.perf_counter()
+                    for m_ in marks:
+                        if m_ not in got_at and k_ >= m_ * B:
+                            got_at[m_] = now
+                            if m_ == 0.8:
+                                h_st.copy_(st, non_blocking=True); side.synchronize()       # (status first: tests/test_gpu_budget.py)
+                                h_x.copy_(x, non_blocking=True); side.synchronize()
+                                got_at["copied"] = time.perf_counter()
+                                snap_done = (h_st.numpy() != -1).copy(), h_x.numpy().copy()
+                    if k_ >= B:
+                        break
+            torch.cuda.synchronize()
+            if rep:
+                for m_ in marks:
+                    times[m_].append(1e3 * (got_at[m_] - t0))
+                usable.append((float(snap_done[0].mean()), 1e3 * (got_at["copied"] - t0)))
+            fin = x.cpu().numpy()
+            ok_final = ok_final and bool(np.array_equal(snap_done[1][snap_done[0]], fin[snap_done[0]]))
+        ctx.check(ctx.lib.neo_optimize_progress_counter(ctx.h, None))
+        same = all(torch.equal(a_, b_) for a_, b_ in zip(ref, (x, costs, last, nit, nfev, st)))
+        out["progress"] = {"what": "ONE plain launch of batch 0 with a progress counter (neo_optimize_progress_counter): wall clock from "
+                                   "the launch call until the polled counter passes each share of the batch; at 80 % the host copies "
+                                   "status and x (D2H, whole arrays) -- `usable_*`: share of the batch final on the host and when",
+                           "ms_until_share_finished": {str(m_): float(np.mean(v_)) for m_, v_ in times.items()},
+                           "usable_share_on_host": float(np.mean([u_[0] for u_ in usable])),
+                           "usable_on_host_ms": float(np.mean([u_[1] for u_ in usable])),
+                           "finished_results_were_final": ok_final, "bit_identical_to_the_launch_without_counter": bool(same)}
+    except Exception as ex:   # (the side file says what failed; the rest of the report stands)
+        out["progress"] = {"error": f"{type(ex).__name__}: {ex}"}
     ctx.set_stream(None)
     bp._sync()
     return out
