@@ -96,11 +96,12 @@ def parse(argv=None):
                          "(BatchPlanner.spatial_order) or index order; the other one is timed beside it")
     ap.add_argument("--planar", action="store_true", help="round-1 workload: every request in the plane z = 2 m, no canopy")
     ap.add_argument("--no-order", action="store_true", help="dispatch trajectories in index order everywhere")
-    ap.add_argument("--order", default="none", choices=["none", "effort"],
+    ap.add_argument("--order", default="auto", choices=["auto", "none", "effort"],
                     help="dispatch order of the PIPELINED steps: index order, or expected effort computed on the device inside the "
                          "timed region (neo_effort_order_dev).  With four launches in flight the order is worth less than its three "
                          "small launches cost (round 6, one box: 1.498 M traj/s without, 1.489 M with); launches that run alone "
-                         "(single_batch_*) always use it")
+                         "(single_batch_*) always use it.  auto: effort when a step has fewer batches than launches in flight "
+                         "(cfg3, cfg4: one launch a step runs alone), none otherwise")
     ap.add_argument("--lane-groups", action="store_true",
                     help="small problems (cfg3): eight trajectories per wavefront (NEO_FLAG_LANE_GROUPS)")
     ap.add_argument("--streams", type=int, default=4,
@@ -527,7 +528,7 @@ class Rank:
                 self.batches.append(dict(
                     st=st_, x0=x0, x=torch.empty_like(x0), head=torch.from_numpy(h_).to(dev), tail=torch.from_numpy(t_).to(dev),
                     order=torch.zeros(B, dtype=torch.int32, device=dev),
-                    okeys=torch.zeros(2 * B, dtype=torch.float64, device=dev), nsamp=torch.zeros(B, dtype=torch.int64, device=dev),
+                    okeys=torch.zeros(int(ctx.lib.neo_effort_order_scratch_bytes(B)) // 8 + 1, dtype=torch.float64, device=dev), nsamp=torch.zeros(B, dtype=torch.int64, device=dev),
                     # pinned host mirrors of what a caller reads back (`host_visible_traj_per_s`: time_mode(d2h=True))
                     h_x=torch.empty(B, n, dtype=torch.float64).pin_memory(), h_status=torch.empty(B, dtype=torch.int32).pin_memory(),
                     costs=torch.zeros(B, 4, dtype=torch.float64, device=dev), last=torch.zeros(B, 4, dtype=torch.float64, device=dev),
@@ -589,8 +590,8 @@ class Rank:
     def effort_order_dev(self, bt):
         """BatchPlanner.expected_effort_order on the device, from the batch's resident x0 / head / tail: time slack of the
         guess, sum(ts) v_max / distance, largest first (list scheduling: a long run that starts last is the launch's tail).
-        neo_effort_order_dev: three small launches on the batch's stream (a first version with torch -- sigmoid, norm, a stable
-        argsort: ~20 launches a batch -- cost the step 7 %)"""
+        neo_effort_order_dev: a keys kernel and a radix sort on the batch's stream (a first version with torch -- sigmoid, norm, a
+        stable argsort: ~20 launches a batch -- cost the step 7 %)"""
         ctx, pp = self.ctx, (lambda t: ctypes.c_void_p(t.data_ptr()))
         ctx.check(ctx.lib.neo_effort_order_dev(ctx.h, self.B, self.M, self.D, pp(bt["x0"]), pp(bt["head"]), pp(bt["tail"]),
                                                pp(bt["okeys"]), pp(bt["order"])))
@@ -599,7 +600,10 @@ class Rank:
         """ordered: dispatch the batch's workgroups in expected-effort order, computed on the device ahead of the launch
         (None: `--order`'s choice for the pipelined steps)"""
         torch, ctx, B = self.torch, self.ctx, self.B
-        ordered = (self.a.order == "effort") if ordered is None else (ordered and not self.a.no_order)
+        if ordered is None:
+            ordered = (self.a.order == "effort" or (self.a.order == "auto" and self.n_sets < self.n_lanes)) and not self.a.no_order
+        else:
+            ordered = ordered and not self.a.no_order
         ctx.set_stream(bt["st"].cuda_stream)
         ctx.check(ctx.lib.neo_optimize_sample_counter(ctx.h, ctypes.c_void_p(bt["nsamp"].data_ptr())))
         with torch.cuda.stream(bt["st"]):
@@ -854,7 +858,7 @@ def main():
             "host_visible_traj_per_s": (B * n_sets * a.steps / host_visible) if host_visible else None,
             # kernel-experiment flags ORed into neo_params.flags of the timed runs (environment NEO_BENCH_FLAGS_OR); normally 0
             "flags_or": int(os.environ.get("NEO_BENCH_FLAGS_OR", "0")),
-            "dispatch_order": {"pipelined_steps": "index order" if (a.no_order or a.order == "none")
+            "dispatch_order": {"pipelined_steps": "index order" if (a.no_order or a.order == "none" or (a.order == "auto" and n_sets >= R.n_lanes))
                                else "expected effort, computed on the device inside the timed region (neo_effort_order_dev)",
                                "launches_alone": "index order" if a.no_order else "expected effort, computed on the device ahead of the launch"},
             # what a caller with ONE request batch gets: a single launch of B trajectories alone on the chip (`value` keeps

@@ -327,9 +327,11 @@ int neo_optimize_trace_xg(neo_ctx *ctx, double *dev_xg, int cap);
 int neo_optimize_dispatch_order(neo_ctx *ctx, const int32_t *dev_order, int B);
 /* the expected-effort order computed ON THE DEVICE from a batch's resident start points (round 6): key = time slack of the
  * guess, sum(T) v_max / |goal - start|, largest first, ties by index -- what neo_planner_amd.BatchPlanner.expected_effort_order
- * computes on the host.  Three small launches on the context's stream; `scratch` (16 B bytes, 8-byte aligned: the B keys as
- * doubles, then B ranks) and order[B] are the caller's device buffers (several batches in flight on several streams: one pair
- * per batch).  Hand `order` to neo_optimize_dispatch_order. */
+ * computes on the host: a keys kernel and a stable descending radix sort (rocPRIM) on the context's stream.  `scratch`
+ * (neo_effort_order_scratch_bytes(B) bytes, 256-byte aligned; the B keys stay in its first B doubles) and order[B] are the
+ * caller's device buffers (several batches in flight on several streams: one pair per batch).  Hand `order` to
+ * neo_optimize_dispatch_order. */
+size_t neo_effort_order_scratch_bytes(int B);
 int neo_effort_order_dev(neo_ctx *ctx, int B, int M, int D, const double *x0, const double *head, const double *tail,
                          void *scratch, int32_t *order);
 /* the same from a HOST permutation (copied into a context-owned device buffer); NULL or B = 0 resets.

@@ -8,6 +8,7 @@
 // neo_disp_*.hip translation units.
 #include <cstring>
 #include "neo_host.hpp"
+#include <rocprim/device/device_radix_sort.hpp>
 #include "neo_kernels.hpp"
 
 namespace neo {
@@ -1921,10 +1922,10 @@ namespace neo {
 // iterations: rank correlation 0.5 with the evaluation count at cfg2); NaN -> 0 so that the keys are totally ordered
 __global__ void effort_keys_kernel(int B, int M, int D, double T_min, double T_max, double v_max, const double *__restrict__ x0,
                                    const double *__restrict__ head, const double *__restrict__ tail, double *__restrict__ keys,
-                                   int *__restrict__ ranks) {
+                                   int *__restrict__ idx) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  ranks[b] = 0;
+  idx[b] = b;
   const int nq = D * (M - 1), n = nq + M;
   double sum = 0.0;
   for (int p = 0; p < M; ++p) sum += (T_max - T_min) / (1.0 + exp(-x0[(size_t)b * n + nq + p])) + T_min;  // map_tau2T (:477-483)
@@ -1936,50 +1937,41 @@ __global__ void effort_keys_kernel(int B, int M, int D, double T_min, double T_m
   const double k = sum * v_max / fmax(sqrt(d2), 1e-9);
   keys[b] = (k == k) ? k : 0.0;
 }
-// order[rank(i)] = i with rank(i) = #{j : key_j > key_i, or key_j == key_i and j < i}: the stable descending sort as B^2
-// comparisons, no temporary memory beyond the ranks, a permutation by construction (4096 keys: 17 M comparisons).  The
-// comparisons are tiled over a 2-D grid -- element block x key tile -- so that a batch of 4096 is 128 workgroups, not 16 (a
-// first version with one thread per element and a loop over all keys took ~45 us on 16 CUs); partial counts meet in integer
-// adds (exact in any order).
-constexpr int kRankTile = 512;
-__global__ __launch_bounds__(256) void rank_partial_kernel(int B, const double *__restrict__ keys, int *__restrict__ ranks) {
-  __shared__ double tile[kRankTile];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, j0 = blockIdx.y * kRankTile;
-  for (int t = threadIdx.x; t < kRankTile; t += blockDim.x) tile[t] = j0 + t < B ? keys[j0 + t] : -1.0;  // (keys are >= 0)
-  __syncthreads();
-  if (i >= B) return;
-  const double ki = keys[i];
-  const int m = min(kRankTile, B - j0);
-  int cnt = 0;
-  for (int t = 0; t < m; ++t) {
-    const double kj = tile[t];
-    cnt += (kj > ki || (kj == ki && j0 + t < i)) ? 1 : 0;
-  }
-  if (cnt) atomicAdd(&ranks[i], cnt);
-}
-__global__ void rank_scatter_kernel(int B, const int *__restrict__ ranks, int *__restrict__ order) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) order[ranks[i]] = i;
-}
 }  // namespace neo
+
+// The order itself: a stable descending sort of (key, index) -- rocPRIM's radix sort on the doubles (LSD radix: equal keys
+// keep index order).  Round 6 first ranked by B^2 comparisons (one thread per element: 45 us at 4096 on 16 CUs; tiled over a
+// 2-D grid with integer partial counts: three launches, fine at 4096, 0.6 ms at cfg3's 65 536).
+static size_t effort_sort_temp_bytes(int B) {
+  size_t tb = 0;
+  (void)rocprim::radix_sort_pairs_desc(nullptr, tb, (const double *)nullptr, (double *)nullptr, (const int *)nullptr, (int *)nullptr,
+                                       (unsigned)B, 0, 64, (hipStream_t)0);
+  return (tb + 255) / 256 * 256;
+}
+
+size_t neo_effort_order_scratch_bytes(int B) {
+  if (B <= 0) return 0;
+  // keys in, keys out (doubles), indices in (ints, padded to 8 B), the sort's temporary storage
+  return (size_t)B * 16 + ((size_t)B * 4 + 255) / 256 * 256 + effort_sort_temp_bytes(B);
+}
 
 int neo_effort_order_dev(neo_ctx *c, int B, int M, int D, const double *x0, const double *head, const double *tail, void *scratch,
                          int32_t *order) {
   int rc = check_shape(c, B, M, D);
   if (rc) return rc;
   if (!x0 || !head || !tail || !scratch || !order) return fail_locked(c, NEO_ERR_INVALID, "null buffer");
-  if (((uintptr_t)scratch) & 7) return fail_locked(c, NEO_ERR_INVALID, "scratch must be 8-byte aligned");
+  if (((uintptr_t)scratch) & 255) return fail_locked(c, NEO_ERR_INVALID, "scratch must be 256-byte aligned");
   if (B == 0) return NEO_OK;
   std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
-  double *keys = static_cast<double *>(scratch);
-  int *ranks = reinterpret_cast<int *>(keys + B);
-  const unsigned gb = (unsigned)((B + 255) / 256);
-  hipLaunchKernelGGL(neo::effort_keys_kernel, dim3(gb), dim3(256), 0, c->stream, B, M, D, c->params.T_min, c->params.T_max,
-                     c->params.v_max, x0, head, tail, keys, ranks);
-  hipLaunchKernelGGL(neo::rank_partial_kernel, dim3(gb, (unsigned)((B + neo::kRankTile - 1) / neo::kRankTile)), dim3(256), 0, c->stream,
-                     B, keys, ranks);
-  hipLaunchKernelGGL(neo::rank_scatter_kernel, dim3(gb), dim3(256), 0, c->stream, B, ranks, order);
+  double *keys = static_cast<double *>(scratch), *keys_out = keys + B;
+  int *idx = reinterpret_cast<int *>(keys_out + B);
+  void *temp = reinterpret_cast<char *>(scratch) + (size_t)B * 16 + ((size_t)B * 4 + 255) / 256 * 256;
+  size_t tb = effort_sort_temp_bytes(B);
+  hipLaunchKernelGGL(neo::effort_keys_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, c->stream, B, M, D, c->params.T_min,
+                     c->params.T_max, c->params.v_max, x0, head, tail, keys, idx);
+  HIPCHK(c, rocprim::radix_sort_pairs_desc(temp, tb, (const double *)keys, keys_out, (const int *)idx, (int *)order, (unsigned)B, 0, 64,
+                                           c->stream));
   HIPCHK(c, hipGetLastError());
   return NEO_OK;
 }

@@ -34,7 +34,7 @@ EXPORTS = [
     "neo_optimize_batch_from_dev", "neo_optimize_trace_xg", "neo_sampled_terms_dispatch_order",
     "neo_esdf_build_config", "neo_pack_results_dev", "neo_optimize_state_bytes", "neo_optimize_batch_budget_dev",
     "neo_sampled_terms_batch_f32", "neo_sampled_terms_batch_f32_dev", "neo_effort_order_dev",
-    "neo_optimize_progress_counter",
+    "neo_optimize_progress_counter", "neo_effort_order_scratch_bytes",
 ]
 
 
@@ -116,6 +116,8 @@ def load():
     L.neo_sampled_terms_batch_f32_dev.argtypes = [c_p, c_i, c_i, c_i, c_i] + [c_p] * 5
     L.neo_effort_order_dev.argtypes = [c_p, c_i, c_i, c_i] + [c_p] * 5
     L.neo_optimize_progress_counter.argtypes = [c_p, c_p]
+    L.neo_effort_order_scratch_bytes.argtypes = [c_i]
+    L.neo_effort_order_scratch_bytes.restype = ctypes.c_size_t
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int or name in ("neo_abi_version",):

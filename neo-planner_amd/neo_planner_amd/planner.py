@@ -633,8 +633,8 @@ class BatchPlanner:
         return np.argsort(-slack, kind="stable").astype(np.int32)
 
     def expected_effort_order_dev(self, x0, head, tail):
-        """the same order computed on the device from RESIDENT torch tensors x0 (B, n), head / tail (B, 3, D) -- two launches
-        on the context's stream (neo_effort_order_dev); returns (order int32 [B], keys float64 [B]) device tensors"""
+        """the same order computed on the device from RESIDENT torch tensors x0 (B, n), head / tail (B, 3, D) -- a keys kernel
+        and a radix sort on the context's stream (neo_effort_order_dev); returns (order int32 [B], keys float64 [B]) device tensors"""
         import ctypes
         import torch
         self._sync()
@@ -642,7 +642,7 @@ class BatchPlanner:
         B, n = x0.shape
         D = head.shape[2]
         M = (n + D) // (D + 1)
-        scratch = torch.empty(2 * B, dtype=torch.float64, device=x0.device)     # keys, then the ranks
+        scratch = torch.empty(int(c.lib.neo_effort_order_scratch_bytes(B)) // 8 + 1, dtype=torch.float64, device=x0.device)   # (keys first)
         order = torch.empty(B, dtype=torch.int32, device=x0.device)
         pp = lambda t: ctypes.c_void_p(t.data_ptr())
         c.check(c.lib.neo_effort_order_dev(c.h, B, M, D, pp(x0), pp(head), pp(tail), pp(scratch), pp(order)))
