@@ -563,6 +563,67 @@ class BatchPlanner:
                     status=stn & 0xff, collision=(stn & _lib.NEO_TRAJ_FLAG_COLLISION) != 0, final_cost=(cn_ * w).sum(axis=1),
                     launch_sizes=sizes)
 
+    def optimize_progressive(self, map, x0, head, tail, shares=(0.8,)):
+        """`optimize` as a generator that hands results over as they finish (round 6, neo_optimize_progress_counter): ONE plain
+        launch; the host polls the launch's counter of finished trajectories through a side stream and, each time it passes
+        the next share of the batch, copies status first and then the results -- what status marks finished is final.
+        Yields (indices, dict) -- indices int64 of the trajectories first seen finished, dict with their x, costs, costs_last,
+        nit, nfev, status, collision, final_cost -- once per share and once more for the rest when the launch has ended.
+        Every trajectory is yielded exactly once, with the bits `optimize` returns for it."""
+        import torch
+        c = self.ctx
+        self._sync()
+        dev = torch.device("cuda", c.device)
+        x0 = _lib.as_f64(x0); head = _lib.as_f64(head); tail = _lib.as_f64(tail)
+        B, n = x0.shape
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        d_x0, d_h, d_t = t(x0), t(head), t(tail)
+        bufs = dict(x=torch.empty_like(d_x0), costs=torch.zeros(B, 4, dtype=torch.float64, device=dev),
+                    costs_last=torch.zeros(B, 4, dtype=torch.float64, device=dev), nit=torch.zeros(B, dtype=torch.int32, device=dev),
+                    nfev=torch.zeros(B, dtype=torch.int32, device=dev), status=torch.full((B,), -1, dtype=torch.int32, device=dev))
+        host = {k: torch.empty(tuple(v.shape), dtype=v.dtype).pin_memory() for k, v in bufs.items()}
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        h_cnt = torch.zeros(1, dtype=torch.int32).pin_memory()
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize(dev)        # (the context has its own stream: the buffers above are ready before it starts)
+        w = np.asarray(self.cfg.weights, dtype=np.float64)
+        seen = np.zeros(B, dtype=bool)
+
+        def snapshot():
+            with torch.cuda.stream(side):
+                for k in ["status"] + [k_ for k_ in bufs if k_ != "status"]:     # status FIRST (include/neo_planner.h)
+                    host[k].copy_(bufs[k], non_blocking=True)
+                    side.synchronize()
+            st = host["status"].numpy()
+            new = np.flatnonzero((st != -1) & ~seen)
+            seen[new] = True
+            cn_ = host["costs"].numpy()[new]
+            return new, dict(x=host["x"].numpy()[new].copy(), costs=cn_.copy(), costs_last=host["costs_last"].numpy()[new].copy(),
+                             nit=host["nit"].numpy()[new].copy(), nfev=host["nfev"].numpy()[new].copy(), status=st[new] & 0xff,
+                             collision=(st[new] & _lib.NEO_TRAJ_FLAG_COLLISION) != 0, final_cost=(cn_ * w).sum(axis=1))
+
+        try:
+            self.optimize_dev(map, bufs["x"], d_h, d_t, bufs["costs"], bufs["costs_last"], bufs["nit"], bufs["nfev"],
+                              bufs["status"], x0=d_x0, progress=counter)
+            for share in sorted(float(s_) for s_ in shares):
+                need = min(B, int(np.ceil(share * B)))
+                while True:
+                    with torch.cuda.stream(side):
+                        h_cnt.copy_(counter, non_blocking=True)
+                        side.synchronize()
+                    if int(h_cnt[0]) >= need:
+                        break
+                new, res = snapshot()
+                if new.size:
+                    yield new, res
+            c.synchronize()
+            new, res = snapshot()
+            if new.size:
+                yield new, res
+        finally:
+            c.synchronize()
+            c.check(c.lib.neo_optimize_progress_counter(c.h, None))
+
     def init_guess(self, head, tail, count, rng=None, noise=0.0):
         """generate_init_variables (:82-101) for a batch: `count` waypoints on the straight line from start to target,
         durations init_T with the first and last piece 1.5 times as long; noise > 0 adds the N(0, noise) jitter of the

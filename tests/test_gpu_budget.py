@@ -150,3 +150,25 @@ def test_progress_counter_finished_results_are_final_while_the_launch_runs(mode)
     for name in got:
         a, b = snap[name].numpy()[done], got[name].cpu().numpy()[done]
         assert np.array_equal(a, b), (name, int((a != b).sum()))
+
+
+def test_optimize_progressive_yields_every_trajectory_once_with_optimize_s_bits():
+    """BatchPlanner.optimize_progressive: the host-array generator on the progress counter"""
+    ctx, g3 = _scene("brick")
+    B, M = 2500, 21
+    head, tail, wp, ts = synth.replan_requests(44, B, M - 1, D=3, **synth.VOLUME)
+    bp = npa.BatchPlanner(ctx=ctx, sample_dtype="f32x")
+    x0 = bp.pack_x(wp, ts)
+    ref = bp.optimize(g3, x0, head, tail, order=False)
+    got = {k: np.zeros_like(v) for k, v in ref.items()}
+    count = np.zeros(B, dtype=np.int64)
+    chunks = []
+    for idx, res in bp.optimize_progressive(g3, x0, head, tail, shares=(0.5, 0.8, 0.95)):
+        count[idx] += 1
+        chunks.append(int(idx.size))
+        for k in ref:
+            got[k][idx] = res[k]
+    assert np.all(count == 1) and sum(chunks) == B
+    assert chunks[0] >= B // 2 and len(chunks) >= 2            # (the first hand-over holds at least half of the batch)
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
