@@ -648,7 +648,8 @@ class Rank:
         num = "float" if a.dtype == "f32x" else "double"
         lookup = f"neo::Lookup3D<{real}, {elem}, {lay}>"
         if name == "sample_kernel":
-            return f"void neo::sample_kernel<{D}, {real}, neo::Map3D, {lookup} >"
+            io = "double" if a.dtype == "f64" else "float"      # (round 6: fp32 operand buffers on the fp32 sampling path)
+            return f"void neo::sample_kernel<{D}, {real}, neo::Map3D, {lookup}, {io}>"
         if name == "optimize_kernel":
             ns = min(max((self.n + 63) // 64, 1), 4)
             lg = f"neo::WaveLanesPD<{D}>" if D * M <= 64 else "neo::WaveLanes"
