@@ -41,6 +41,15 @@ OP1(v_fmac_f32, "v_fmac_f32 %0, %1, %2")
 OP1(v_mul_f32, "v_mul_f32 %0, %0, %1")
 OP1(v_fma_f32_sgpr, "v_fma_f32 %0, %0, s20, %2")
 OP1(v_max_f32, "v_max_f32 %0, %0, %1")
+OP1(v_mul_f32_literal, "v_mul_f32 %0, 0x40a00000, %0")
+OP1(v_mul_f32_inline_const, "v_mul_f32 %0, 2.0, %0")
+OP1(v_fma_f32_inline_const, "v_fma_f32 %0, %0, 2.0, %2")
+OP1(v_fmac_f32_sgpr, "v_fmac_f32 %0, s20, %1")
+OP1(v_add_f32_sgpr, "v_add_f32 %0, s20, %0")
+OP1(v_mul_f32_sgpr, "v_mul_f32 %0, s20, %0")
+OP1(v_add_f32, "v_add_f32 %0, %0, %1")
+OP1(v_cmp_lt_i32, "v_cmp_lt_i32 vcc, %0, %1")
+OP1(v_min_f32, "v_min_f32 %0, %0, %1")
 OP1(v_cvt_f32_f64ish, "v_cvt_f32_u32 %0, %0")
 OP1(v_mov_b32, "v_mov_b32 %0, %1")
 OP1(v_mbcnt_lo, "v_mbcnt_lo_u32_b32 %0, %1, %0")
@@ -113,6 +122,9 @@ int main() {
   run<v_cndmask_sgpr_mask>(); run<v_cmp_then_cndmask>(); run<v_cmp_sgpr_then_cndmask>();
   printf("-- lane operations and the fp32 pipe:\n");
   run<v_add_f32_dpp>(); run<v_mov_b32_dpp>(); run<v_readlane>(); run<v_fmac_f32>(); run<v_mul_f32>(); run<v_fma_f32_sgpr>(); run<v_max_f32>();
+  printf("-- constants and scalar operands on the fp32 pipe:\n");
+  run<v_mul_f32_literal>(); run<v_mul_f32_inline_const>(); run<v_fma_f32_inline_const>(); run<v_fmac_f32_sgpr>();
+  run<v_add_f32_sgpr>(); run<v_mul_f32_sgpr>(); run<v_add_f32>(); run<v_cmp_lt_i32>(); run<v_min_f32>();
   run<v_cvt_f32_f64ish>();
   return 0;
 }
