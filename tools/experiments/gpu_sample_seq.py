@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Round 6: the ESDF-lookup kernel's sequence body (neo_sample_seq.hpp) against the round-4 body (flags bit 8192) and the fp64
+"""(Needs the experiment library of tools/probe/seq/README.md: the product has no sequence body and no flags bit 8192.)
+Round 6: the ESDF-lookup kernel's sequence body (neo_sample_seq.hpp) against the round-4 body (flags bit 8192) and the fp64
 kernel on bench.py's cfg2 batch 0 at the initial guess (brick layout, spatial dispatch order): agreement trajectory by
 trajectory, bit reproducibility, independence of the dispatch order, and launch durations -- one launch per HIP-event pair
 (what bench.py's `esdf_kernel` reported up to round 5) and K launches back to back between ONE pair.
