@@ -1949,10 +1949,12 @@ static size_t effort_sort_temp_bytes(int B) {
   return (tb + 255) / 256 * 256;
 }
 
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
 size_t neo_effort_order_scratch_bytes(int B) {
   if (B <= 0) return 0;
-  // keys in, keys out (doubles), indices in (ints, padded to 8 B), the sort's temporary storage
-  return (size_t)B * 16 + ((size_t)B * 4 + 255) / 256 * 256 + effort_sort_temp_bytes(B);
+  // keys in, keys out (doubles), indices in (ints), the sort's temporary storage: every part 256-byte aligned
+  return align256((size_t)B * 16) + align256((size_t)B * 4) + effort_sort_temp_bytes(B);
 }
 
 int neo_effort_order_dev(neo_ctx *c, int B, int M, int D, const double *x0, const double *head, const double *tail, void *scratch,
@@ -1965,8 +1967,8 @@ int neo_effort_order_dev(neo_ctx *c, int B, int M, int D, const double *x0, cons
   std::lock_guard<std::recursive_mutex> g(c->mu);
   hipSetDevice(c->device);
   double *keys = static_cast<double *>(scratch), *keys_out = keys + B;
-  int *idx = reinterpret_cast<int *>(keys_out + B);
-  void *temp = reinterpret_cast<char *>(scratch) + (size_t)B * 16 + ((size_t)B * 4 + 255) / 256 * 256;
+  int *idx = reinterpret_cast<int *>(reinterpret_cast<char *>(scratch) + align256((size_t)B * 16));
+  void *temp = reinterpret_cast<char *>(idx) + align256((size_t)B * 4);
   size_t tb = effort_sort_temp_bytes(B);
   hipLaunchKernelGGL(neo::effort_keys_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, c->stream, B, M, D, c->params.T_min,
                      c->params.T_max, c->params.v_max, x0, head, tail, keys, idx);
